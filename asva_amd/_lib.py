@@ -1,0 +1,94 @@
+"""ctypes binding of libavsd_hip.so (declared in include/avsd.h).
+
+The library is the only compute path: there is no fallback.  Importing this module is cheap; the
+shared object is loaded on first use and a missing/unbuilt library raises immediately.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libavsd_hip.so")
+
+c_void_p, c_int, c_float, c_int64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
+
+
+class GemmDesc(C.Structure):
+    """Mirror of `avsd_gemm_desc` (include/avsd.h)."""
+
+    _fields_ = [
+        ("A", c_void_p), ("A2", c_void_p), ("W", c_void_p), ("out", c_void_p),
+        ("bias", c_void_p), ("rowvec", c_void_p), ("res1", c_void_p), ("res2", c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("lda", C.c_int32), ("lda2", C.c_int32), ("k_split", C.c_int32), ("ldw", C.c_int32),
+        ("ldc", C.c_int32), ("ldr1", C.c_int32), ("ldr2", C.c_int32),
+        ("rows_per_vec", C.c_int32), ("ldv", C.c_int32),
+        ("alpha", C.c_float),
+        ("mode", C.c_int32), ("flags", C.c_int32), ("batch", C.c_int32),
+        ("batch_stride_a", C.c_int64), ("batch_stride_w", C.c_int64), ("batch_stride_out", C.c_int64),
+        ("hw", C.c_int32), ("frames", C.c_int32), ("cseg", C.c_int32),
+        ("hs", C.c_int32), ("ws", C.c_int32), ("ho", C.c_int32), ("wo", C.c_int32),
+        ("cin", C.c_int32), ("stride", C.c_int32), ("ups", C.c_int32),
+        ("tile", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); exactly the symbols include/avsd.h declares
+SIGNATURES = {
+    "avsd_abi_version": (c_int, []),
+    "avsd_last_error": (C.c_char_p, []),
+    "avsd_device_info": (c_int, [C.c_char_p, c_int, C.POINTER(c_int)]),
+    "avsd_gemm_bf16": (c_int, [C.POINTER(GemmDesc), c_void_p]),
+    "avsd_sizeof_gemm_desc": (c_int, []),
+    "avsd_linear_small_m": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "avsd_groupnorm_stats": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "avsd_groupnorm_apply": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                                     c_void_p, c_void_p, c_float, c_int, c_void_p, c_int, c_void_p]),
+    "avsd_groupnorm_nchunks": (c_int, [c_int, c_int, c_int]),
+    "avsd_layernorm": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p]),
+    "avsd_softmax_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "avsd_attention": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                               c_int, c_int, c_int, c_void_p, c_int, c_float, c_void_p]),
+    "avsd_temporal_attention": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "avsd_ncfhw_to_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "avsd_rows_to_ncfhw": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "avsd_timestep_embedding": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "avsd_guided_step": (c_int, [c_void_p, c_int, c_float, c_void_p, c_int, c_float, C.POINTER(C.c_int32), C.POINTER(C.c_float),
+                                 c_int, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_int, c_void_p]),
+    "avsd_vae_postprocess": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+class AvsdError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Loads libavsd_hip.so (once).  Raises if it has not been built — there is no CPU path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AvsdError(
+                f"{LIB_PATH} not found: build it with `python -m asva_amd.build` "
+                "(hipcc --offload-arch=gfx950).  asva_amd has no fallback compute path."
+            )
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if handle.avsd_sizeof_gemm_desc() != C.sizeof(GemmDesc):
+            raise AvsdError(
+                f"avsd_gemm_desc layout mismatch: C {handle.avsd_sizeof_gemm_desc()} B vs ctypes {C.sizeof(GemmDesc)} B"
+            )
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().avsd_last_error()
+        raise AvsdError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,211 @@
+// Small / elementwise kernels: layout conversion at the NCFHW boundary, sinusoidal timestep
+// embedding, skinny (M <= 32) linear layers, the fused guidance + scheduler update and the VAE
+// post-processing.  All HBM- or latency-bound; none is worth an MFMA.
+//
+// Reference: audio_cond_unet_3d_condition.py:673-681 (time embedding), ff_spatio_temp_resnet_3d.py:170
+// (time_emb_proj), ff_spatio_audio_temp_transformer_3d.py:348-349 (temporal position MLP),
+// pipeline_audio_cond_animation.py:331-337 (latent duplication), :349-364 (guidance, scheduler.step on
+// frames 1..), :206-213 (decode post-processing).  diffusers 0.29.2 get_timestep_embedding /
+// PNDMScheduler.step_plms / DDIMScheduler.step supply the formulas.
+#include "avsd_common.h"
+
+namespace {
+
+__global__ void ncfhw_to_rows_kernel(const float* src, bf16_t* dst, int B, int C, int F, int HW, int cpad,
+                                     int rep, float scale) {
+  // one thread per (rep, b, f, p); writes cpad channels
+  const int64_t n = (int64_t)rep * B * F * HW;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int p = (int)(i % HW);
+    const int f = (int)((i / HW) % F);
+    const int b = (int)((i / ((int64_t)HW * F)) % B);
+    bf16_t* o = dst + i * cpad;
+    for (int c = 0; c < cpad; ++c) {
+      float v = 0.f;
+      if (c < C) v = src[(((int64_t)b * C + c) * F + f) * HW + p] * scale;
+      o[c] = f2bf(v);
+    }
+  }
+}
+
+__global__ void rows_to_ncfhw_kernel(const float* src, int ld, float* dst, int B, int C, int F, int HW) {
+  const int64_t n = (int64_t)B * C * F * HW;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int p = (int)(i % HW);
+    const int f = (int)((i / HW) % F);
+    const int c = (int)((i / ((int64_t)HW * F)) % C);
+    const int b = (int)(i / ((int64_t)HW * F * C));
+    dst[i] = src[(((int64_t)b * F + f) * HW + p) * ld + c];
+  }
+}
+
+__global__ void timestep_embedding_kernel(const float* t, float* out, int n, int dim) {
+  const int half = dim / 2;
+  const int i = blockIdx.x;
+  const float tv = t[i];
+  for (int j = threadIdx.x; j < half; j += blockDim.x) {
+    const float w = expf(-9.210340371976184f * (float)j / (float)half);  // ln(10000)
+    const float a = tv * w;
+    out[(int64_t)i * dim + j] = cosf(a);          // flip_sin_to_cos: cos half first
+    out[(int64_t)i * dim + half + j] = sinf(a);
+  }
+}
+
+// out[m, n] = act_out(sum_k act_in(x[m, k]) * W[n, k] + bias[n]); one wave per n, 8 rows per block.y
+__global__ __launch_bounds__(256) void linear_small_m_kernel(const float* x, const bf16_t* W, const float* bias,
+                                                             float* out, int M, int N, int K, int ldw, int act_in,
+                                                             int act_out) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int m0 = blockIdx.y * 8;
+  const int mcount = min(8, M - m0);
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  const bf16_t* wrow = W + (int64_t)n * ldw;
+  for (int k = lane * 8; k < K; k += 512) {
+    float w[8];
+    unpack8(*reinterpret_cast<const uint4*>(wrow + k), w);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (i < mcount) {
+        const float* xr = x + (int64_t)(m0 + i) * K + k;
+        const float4 a0 = *reinterpret_cast<const float4*>(xr);
+        const float4 a1 = *reinterpret_cast<const float4*>(xr + 4);
+        float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xv = act_in ? silu_f(a[e]) : a[e];
+          acc[i] = fmaf(xv, w[e], acc[i]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float v = wave_sum(acc[i]);
+    if (lane == 0 && i < mcount) {
+      float r = v + (bias ? bias[n] : 0.f);
+      if (act_out) r = silu_f(r);
+      out[(int64_t)(m0 + i) * N + n] = r;
+    }
+  }
+}
+
+struct GuidedArgs {
+  const float* noise_pred; float* eps_hist; const float* x_in; float* x_out;
+  int n_branch, store_slot, n_hist;
+  int hist_idx[4];
+  float w[4];
+  float g, w_cur, ca, cb;
+  int B, C, F, HW;
+};
+
+__global__ void guided_step_kernel(const GuidedArgs a) {
+  const int64_t per = (int64_t)a.B * a.C * a.F * a.HW;   // elements of one latent tensor
+  const int64_t fhw = (int64_t)a.F * a.HW;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.x * blockDim.x) {
+    float eps = a.noise_pred[i];
+    if (a.n_branch == 2) eps = eps + a.g * (a.noise_pred[per + i] - eps);
+    if (a.eps_hist && a.store_slot >= 0) a.eps_hist[(int64_t)a.store_slot * per + i] = eps;
+    float e = a.w_cur * eps;
+    for (int k = 0; k < a.n_hist; ++k) {
+      // the freshly stored slot is read back from the register copy
+      const float h = (a.hist_idx[k] == a.store_slot) ? eps : a.eps_hist[(int64_t)a.hist_idx[k] * per + i];
+      e = fmaf(a.w[k], h, e);
+    }
+    const int f = (int)((i % fhw) / a.HW);
+    const float xin = a.x_in[i];
+    a.x_out[i] = (f == 0) ? xin : fmaf(a.ca, xin, a.cb * e);
+  }
+}
+
+__global__ void vae_postprocess_kernel(const bf16_t* src, int ld, float* dst, int N, int HW) {
+  const int64_t n = (int64_t)N * 3 * HW;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int p = (int)(i % HW);
+    const int c = (int)((i / HW) % 3);
+    const int im = (int)(i / ((int64_t)3 * HW));
+    const float v = bf2f(src[((int64_t)im * HW + p) * ld + c]) * 0.5f + 0.5f;
+    dst[i] = fminf(fmaxf(v, 0.f), 1.f);
+  }
+}
+
+inline unsigned grid_for(int64_t n, int block) {
+  int64_t g = (n + block - 1) / block;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" int avsd_ncfhw_to_rows(const float* src, void* dst, int B, int C, int F, int HW, int cpad, int rep,
+                                  float scale, void* stream) {
+  AVSD_REQUIRE(src && dst && B > 0 && C > 0 && F > 0 && HW > 0 && cpad >= C && rep >= 1, "ncfhw_to_rows: bad arguments");
+  const int64_t n = (int64_t)rep * B * F * HW;
+  hipLaunchKernelGGL(ncfhw_to_rows_kernel, dim3(grid_for(n, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     src, (bf16_t*)dst, B, C, F, HW, cpad, rep, scale);
+  AVSD_CHECK_LAUNCH("ncfhw_to_rows launch");
+  return AVSD_OK;
+}
+
+extern "C" int avsd_rows_to_ncfhw(const float* src, int ld, float* dst, int B, int C, int F, int HW, void* stream) {
+  AVSD_REQUIRE(src && dst && B > 0 && C > 0 && F > 0 && HW > 0 && ld >= C, "rows_to_ncfhw: bad arguments");
+  const int64_t n = (int64_t)B * C * F * HW;
+  hipLaunchKernelGGL(rows_to_ncfhw_kernel, dim3(grid_for(n, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     src, ld, dst, B, C, F, HW);
+  AVSD_CHECK_LAUNCH("rows_to_ncfhw launch");
+  return AVSD_OK;
+}
+
+extern "C" int avsd_timestep_embedding(const float* t, float* out, int n, int dim, void* stream) {
+  AVSD_REQUIRE(t && out && n > 0 && dim > 0 && dim % 2 == 0, "timestep_embedding: bad arguments");
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((unsigned)n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), t,
+                     out, n, dim);
+  AVSD_CHECK_LAUNCH("timestep_embedding launch");
+  return AVSD_OK;
+}
+
+extern "C" int avsd_linear_small_m(const float* x, const void* W, const float* bias, float* out, int M, int N, int K,
+                                   int ldw, int act_in, int act_out, void* stream) {
+  AVSD_REQUIRE(x && W && out, "linear_small_m: null pointer");
+  AVSD_REQUIRE(M > 0 && M <= 64 && N > 0 && K > 0 && K % 8 == 0 && ldw % 8 == 0 && ldw >= K,
+               "linear_small_m: need 0 < M <= 64, K %% 8 == 0, ldw %% 8 == 0 (M=%d N=%d K=%d ldw=%d)", M, N, K, ldw);
+  dim3 grid((unsigned)((N + 3) / 4), (unsigned)((M + 7) / 8));
+  hipLaunchKernelGGL(linear_small_m_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+                     (const bf16_t*)W, bias, out, M, N, K, ldw, act_in, act_out);
+  AVSD_CHECK_LAUNCH("linear_small_m launch");
+  return AVSD_OK;
+}
+
+extern "C" int avsd_guided_step(const float* noise_pred, int n_branch, float g, float* eps_hist, int store_slot,
+                                float w_cur, const int32_t* hist_idx, const float* w, int n_hist, const float* x_in,
+                                float* x_out, float ca, float cb, int B, int C, int F, int HW, void* stream) {
+  AVSD_REQUIRE(noise_pred && x_in && x_out, "guided_step: null pointer");
+  AVSD_REQUIRE(n_branch == 1 || n_branch == 2, "guided_step: n_branch must be 1 or 2");
+  AVSD_REQUIRE(n_hist >= 0 && n_hist <= 4, "guided_step: n_hist must be in [0, 4]");
+  AVSD_REQUIRE((n_hist == 0 && store_slot < 0) || eps_hist, "guided_step: history requested without eps_hist");
+  AVSD_REQUIRE(n_hist == 0 || (hist_idx && w), "guided_step: null history tables");
+  AVSD_REQUIRE(B > 0 && C > 0 && F > 0 && HW > 0, "guided_step: bad shape");
+  GuidedArgs a;
+  a.noise_pred = noise_pred; a.eps_hist = eps_hist; a.x_in = x_in; a.x_out = x_out;
+  a.n_branch = n_branch; a.store_slot = store_slot; a.n_hist = n_hist;
+  for (int k = 0; k < 4; ++k) { a.hist_idx[k] = k < n_hist ? hist_idx[k] : 0; a.w[k] = k < n_hist ? w[k] : 0.f; }
+  a.g = g; a.w_cur = w_cur; a.ca = ca; a.cb = cb;
+  a.B = B; a.C = C; a.F = F; a.HW = HW;
+  const int64_t n = (int64_t)B * C * F * HW;
+  hipLaunchKernelGGL(guided_step_kernel, dim3(grid_for(n, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+  AVSD_CHECK_LAUNCH("guided_step launch");
+  return AVSD_OK;
+}
+
+extern "C" int avsd_vae_postprocess(const void* src, int ld, float* dst, int N, int HW, void* stream) {
+  AVSD_REQUIRE(src && dst && N > 0 && HW > 0 && ld >= 3, "vae_postprocess: bad arguments");
+  const int64_t n = (int64_t)N * 3 * HW;
+  hipLaunchKernelGGL(vae_postprocess_kernel, dim3(grid_for(n, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     (const bf16_t*)src, ld, dst, N, HW);
+  AVSD_CHECK_LAUNCH("vae_postprocess launch");
+  return AVSD_OK;
+}

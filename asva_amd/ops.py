@@ -1,0 +1,295 @@
+"""Torch-tensor front end of the C ABI (include/avsd.h): one thin function per entry point.
+
+Tensors are device-resident; activations are channels-last bf16 matrices [rows, C].  Every call
+launches on torch's current HIP stream, so a `torch.cuda.graph` capture records the whole step.
+PyTorch is used for memory and streams only; all arithmetic happens in libavsd_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, check
+
+PLAIN, TMIX, CONV3 = 0, 1, 2
+GEGLU, OUT_F32 = 1, 2
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, dtype, name: str):
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_cuda:
+        raise ValueError(f"{name}: expected a device tensor (libavsd_hip.so has no host path)")
+    if t.dim() >= 1 and t.stride(-1) != 1:
+        raise ValueError(f"{name}: innermost dimension must be contiguous")
+
+
+def _ld(t: torch.Tensor) -> int:
+    return t.stride(0) if t.dim() == 2 else t.stride(-2)
+
+
+def gemm(
+    a: torch.Tensor,
+    w: torch.Tensor,
+    *,
+    n: Optional[int] = None,
+    k: Optional[int] = None,
+    a2: Optional[torch.Tensor] = None,
+    bias: Optional[torch.Tensor] = None,
+    rowvec: Optional[torch.Tensor] = None,
+    rows_per_vec: int = 0,
+    res1: Optional[torch.Tensor] = None,
+    res2: Optional[torch.Tensor] = None,
+    alpha: float = 1.0,
+    geglu: bool = False,
+    out_f32: bool = False,
+    out: Optional[torch.Tensor] = None,
+    mode: int = PLAIN,
+    tmix: Optional[tuple] = None,      # (hw, frames)
+    conv: Optional[tuple] = None,      # (n_img, hs, ws, stride, ups)
+    m: Optional[int] = None,
+    tile: int = 0,
+) -> torch.Tensor:
+    """out = epilogue(alpha * A' . W^T); see avsd_gemm_bf16 in include/avsd.h."""
+    _req(a, BF16, "a")
+    _req(w, BF16, "w")
+    d = GemmDesc()
+    N = w.shape[0] if n is None else n
+    lda = _ld(a)
+    if mode == PLAIN:
+        M = a.shape[0] if m is None else m
+        K1 = a.shape[1]
+        K = K1 + (a2.shape[1] if a2 is not None else 0)
+        if a2 is not None:
+            _req(a2, BF16, "a2")
+            d.A2, d.lda2, d.k_split = _p(a2), _ld(a2), K1
+        else:
+            d.k_split = K
+        if k is not None:
+            K = k
+    elif mode == TMIX:
+        hw, frames = tmix
+        M = a.shape[0]
+        cseg = a.shape[1]
+        K = 3 * cseg
+        d.hw, d.frames, d.cseg = hw, frames, cseg
+    elif mode == CONV3:
+        n_img, hs, ws, stride, ups = conv
+        cin = a.shape[1]
+        hin, win = hs << ups, ws << ups
+        ho, wo = (hin + 2 - 3) // stride + 1, (win + 2 - 3) // stride + 1
+        M = n_img * ho * wo
+        K = 9 * cin
+        d.hs, d.ws, d.ho, d.wo, d.cin, d.stride, d.ups = hs, ws, ho, wo, cin, stride, ups
+    else:
+        raise ValueError(f"unknown gemm mode {mode}")
+    n_out = N // 2 if geglu else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=F32 if out_f32 else BF16, device=a.device)
+    else:
+        _req(out, F32 if out_f32 else BF16, "out")
+    d.A, d.W, d.out = _p(a), _p(w), _p(out)
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldw, d.ldc = lda, _ld(w), _ld(out)
+    if bias is not None:
+        _req(bias, F32, "bias")
+        d.bias = _p(bias)
+    if rowvec is not None:
+        _req(rowvec, F32, "rowvec")
+        d.rowvec, d.rows_per_vec, d.ldv = _p(rowvec), rows_per_vec, _ld(rowvec)
+    if res1 is not None:
+        _req(res1, BF16, "res1")
+        d.res1, d.ldr1 = _p(res1), _ld(res1)
+    if res2 is not None:
+        _req(res2, BF16, "res2")
+        d.res2, d.ldr2 = _p(res2), _ld(res2)
+    d.alpha = alpha
+    d.mode = mode
+    d.flags = (GEGLU if geglu else 0) | (OUT_F32 if out_f32 else 0)
+    d.batch = 1
+    d.tile = tile
+    check(_lib.lib().avsd_gemm_bf16(C.byref(d), _stream()), "avsd_gemm_bf16")
+    return out
+
+
+def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, alpha: float = 1.0, out_f32: bool = False,
+                 tile: int = 0) -> torch.Tensor:
+    """out[b] = alpha * a[b] . w[b]^T for 3-D a [B, M, K], w [B, N, K] (VAE mid-block attention)."""
+    _req(a, BF16, "a")
+    _req(w, BF16, "w")
+    B, M, K = a.shape
+    N = w.shape[1]
+    out = torch.empty((B, M, N), dtype=F32 if out_f32 else BF16, device=a.device)
+    d = GemmDesc()
+    d.A, d.W, d.out = _p(a), _p(w), _p(out)
+    d.M, d.N, d.K, d.k_split = M, N, K, K
+    d.lda, d.ldw, d.ldc = a.stride(1), w.stride(1), out.stride(1)
+    d.alpha, d.mode, d.flags, d.batch, d.tile = alpha, PLAIN, (OUT_F32 if out_f32 else 0), B, tile
+    d.batch_stride_a, d.batch_stride_w, d.batch_stride_out = a.stride(0), w.stride(0), out.stride(0)
+    check(_lib.lib().avsd_gemm_bf16(C.byref(d), _stream()), "avsd_gemm_bf16(batched)")
+    return out
+
+
+def linear_small_m(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, act_in: bool = False,
+                   act_out: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _req(x, F32, "x")
+    _req(w, BF16, "w")
+    M, K = x.shape
+    N = w.shape[0]
+    if not x.is_contiguous():
+        raise ValueError("linear_small_m: x must be contiguous")
+    if out is None:
+        out = torch.empty((M, N), dtype=F32, device=x.device)
+    check(_lib.lib().avsd_linear_small_m(_p(x), _p(w), _p(bias), _p(out), M, N, K, _ld(w), int(act_in), int(act_out),
+                                         _stream()), "avsd_linear_small_m")
+    return out
+
+
+def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], nb: int, rows_per_batch: int, groups: int,
+              gamma: torch.Tensor, beta: torch.Tensor, eps: float, act: bool,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """GroupNorm(+SiLU) of the channel concat [x1 | x2]; statistics pooled over each run of
+    `rows_per_batch` rows.  Two launches: partial sums, then reduce + apply."""
+    _req(x1, BF16, "x1")
+    c1 = x1.shape[1]
+    c2 = 0
+    if x2 is not None:
+        _req(x2, BF16, "x2")
+        c2 = x2.shape[1]
+    _req(gamma, F32, "gamma")
+    _req(beta, F32, "beta")
+    L = _lib.lib()
+    rows = nb * rows_per_batch
+    nchunks = L.avsd_groupnorm_nchunks(nb, rows_per_batch, c1 + c2)
+    partial = torch.empty((nb, nchunks, groups, 2), dtype=F32, device=x1.device)
+    if out is None:
+        out = torch.empty((rows, c1 + c2), dtype=BF16, device=x1.device)
+    s = _stream()
+    check(L.avsd_groupnorm_stats(_p(x1), _ld(x1), c1, _p(x2), _ld(x2) if x2 is not None else 0, c2, nb, rows_per_batch,
+                                 groups, _p(partial), nchunks, s), "avsd_groupnorm_stats")
+    check(L.avsd_groupnorm_apply(_p(x1), _ld(x1), c1, _p(x2), _ld(x2) if x2 is not None else 0, c2, nb, rows_per_batch,
+                                 groups, _p(partial), nchunks, _p(gamma), _p(beta), float(eps), int(act), _p(out),
+                                 _ld(out), s), "avsd_groupnorm_apply")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
+              pos: Optional[torch.Tensor] = None, hw: int = 1, frames: int = 1,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _req(x, BF16, "x")
+    _req(gamma, F32, "gamma")
+    _req(beta, F32, "beta")
+    M, Cc = x.shape
+    if pos is not None:
+        _req(pos, F32, "pos")
+        if not pos.is_contiguous() or pos.shape != (frames, Cc):
+            raise ValueError("layernorm: pos must be contiguous [frames, C]")
+    if out is None:
+        out = torch.empty((M, Cc), dtype=BF16, device=x.device)
+    check(_lib.lib().avsd_layernorm(_p(x), _ld(x), _p(out), _ld(out), M, Cc, _p(gamma), _p(beta), float(eps), _p(pos),
+                                    hw, frames, _stream()), "avsd_layernorm")
+    return out
+
+
+def softmax_rows(s: torch.Tensor) -> torch.Tensor:
+    _req(s, F32, "s")
+    rows, L = s.shape
+    out = torch.empty((rows, L), dtype=BF16, device=s.device)
+    check(_lib.lib().avsd_softmax_rows(_p(s), _ld(s), _p(out), _ld(out), rows, L, _stream()), "avsd_softmax_rows")
+    return out
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, bq: int, lq: int, lk: int, kv_rows: int,
+              heads: int, q_per_kv: int, frames: int, key_index: Optional[torch.Tensor] = None,
+              scale: Optional[float] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q [bq*lq, heads*d]; k, v [(bq/q_per_kv)*kv_rows, >= heads*d] (views into a fused k|v buffer are fine)."""
+    _req(q, BF16, "q")
+    _req(k, BF16, "k")
+    _req(v, BF16, "v")
+    Cc = q.shape[1]
+    d = Cc // heads
+    if key_index is not None:
+        if key_index.dtype != torch.int32 or not key_index.is_contiguous() or key_index.shape != (frames, lk):
+            raise ValueError("attention: key_index must be contiguous int32 [frames, lk]")
+    if out is None:
+        out = torch.empty((bq * lq, Cc), dtype=BF16, device=q.device)
+    if scale is None:
+        scale = float(d) ** -0.5
+    check(_lib.lib().avsd_attention(_p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(out), _ld(out), bq, lq, lk, kv_rows,
+                                    heads, d, q_per_kv, _p(key_index), frames, float(scale), _stream()),
+          "avsd_attention")
+    return out
+
+
+def temporal_attention(qkv: torch.Tensor, *, b: int, frames: int, hw: int, heads: int,
+                       scale: Optional[float] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _req(qkv, BF16, "qkv")
+    Cc = qkv.shape[1] // 3
+    d = Cc // heads
+    if out is None:
+        out = torch.empty((qkv.shape[0], Cc), dtype=BF16, device=qkv.device)
+    if scale is None:
+        scale = float(d) ** -0.5
+    check(_lib.lib().avsd_temporal_attention(_p(qkv), _ld(qkv), _p(out), _ld(out), b, frames, hw, heads, d, float(scale),
+                                             _stream()), "avsd_temporal_attention")
+    return out
+
+
+def ncfhw_to_rows(x: torch.Tensor, cpad: int, rep: int = 1, scale: float = 1.0) -> torch.Tensor:
+    _req(x, F32, "x")
+    if not x.is_contiguous():
+        raise ValueError("ncfhw_to_rows: x must be contiguous")
+    B, Cc, Fr, H, W = x.shape
+    out = torch.empty((rep * B * Fr * H * W, cpad), dtype=BF16, device=x.device)
+    check(_lib.lib().avsd_ncfhw_to_rows(_p(x), _p(out), B, Cc, Fr, H * W, cpad, rep, float(scale), _stream()),
+          "avsd_ncfhw_to_rows")
+    return out
+
+
+def rows_to_ncfhw(rows: torch.Tensor, B: int, Cc: int, Fr: int, H: int, W: int) -> torch.Tensor:
+    _req(rows, F32, "rows")
+    out = torch.empty((B, Cc, Fr, H, W), dtype=F32, device=rows.device)
+    check(_lib.lib().avsd_rows_to_ncfhw(_p(rows), _ld(rows), _p(out), B, Cc, Fr, H * W, _stream()), "avsd_rows_to_ncfhw")
+    return out
+
+
+def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    _req(t, F32, "t")
+    n = t.numel()
+    out = torch.empty((n, dim), dtype=F32, device=t.device)
+    check(_lib.lib().avsd_timestep_embedding(_p(t), _p(out), n, dim, _stream()), "avsd_timestep_embedding")
+    return out
+
+
+def guided_step(noise_pred: torch.Tensor, n_branch: int, g: float, x_in: torch.Tensor, x_out: torch.Tensor,
+                ca: float, cb: float, *, eps_hist: Optional[torch.Tensor] = None, store_slot: int = -1,
+                w_cur: float = 1.0, hist_idx=(), w=()) -> None:
+    _req(noise_pred, F32, "noise_pred")
+    _req(x_in, F32, "x_in")
+    _req(x_out, F32, "x_out")
+    B, Cc, Fr, H, W = x_in.shape
+    nh = len(hist_idx)
+    idx = (C.c_int32 * 4)(*(list(hist_idx) + [0] * (4 - nh)))
+    ws = (C.c_float * 4)(*(list(w) + [0.0] * (4 - nh)))
+    check(_lib.lib().avsd_guided_step(_p(noise_pred), n_branch, float(g), _p(eps_hist), store_slot, float(w_cur), idx, ws,
+                                      nh, _p(x_in), _p(x_out), float(ca), float(cb), B, Cc, Fr, H * W, _stream()),
+          "avsd_guided_step")
+
+
+def vae_postprocess(rows: torch.Tensor, n_img: int, H: int, W: int) -> torch.Tensor:
+    _req(rows, BF16, "rows")
+    out = torch.empty((n_img, 3, H, W), dtype=F32, device=rows.device)
+    check(_lib.lib().avsd_vae_postprocess(_p(rows), _ld(rows), _p(out), n_img, H * W, _stream()), "avsd_vae_postprocess")
+    return out

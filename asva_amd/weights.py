@@ -1,0 +1,58 @@
+"""Weight packing: reference state_dict tensors -> the layouts the gfx950 kernels read.
+
+All GEMM-class weights become bf16 [N][K] matrices (K contiguous):
+  * nn.Linear weight [out, in]                      -> as is
+  * 1x1 nn.Conv2d weight [out, in, 1, 1]            -> [out, in]
+  * 3x3 nn.Conv2d weight [out, in, 3, 3]            -> [out, 9*cin_pad], k = (kh*3 + kw)*cin_pad + c
+    (cin padded to a multiple of 8 with zeros: conv_in has 4 input channels)
+  * GEGLU proj weight [2*Nh, K] (diffusers: value rows then gate rows) -> per 32-row block
+    [16 value rows | 16 gate rows] so one MFMA accumulator fragment holds value and gate of the
+    same output feature in the same lane (see gemm.hip epilogue)
+  * output rows are padded to a multiple of 4 where the layer has fewer (conv_out: 4 -> 4 ok).
+Biases and norm parameters stay f32.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def pack_linear(w: torch.Tensor) -> torch.Tensor:
+    return w.detach().to(torch.bfloat16).contiguous()
+
+
+def pack_conv1x1(w: torch.Tensor) -> torch.Tensor:
+    return w.detach().reshape(w.shape[0], w.shape[1]).to(torch.bfloat16).contiguous()
+
+
+def pack_conv3x3(w: torch.Tensor, cin_pad: int | None = None, cout_pad: int | None = None) -> torch.Tensor:
+    cout, cin, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    cin_pad = cin_pad or (cin + 7) // 8 * 8
+    cout_pad = cout_pad or (cout + 3) // 4 * 4
+    p = torch.zeros((cout_pad, 3, 3, cin_pad), dtype=torch.float32, device=w.device)
+    p[:cout, :, :, :cin] = w.detach().float().permute(0, 2, 3, 1)
+    return p.reshape(cout_pad, 9 * cin_pad).to(torch.bfloat16).contiguous()
+
+
+def geglu_row_order(nh: int) -> torch.Tensor:
+    """Packed row r of a GEGLU projection with nh output features reads source row order[r]."""
+    assert nh % 16 == 0, "GEGLU packing needs the inner dim to be a multiple of 16"
+    blk = torch.arange(nh // 16).repeat_interleave(32)
+    p = torch.arange(32).repeat(nh // 16)
+    return torch.where(p < 16, blk * 16 + p, nh + blk * 16 + p - 16)
+
+
+def pack_geglu(w: torch.Tensor, b: torch.Tensor | None):
+    nh = w.shape[0] // 2
+    order = geglu_row_order(nh).to(w.device)
+    wp = w.detach()[order].to(torch.bfloat16).contiguous()
+    bp = None if b is None else b.detach()[order].float().contiguous()
+    return wp, bp
+
+
+def pad_rows(w: torch.Tensor, mult: int = 4) -> torch.Tensor:
+    n = w.shape[0]
+    if n % mult == 0:
+        return w
+    pad = torch.zeros((mult - n % mult,) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)
+    return torch.cat([w, pad], 0).contiguous()

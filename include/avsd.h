@@ -1,0 +1,193 @@
+/*
+ * avsd.h — C ABI of libavsd_hip.so: the MI355X (gfx950) kernels behind the AVSyncD
+ * denoising path (per-step AudioUNet3D forward, CFG + scheduler update, VAE decode).
+ *
+ * The reference (lzhangbj/ASVA) has no FFI layer: its hot path is PyTorch module calls.
+ * Each entry point below names the reference call site (file:line under /root/reference)
+ * whose arithmetic it replaces.  The host side (the asva_amd Python package) binds these with ctypes;
+ * INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative AVSD_E* code otherwise;
+ *     avsd_last_error() returns a thread-local message for the last failure.
+ *   - all pointers are DEVICE pointers owned by the caller (torch tensors) unless the
+ *     parameter name ends in _host.  Nothing here allocates or frees device memory, and
+ *     nothing synchronises: every launch goes to `stream` (a hipStream_t), so the whole
+ *     step is capturable in a hipGraph.
+ *   - "bf16" buffers are raw uint16 bfloat16; statistics / biases / norm parameters are f32.
+ *   - activations are channels-last: a (B, F, H, W, C) tensor is the row-major matrix
+ *     [M = B*F*H*W, C]; "ld*" arguments are row strides in ELEMENTS.
+ */
+#ifndef AVSD_H
+#define AVSD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVSD_OK 0
+#define AVSD_EINVAL (-1)   /* bad argument (shape / alignment / null pointer)   */
+#define AVSD_ELAUNCH (-2)  /* hipLaunch / runtime error                          */
+#define AVSD_ENODEV (-3)   /* no gfx950 device / wrong architecture              */
+
+#define AVSD_ABI_VERSION 1
+
+/* ---- library ------------------------------------------------------------------------ */
+int avsd_abi_version(void);
+const char* avsd_last_error(void);
+/* Fills name[<=len] with the device arch string (e.g. "gfx950:sramecc+:xnack-"), and the
+ * CU count.  AVSD_ENODEV when no device is visible. */
+int avsd_device_info(char* name_host, int len, int* num_cu_host);
+
+/* ---- GEMM family ---------------------------------------------------------------------
+ * out[M, N] = epilogue( alpha * A'[M, K] . W[N, K]^T )
+ * W is always [N][ldw] (K contiguous) — torch nn.Linear / packed conv weight layout.
+ * A' is produced by the A-loader selected by `mode`:
+ *
+ *   AVSD_GEMM_PLAIN  A'[m, k] = k < k_split ? A[m*lda + k] : A2[m*lda2 + (k - k_split)]
+ *                    (k_split == K, A2 == NULL for a single source).  Replaces nn.Linear /
+ *                    1x1 nn.Conv2d: utils.py:123-131,159 (q/k/v/out), proj_in/proj_out
+ *                    ff_spatio_audio_temp_transformer_3d.py:66,92, GEGLU FeedForward :276,
+ *                    conv_shortcut ff_spatio_temp_resnet_3d.py:159 on a torch.cat input
+ *                    (unet_3d_blocks.py:358,1038).
+ *   AVSD_GEMM_TMIX   the temporal mixing linear of FFInflatedConv3d (utils.py:43-53):
+ *                    K = 3*cseg; for row m = (b, f, p) (p in [0,hw)) segment s of K reads
+ *                    row (b, g_s(f), p) of A with g = {0, max(f-1,0), f}.
+ *   AVSD_GEMM_CONV3  implicit-GEMM 3x3 pad-1 convolution over channels-last images
+ *                    (utils.py:37-38 -> nn.Conv2d): K = 9*cin (tap-major, cin-minor),
+ *                    row m = (n, ho, wo); stride 1 or 2; `ups`=1 reads the input through a
+ *                    nearest x2 upsample (ff_spatio_temp_resnet_3d.py:48).
+ *
+ * epilogue, in f32:  v = alpha*acc + bias[n] + rowvec[(m / rows_per_vec)*ldv + n]
+ *                                   + res1[m*ldr1 + n] + res2[m*ldr2 + n]
+ *   AVSD_GEMM_GEGLU: W rows are packed per 32-row block as [16 value rows | 16 gate rows];
+ *                    out[M, N/2] = value * gelu_erf(gate)   (diffusers GEGLU)
+ *   AVSD_GEMM_OUT_F32: out is f32 instead of bf16.
+ * blockIdx.z batches: pointers advance by batch_stride_* elements (0 = shared).
+ */
+enum { AVSD_GEMM_PLAIN = 0, AVSD_GEMM_TMIX = 1, AVSD_GEMM_CONV3 = 2 };
+enum { AVSD_GEMM_GEGLU = 1, AVSD_GEMM_OUT_F32 = 2 };
+
+typedef struct avsd_gemm_desc {
+  const void* A;        /* bf16 */
+  const void* A2;       /* bf16 or NULL */
+  const void* W;        /* bf16 [N][ldw] */
+  void* out;            /* bf16 or f32 [M][ldc] */
+  const float* bias;    /* [N] or NULL */
+  const float* rowvec;  /* [ceil(M/rows_per_vec)][ldv] or NULL */
+  const void* res1;     /* bf16 [M][ldr1] or NULL */
+  const void* res2;     /* bf16 [M][ldr2] or NULL */
+  int32_t M, N, K;
+  int32_t lda, lda2, k_split, ldw, ldc, ldr1, ldr2;
+  int32_t rows_per_vec, ldv;
+  float alpha;
+  int32_t mode, flags;
+  int32_t batch;                        /* >= 1 */
+  int64_t batch_stride_a, batch_stride_w, batch_stride_out;
+  /* TMIX */
+  int32_t hw, frames, cseg;
+  /* CONV3: source image (hs, ws) with cin channels at row stride lda; output (ho, wo) */
+  int32_t hs, ws, ho, wo, cin, stride, ups;
+  int32_t tile;                         /* 0 = auto; 1 = 128x128, 2 = 128x64, 3 = 64x64 */
+} avsd_gemm_desc;
+
+int avsd_gemm_bf16(const avsd_gemm_desc* desc_host, void* stream);
+/* sizeof(avsd_gemm_desc) as compiled: lets an FFI binding verify its mirror of the struct. */
+int avsd_sizeof_gemm_desc(void);
+
+/* out[M, N] (f32) = act_out( act_in(x[M, K] f32) . W[N, K]^T + bias ), M <= 16.
+ * act: 0 none, 1 SiLU.  Time-embedding MLP and the per-ResBlock time_emb_proj
+ * (audio_cond_unet_3d_condition.py:673-680, ff_spatio_temp_resnet_3d.py:170), and the
+ * temporal position MLP (ff_spatio_audio_temp_transformer_3d.py:348-349). */
+int avsd_linear_small_m(const float* x, const void* W_bf16, const float* bias, float* out,
+                        int M, int N, int K, int ldw, int act_in, int act_out, void* stream);
+
+/* ---- normalisation -------------------------------------------------------------------
+ * GroupNorm over channels-last data, two kernels.
+ * stats: for each of `nb` normalisation batches (a batch = `rows_per_batch` consecutive
+ *   rows: F*H*W for the 5-D GroupNorm of ff_spatio_temp_resnet_3d.py:130,146 /
+ *   audio_cond_unet_3d_condition.py:445, H*W for the per-frame GroupNorm of
+ *   ff_spatio_audio_temp_transformer_3d.py:62) writes per-chunk partial (sum, sumsq) for
+ *   each of `groups` channel groups to partial[nb][nchunks][groups][2].
+ *   The input is the channel concat [x1 (c1 channels) | x2 (c2 channels)] (c2 may be 0).
+ * apply: finishes the reduction and writes
+ *   y[m, c] = act( (x - mean) * rstd * gamma[c] + beta[c] ), act 0 none / 1 SiLU, as bf16. */
+int avsd_groupnorm_stats(const void* x1, int ld1, int c1, const void* x2, int ld2, int c2,
+                         int nb, int rows_per_batch, int groups, float* partial, int nchunks,
+                         void* stream);
+int avsd_groupnorm_apply(const void* x1, int ld1, int c1, const void* x2, int ld2, int c2,
+                         int nb, int rows_per_batch, int groups, const float* partial,
+                         int nchunks, const float* gamma, const float* beta, float eps,
+                         int act, void* y, int ldy, void* stream);
+/* Suggested nchunks for the two calls above (pure host arithmetic). */
+int avsd_groupnorm_nchunks(int nb, int rows_per_batch, int channels);
+
+/* LayerNorm over the last dim (eps 1e-5 in the reference): y = LN(x + pos[f(m)]) with
+ * pos == NULL for plain LN; f(m) = (m / hw) % frames.
+ * (ff_spatio_audio_temp_transformer_3d.py:300,317,330,354,361) */
+int avsd_layernorm(const void* x, int ldx, void* y, int ldy, int M, int C,
+                   const float* gamma, const float* beta, float eps,
+                   const float* pos, int hw, int frames, void* stream);
+
+/* Row softmax: P[r, :] = softmax(S[r, :L]) ; S f32, P bf16 (VAE mid-block attention). */
+int avsd_softmax_rows(const float* S, int lds, void* P, int ldp, int rows, int L, void* stream);
+
+/* ---- attention -----------------------------------------------------------------------
+ * Multi-head attention with queries [Bq][Lq] and keys/values [Bk][Lk]; query batch qb
+ * attends to kv batch qb / q_per_kv (first-frame attention utils.py:133-153: q_per_kv =
+ * frames, K/V computed for frame 0 only; audio / text cross-attention
+ * ff_spatio_audio_temp_transformer_3d.py:319-341: K/V computed once per clip branch).
+ * Head h occupies columns [h*d, (h+1)*d) of each row.  key_index (optional, int32
+ * [frames][Lk]) gathers key rows for frame qb % frames — the boolean audio segment mask
+ * (segmask_imagebind.py:104-114) turned into the list of unmasked keys.
+ * kv_rows = rows per kv batch in the K/V buffers (229 audio tokens while Lk = 25 gathered).
+ * softmax scale = scale (d^-1/2).  d in {40, 64, 80, 128, 160}. */
+int avsd_attention(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
+                   void* O, int ldo, int Bq, int Lq, int Lk, int kv_rows, int heads, int d,
+                   int q_per_kv, const int32_t* key_index, int frames, float scale, void* stream);
+
+/* Temporal self-attention across frames for every pixel
+ * (ff_spatio_audio_temp_transformer_3d.py:352-358): qkv is [B*F*hw][ldqkv] with q|k|v at
+ * column offsets 0, C, 2C; sequence (b, p) = rows {(b*F + f)*hw + p : f}. */
+int avsd_temporal_attention(const void* QKV, int ldqkv, void* O, int ldo, int B, int frames,
+                            int hw, int heads, int d, float scale, void* stream);
+
+/* ---- elementwise / layout ------------------------------------------------------------ */
+/* (B, C, F, H, W) f32  ->  channels-last bf16 [rep*B*F*H*W][cpad] = scale * src, channels >= C
+ * zeroed, the batch repeated `rep` times (torch.cat([latents] * k), pipeline...py:331-336). */
+int avsd_ncfhw_to_rows(const float* src, void* dst, int B, int C, int F, int HW, int cpad,
+                       int rep, float scale, void* stream);
+/* channels-last f32 [B*F*HW][ld] (first C columns) -> (B, C, F, H, W) f32. */
+int avsd_rows_to_ncfhw(const float* src, int ld, float* dst, int B, int C, int F, int HW,
+                       void* stream);
+/* Sinusoidal embedding, diffusers Timesteps(dim, flip_sin_to_cos=True, shift=0):
+ * out[i, :] = [cos(t_i * w) | sin(t_i * w)], w_j = exp(-ln(1e4) * j / (dim/2)).
+ * t is a device f32 array of n values. */
+int avsd_timestep_embedding(const float* t, float* out, int n, int dim, void* stream);
+
+/* Guidance + multistep scheduler update on (B, C, F, H, W) f32 latents, frame 0 pinned
+ * (pipeline_audio_cond_animation.py:349-364):
+ *   eps      = e[0] + g * (e[1] - e[0])      (e = noise_pred of the [null-audio, audio] UNet
+ *                                            batch; g = audio guidance scale; n_branch = 1
+ *                                            disables guidance)
+ *   eps_hist[store_slot] = eps                (if store_slot >= 0)
+ *   eps'     = w_cur * eps + sum_k w[k] * eps_hist[hist_idx[k]]      (n_hist <= 4 terms)
+ *   x_out[:, :, 1:] = ca * x_in[:, :, 1:] + cb * eps'[:, :, 1:] ;  x_out[:, :, 0] = x_in[:, :, 0]
+ * PNDM (PLMS, incl. its averaged second step on the saved sample) and DDIM (eta = 0) are both
+ * of this form; the scalar schedule lives on the host (asva_amd/schedulers.py). */
+int avsd_guided_step(const float* noise_pred, int n_branch, float g, float* eps_hist,
+                     int store_slot, float w_cur, const int32_t* hist_idx_host,
+                     const float* w_host, int n_hist, const float* x_in, float* x_out, float ca,
+                     float cb, int B, int C, int F, int HW, void* stream);
+
+/* VAE post-processing (pipeline_audio_cond_animation.py:212): channels-last bf16
+ * [N*H*W][ld] (3 channels) -> (N, 3, H, W) f32 = clamp(x / 2 + 0.5, 0, 1). */
+int avsd_vae_postprocess(const void* src, int ld, float* dst, int N, int HW, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVSD_H */

@@ -1,0 +1,361 @@
+"""Per-kernel parity: every C-ABI entry point against a plain PyTorch fp32 statement of the same op on
+the same bf16-representable inputs.  Tolerances (rel-L2 over the whole output):
+  * bf16 outputs: 4e-3  (bf16 rounding of the result alone is ~1.1e-3 RMS; attention adds the bf16
+    rounding of P before P.V)
+  * f32 outputs:  2e-5  (same products, different f32 summation order)
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL_BF16 = 4e-3
+TOL_F32 = 2e-5
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel_l2(a, b):
+    a = a.float()
+    b = b.float()
+    return ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).to(dev())
+
+
+def rndf(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev())
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from asva_amd import ops as _ops
+
+    return _ops
+
+
+def test_device_is_gfx950():
+    import ctypes
+
+    from asva_amd import _lib
+
+    name = ctypes.create_string_buffer(64)
+    cu = ctypes.c_int(0)
+    rc = _lib.lib().avsd_device_info(name, 64, ctypes.byref(cu))
+    assert rc == 0, _lib.lib().avsd_last_error()
+    assert name.value.startswith(b"gfx950") and cu.value > 0
+
+
+# ---- GEMM ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tile", [1, 2, 3, 0])
+@pytest.mark.parametrize("M,N,K", [(384, 320, 320), (1000, 640, 1280), (128, 64, 64), (77, 132, 200), (2048, 1280, 768)])
+def test_gemm_plain(ops, tile, M, N, K):
+    a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    bias = rndf(N, seed=3)
+    res = rnd(M, N, seed=4)
+    out = ops.gemm(a, w, bias=bias, res1=res, tile=tile)
+    ref = a.float() @ w.float().T + bias + res.float()
+    assert out.dtype == torch.bfloat16 and out.shape == (M, N)
+    assert rel_l2(out, ref) < TOL_BF16
+    out32 = ops.gemm(a, w, bias=bias, res1=res, out_f32=True, tile=tile)
+    assert rel_l2(out32, ref) < TOL_F32
+
+
+def test_gemm_asymmetric_transpose_detect(ops):
+    # A = I with an asymmetric W catches a swapped row/col in the accumulator layout
+    M = N = K = 128
+    a = torch.eye(M, dtype=torch.bfloat16, device=dev())
+    w = (torch.arange(N * K, device=dev()).reshape(N, K) % 251).to(torch.bfloat16)
+    for tile in (1, 2, 3):
+        out = ops.gemm(a, w, out_f32=True, tile=tile)
+        assert torch.equal(out, w.float().T.contiguous())
+
+
+def test_gemm_strided_views_two_residuals_rowvec_alpha(ops):
+    M, N, K = 768, 320, 640
+    big = rnd(M, 3 * K, seed=5)
+    a = big[:, K:2 * K]                      # lda = 3K
+    w = rnd(N, K, seed=6, scale=K ** -0.5)
+    r1, r2 = rnd(M, N, seed=7), rnd(M, N, seed=8)
+    rows_per_vec = 192
+    rv = rndf(M // rows_per_vec, N + 64, seed=9)[:, 32:32 + N]   # ldv = N + 64, offset view
+    out = ops.gemm(a, w, res1=r1, res2=r2, rowvec=rv, rows_per_vec=rows_per_vec, alpha=0.5)
+    ref = 0.5 * (a.float() @ w.float().T) + r1.float() + r2.float() + rv.repeat_interleave(rows_per_vec, 0)
+    assert rel_l2(out, ref) < TOL_BF16
+
+
+def test_gemm_two_source_concat(ops):
+    M, N, K1, K2 = 512, 320, 640, 320
+    a1, a2 = rnd(M, K1, seed=1), rnd(M, K2, seed=2)
+    w = rnd(N, K1 + K2, seed=3, scale=(K1 + K2) ** -0.5)
+    out = ops.gemm(a1, w, a2=a2, out_f32=True)
+    ref = torch.cat([a1, a2], 1).float() @ w.float().T
+    assert rel_l2(out, ref) < TOL_F32
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3])
+def test_gemm_geglu(ops, tile):
+    from asva_amd.weights import pack_geglu
+
+    M, C = 640, 320
+    x = rnd(M, C, seed=1)
+    w = rnd(8 * C, C, seed=2, scale=C ** -0.5)
+    b = rndf(8 * C, seed=3)
+    wp, bp = pack_geglu(w, b)
+    out = ops.gemm(x, wp, bias=bp, geglu=True, tile=tile)
+    h = x.float() @ w.float().T + b
+    val, gate = h.chunk(2, dim=-1)
+    ref = val * F.gelu(gate)
+    assert out.shape == (M, 4 * C)
+    assert rel_l2(out, ref) < TOL_BF16
+
+
+def _tmix_ref(y, w, b, B, Fr, hw):
+    C = y.shape[1]
+    y5 = y.float().reshape(B, Fr, hw, C)
+    prev = torch.clamp(torch.arange(Fr) - 1, min=0)
+    cat = torch.cat([y5[:, [0] * Fr], y5[:, prev], y5], dim=-1)
+    return (y5 + cat @ w.float().T + b).reshape(B * Fr * hw, C)
+
+
+@pytest.mark.parametrize("B,Fr,hw,C", [(2, 12, 64, 320), (1, 4, 16, 80), (2, 3, 100, 640)])
+def test_gemm_tmix(ops, B, Fr, hw, C):
+    y = rnd(B * Fr * hw, C, seed=1)
+    w = rnd(C, 3 * C, seed=2, scale=(3 * C) ** -0.5)
+    b = rndf(C, seed=3)
+    out = ops.gemm(y, w, bias=b, res1=y, mode=ops.TMIX, tmix=(hw, Fr))
+    assert rel_l2(out, _tmix_ref(y, w, b, B, Fr, hw)) < TOL_BF16
+
+
+@pytest.mark.parametrize("stride,ups", [(1, 0), (2, 0), (1, 1)])
+@pytest.mark.parametrize("n_img,hs,ws,cin,cout", [(3, 16, 16, 64, 128), (2, 8, 12, 320, 320), (4, 5, 7, 8, 4), (2, 32, 32, 4, 320)])
+def test_gemm_conv3x3(ops, stride, ups, n_img, hs, ws, cin, cout):
+    from asva_amd.weights import pack_conv3x3
+
+    if stride == 2 and (hs % 2 or ws % 2):
+        pytest.skip("stride-2 case uses even sizes")
+    cin_pad = (cin + 7) // 8 * 8
+    x = torch.zeros(n_img * hs * ws, cin_pad, dtype=torch.bfloat16, device=dev())
+    x[:, :cin] = rnd(n_img * hs * ws, cin, seed=1)
+    w = rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5)
+    b = rndf(cout, seed=3)
+    out = ops.gemm(x, pack_conv3x3(w, cin_pad), bias=b, mode=ops.CONV3, conv=(n_img, hs, ws, stride, ups))
+    xi = x[:, :cin].float().reshape(n_img, hs, ws, cin).permute(0, 3, 1, 2)
+    if ups:
+        xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xi, w.float(), b, stride=stride, padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
+    assert out.shape == ref.shape
+    assert rel_l2(out, ref) < TOL_BF16
+
+
+def test_gemm_batched_f32(ops):
+    B, M, N, K = 3, 256, 192, 512
+    a, w = rnd(B, M, K, seed=1), rnd(B, N, K, seed=2)
+    out = ops.gemm_batched(a, w, alpha=K ** -0.5, out_f32=True)
+    ref = torch.einsum("bmk,bnk->bmn", a.float(), w.float()) * K ** -0.5
+    assert rel_l2(out, ref) < TOL_F32
+
+
+def test_gemm_rejects_bad_arguments(ops):
+    from asva_amd._lib import AvsdError
+
+    a, w = rnd(64, 36), rnd(64, 36)   # K not a multiple of 8
+    with pytest.raises(AvsdError):
+        ops.gemm(a, w)
+
+
+def test_linear_small_m(ops):
+    for M, N, K, ai, ao in [(2, 1280, 320, False, True), (2, 9000, 1280, True, False), (12, 640, 640, False, False), (24, 320, 320, True, True)]:
+        x = rndf(M, K, seed=1)
+        w = rnd(N, K, seed=2, scale=K ** -0.5)
+        b = rndf(N, seed=3)
+        out = ops.linear_small_m(x, w, b, act_in=ai, act_out=ao)
+        xin = F.silu(x) if ai else x
+        ref = xin @ w.float().T + b
+        ref = F.silu(ref) if ao else ref
+        assert rel_l2(out, ref) < TOL_F32 * 5
+
+
+# ---- normalisation -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("nb,rows,c1,c2,groups,act", [
+    (2, 12 * 64, 320, 0, 32, True),      # 5-D resnet norm
+    (24, 64, 640, 0, 32, False),         # per-frame transformer norm
+    (2, 12 * 16, 1280, 640, 32, True),   # concat with a group straddling the two sources (60 ch/group)
+    (2, 4 * 64, 80, 80, 16, True),       # tiny config, 10 ch/group
+    (1, 7 * 9, 2560, 0, 32, True),
+])
+def test_groupnorm(ops, nb, rows, c1, c2, groups, act):
+    x1 = rnd(nb * rows, c1, seed=1) + 0.5
+    x2 = rnd(nb * rows, c2, seed=2) * 2 if c2 else None
+    C = c1 + c2
+    gamma, beta = rndf(C, seed=3) + 1.0, rndf(C, seed=4)
+    eps = 1e-5
+    out = ops.groupnorm(x1, x2, nb, rows, groups, gamma, beta, eps, act)
+    x = torch.cat([x1, x2], 1) if c2 else x1
+    xr = x.float().reshape(nb, rows, C).permute(0, 2, 1)
+    ref = F.group_norm(xr, groups, gamma, beta, eps)
+    ref = (F.silu(ref) if act else ref).permute(0, 2, 1).reshape(nb * rows, C)
+    assert rel_l2(out, ref) < TOL_BF16
+
+
+@pytest.mark.parametrize("M,C", [(1000, 320), (257, 640), (64, 1280), (33, 80), (16, 2048)])
+def test_layernorm(ops, M, C):
+    x = rnd(M, C, seed=1) * 3 + 1
+    g, b = rndf(C, seed=2) + 1, rndf(C, seed=3)
+    out = ops.layernorm(x, g, b, 1e-5)
+    assert rel_l2(out, F.layer_norm(x.float(), (C,), g, b, 1e-5)) < TOL_BF16
+
+
+def test_layernorm_with_frame_pos(ops):
+    B, Fr, hw, C = 2, 12, 16, 320
+    x = rnd(B * Fr * hw, C, seed=1)
+    pos = rndf(Fr, C, seed=2)
+    g, b = rndf(C, seed=3) + 1, rndf(C, seed=4)
+    out = ops.layernorm(x, g, b, 1e-5, pos=pos, hw=hw, frames=Fr)
+    xp = x.float().reshape(B, Fr, hw, C) + pos[None, :, None, :]
+    assert rel_l2(out, F.layer_norm(xp, (C,), g, b, 1e-5).reshape(-1, C)) < TOL_BF16
+
+
+def test_softmax_rows(ops):
+    s = rndf(300, 1024, seed=1) * 4
+    out = ops.softmax_rows(s)
+    assert rel_l2(out, torch.softmax(s, -1)) < TOL_BF16
+
+
+# ---- attention -----------------------------------------------------------------------------------------
+def _sdpa_ref(q, k, v, heads):
+    # q [Bq, Lq, C], k/v [Bq, Lk, C]
+    Bq, Lq, C = q.shape
+    d = C // heads
+    qh = q.float().reshape(Bq, Lq, heads, d).transpose(1, 2)
+    kh = k.float().reshape(Bq, -1, heads, d).transpose(1, 2)
+    vh = v.float().reshape(Bq, -1, heads, d).transpose(1, 2)
+    o = F.scaled_dot_product_attention(qh, kh, vh)
+    return o.transpose(1, 2).reshape(Bq * Lq, C)
+
+
+@pytest.mark.parametrize("d", [40, 64, 80, 128, 160])
+@pytest.mark.parametrize("Lq,Lk", [(256, 256), (64, 64), (16, 16), (200, 77)])
+def test_attention_first_frame_layout(ops, d, Lq, Lk):
+    heads, B, Fr = 4, 2, 3
+    C = heads * d
+    q = rnd(B * Fr * Lq, C, seed=1)
+    kv = rnd(B * Lk, 2 * C, seed=2)          # fused k|v rows, one set per clip branch
+    k, v = kv[:, :C], kv[:, C:]
+    out = ops.attention(q, k, v, bq=B * Fr, lq=Lq, lk=Lk, kv_rows=Lk, heads=heads, q_per_kv=Fr, frames=Fr)
+    kk = k.reshape(B, 1, Lk, C).expand(B, Fr, Lk, C).reshape(B * Fr, Lk, C)
+    vv = v.reshape(B, 1, Lk, C).expand(B, Fr, Lk, C).reshape(B * Fr, Lk, C)
+    ref = _sdpa_ref(q.reshape(B * Fr, Lq, C), kk, vv, heads)
+    assert rel_l2(out, ref) < TOL_BF16
+
+
+def test_attention_key_gather_matches_bool_mask(ops):
+    # audio cross-attention: 229 keys, per-frame boolean mask == gather of the unmasked keys
+    from asva_amd.conditioning import audio_segment_mask, mask_to_key_index
+
+    heads, d, B, Fr, Lq = 8, 40, 2, 12, 64
+    C = heads * d
+    q = rnd(B * Fr * Lq, C, seed=1)
+    k, v = rnd(B * 229, C, seed=2), rnd(B * 229, C, seed=3)
+    mask = audio_segment_mask(Fr)                                  # [Fr, 229] bool
+    idx = mask_to_key_index(mask).to(dev())                        # [Fr, 25] int32
+    out = ops.attention(q, k, v, bq=B * Fr, lq=Lq, lk=idx.shape[1], kv_rows=229, heads=heads, q_per_kv=Fr,
+                        frames=Fr, key_index=idx)
+    qh = q.float().reshape(B, Fr, Lq, heads, d).permute(0, 1, 3, 2, 4)
+    kh = k.float().reshape(B, 1, 229, heads, d).permute(0, 1, 3, 2, 4).expand(B, Fr, heads, 229, d)
+    vh = v.float().reshape(B, 1, 229, heads, d).permute(0, 1, 3, 2, 4).expand(B, Fr, heads, 229, d)
+    m = mask.to(dev())[None, :, None, None, :]
+    ref = F.scaled_dot_product_attention(qh, kh, vh, attn_mask=m).permute(0, 1, 3, 2, 4).reshape(B * Fr * Lq, C)
+    assert rel_l2(out, ref) < TOL_BF16
+
+
+def test_attention_online_softmax_rescale(ops):
+    # a key far above the rest in a LATER tile forces the running-max rescale path
+    heads, d, Lq, Lk = 1, 64, 32, 96
+    q = rnd(Lq, d, seed=1)
+    k = rnd(Lk, d, seed=2)
+    v = rnd(Lk, d, seed=3)
+    k[70] = q[5] * 4
+    out = ops.attention(q, k, v, bq=1, lq=Lq, lk=Lk, kv_rows=Lk, heads=heads, q_per_kv=1, frames=1)
+    ref = _sdpa_ref(q[None], k[None], v[None], heads)
+    assert rel_l2(out, ref) < TOL_BF16
+
+
+@pytest.mark.parametrize("d", [40, 80, 160, 64])
+@pytest.mark.parametrize("Fr", [12, 24, 4])
+def test_temporal_attention(ops, d, Fr):
+    heads, B, hw = 8, 2, 24
+    if heads * Fr > 256:
+        heads = 256 // Fr
+    C = heads * d
+    qkv = rnd(B * Fr * hw, 3 * C, seed=1)
+    out = ops.temporal_attention(qkv, b=B, frames=Fr, hw=hw, heads=heads)
+    x = qkv.float().reshape(B, Fr, hw, 3, heads, d).permute(3, 0, 2, 4, 1, 5)   # [3, B, hw, heads, Fr, d]
+    o = F.scaled_dot_product_attention(x[0], x[1], x[2])                         # [B, hw, heads, Fr, d]
+    ref = o.permute(0, 3, 1, 2, 4).reshape(B * Fr * hw, C)
+    assert rel_l2(out, ref) < TOL_BF16
+
+
+# ---- elementwise ------------------------------------------------------------------------------------------
+def test_layout_roundtrip_and_replication(ops):
+    B, C, Fr, H, W = 2, 4, 3, 8, 8
+    x = rndf(B, C, Fr, H, W, seed=1)
+    rows = ops.ncfhw_to_rows(x, cpad=8, rep=2, scale=0.5)
+    ref = (0.5 * x).permute(0, 2, 3, 4, 1).reshape(-1, C).to(torch.bfloat16)
+    assert rows.shape == (2 * B * Fr * H * W, 8)
+    assert torch.equal(rows[: B * Fr * H * W, :C], ref) and torch.equal(rows[B * Fr * H * W:, :C], ref)
+    assert torch.count_nonzero(rows[:, C:]) == 0
+    r32 = rndf(B * Fr * H * W, 8, seed=2)
+    back = ops.rows_to_ncfhw(r32, B, C, Fr, H, W)
+    assert torch.equal(back, r32[:, :C].reshape(B, Fr, H, W, C).permute(0, 4, 1, 2, 3))
+
+
+def test_timestep_embedding(ops):
+    t = torch.tensor([0.0, 1.0, 981.0, 501.0], device=dev())
+    out = ops.timestep_embedding(t, 320)
+    half = 160
+    w = torch.exp(-math.log(10000.0) * torch.arange(half, device=dev(), dtype=torch.float32) / half)
+    arg = t[:, None] * w[None]
+    ref = torch.cat([torch.cos(arg), torch.sin(arg)], -1)
+    assert torch.allclose(out, ref, atol=2e-4)
+    assert torch.equal(out[0], torch.cat([torch.ones(half), torch.zeros(half)]).to(dev()))
+
+
+def test_guided_step(ops):
+    B, C, Fr, H, W = 1, 4, 5, 8, 8
+    npred = rndf(2 * B, C, Fr, H, W, seed=1)
+    x = rndf(B, C, Fr, H, W, seed=2)
+    hist = rndf(4, B, C, Fr, H, W, seed=3)
+    xo = torch.empty_like(x)
+    hist2 = hist.clone()
+    ops.guided_step(npred, 2, 4.0, x, xo, 0.9, -0.3, eps_hist=hist2, store_slot=2, w_cur=0.0, hist_idx=(2, 1, 0),
+                    w=(23 / 12, -16 / 12, 5 / 12))
+    eps = npred[:B] + 4.0 * (npred[B:] - npred[:B])
+    e = 23 / 12 * eps - 16 / 12 * hist[1] + 5 / 12 * hist[0]
+    ref = 0.9 * x - 0.3 * e
+    ref[:, :, 0] = x[:, :, 0]
+    assert torch.allclose(xo, ref, atol=1e-5)
+    assert torch.allclose(hist2[2], eps, atol=1e-6) and torch.equal(hist2[3], hist[3])
+    # DDIM form, no guidance, in place
+    x2 = x.clone()
+    ops.guided_step(npred[:B].contiguous(), 1, 1.0, x2, x2, 1.1, 0.2)
+    ref2 = 1.1 * x + 0.2 * npred[:B]
+    ref2[:, :, 0] = x[:, :, 0]
+    assert torch.allclose(x2, ref2, atol=1e-5)
+
+
+def test_vae_postprocess(ops):
+    n, H, W = 3, 16, 8
+    rows = rnd(n * H * W, 4, seed=1)
+    out = ops.vae_postprocess(rows, n, H, W)
+    ref = (rows[:, :3].float().reshape(n, H, W, 3).permute(0, 3, 1, 2) / 2 + 0.5).clamp(0, 1)
+    assert torch.allclose(out, ref, atol=1e-6)

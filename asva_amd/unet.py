@@ -1,0 +1,837 @@
+"""AudioUNet3DConditionModel — MI355X-native host mirror of the reference model class
+(avgen/models/unets/audio_cond_unet_3d_condition.py:56): same constructor/config keys, same
+state_dict (names and shapes), same forward signature and output, same from_pretrained /
+from_pretrained_2d / save_pretrained surface — but the modules below are PARAMETER HOLDERS only.
+`forward` packs the weights once into kernel layouts (one device blob) and drives the hand-written
+gfx950 kernels of libavsd_hip.so through asva_amd.ops.  There is no torch arithmetic path: without the
+HIP library (or a GPU) forward raises.
+
+Activation layout inside forward: channels-last bf16 matrices [B*F*H*W, C] ("rows"); f32 accumulation
+everywhere; the returned noise prediction is f32 in the reference's (B, C, F, H, W) layout.
+"""
+from __future__ import annotations
+
+import inspect
+import json
+import math
+import os
+from typing import Any, Dict, Optional, Tuple, Union
+
+import torch
+from torch import nn
+
+from . import ops
+from .conditioning import mask_to_key_index
+from .weights import pack_conv1x1, pack_conv3x3, pack_geglu, pack_linear
+
+CONFIG_NAME = "config.json"
+SAFETENSORS_NAME = "diffusion_pytorch_model.safetensors"
+BIN_NAME = "diffusion_pytorch_model.bin"
+
+DOWN_TYPES = ("FFSpatioAudioTempCrossAttnDownBlock3D", "FFSpatioTempCrossAttnDownBlock3D", "FFSpatioTempResDownBlock3D")
+UP_TYPES = ("FFSpatioAudioTempCrossAttnUpBlock3D", "FFSpatioTempCrossAttnUpBlock3D", "FFSpatioTempResUpBlock3D")
+MID_TYPES = ("FFSpatioAudioTempCrossAttnUNetMidBlock3D", "FFSpatioTempCrossAttnUNetMidBlock3D")
+
+
+class FrozenConfig(dict):
+    """Attribute-style read access, like diffusers' FrozenDict (`unet.config.in_channels`)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        raise AttributeError("config is read-only")
+
+
+class UNet3DConditionOutput:
+    """`.sample` holder (reference: UNet3DConditionOutput, audio_cond_unet_3d_condition.py:45-53)."""
+
+    def __init__(self, sample: torch.Tensor):
+        self.sample = sample
+
+    def __getitem__(self, i):
+        return (self.sample,)[i]
+
+
+# ---- parameter holders (never called) ---------------------------------------------------------------
+class _Affine(nn.Module):
+    """weight/bias of a GroupNorm or LayerNorm."""
+
+    def __init__(self, c: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+
+
+class _Linear(nn.Module):
+    def __init__(self, cin: int, cout: int, bias: bool = True, zero: bool = False):
+        super().__init__()
+        w = torch.zeros(cout, cin)
+        if not zero:
+            nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        self.weight = nn.Parameter(w)
+        if bias:
+            b = torch.zeros(cout)
+            if not zero:
+                nn.init.uniform_(b, -1 / math.sqrt(cin), 1 / math.sqrt(cin))
+            self.bias = nn.Parameter(b)
+        else:
+            self.register_parameter("bias", None)
+
+
+class _Conv(nn.Module):
+    def __init__(self, cin: int, cout: int, k: int):
+        super().__init__()
+        w = torch.empty(cout, cin, k, k)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        self.weight = nn.Parameter(w)
+        bound = 1 / math.sqrt(cin * k * k)
+        self.bias = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
+        self.kernel = k
+
+
+class _FFConv(_Conv):
+    """FFInflatedConv3d (utils.py:22-32): 2-D conv + zero-initialised temporal Linear(3C -> C)."""
+
+    def __init__(self, cin: int, cout: int, k: int):
+        super().__init__(cin, cout, k)
+        self.conv_temp = _Linear(3 * cout, cout, zero=True)
+
+
+class _TimestepMLP(nn.Module):
+    def __init__(self, cin: int, cout: int):
+        super().__init__()
+        self.linear_1 = _Linear(cin, cout)
+        self.linear_2 = _Linear(cout, cout)
+
+
+class _Attention(nn.Module):
+    def __init__(self, dim: int, ctx: Optional[int], zero_out: bool = False):
+        super().__init__()
+        ctx = ctx or dim
+        self.to_q = _Linear(dim, dim, bias=False)
+        self.to_k = _Linear(ctx, dim, bias=False)
+        self.to_v = _Linear(ctx, dim, bias=False)
+        out = _Linear(dim, dim)
+        if zero_out:
+            nn.init.zeros_(out.weight)      # ff_spatio_audio_temp_transformer_3d.py:267
+        self.to_out = nn.ModuleList([out])
+
+
+class _GEGLU(nn.Module):
+    def __init__(self, dim: int, inner: int):
+        super().__init__()
+        self.proj = _Linear(dim, 2 * inner)
+
+
+class _FeedForward(nn.Module):
+    def __init__(self, dim: int):
+        super().__init__()
+        self.net = nn.ModuleList([_GEGLU(dim, 4 * dim), nn.Identity(), _Linear(4 * dim, dim)])
+
+
+class _TransformerBlock(nn.Module):
+    def __init__(self, dim: int, text_dim: int, audio_dim: Optional[int]):
+        super().__init__()
+        self.norm1 = _Affine(dim)
+        self.attn1 = _Attention(dim, None)
+        if audio_dim is not None:
+            self.norm_audio = _Affine(dim)
+            self.attn_audio = _Attention(dim, audio_dim)
+        self.norm2 = _Affine(dim)
+        self.attn2 = _Attention(dim, text_dim)
+        self.pos_embedding_temp = _TimestepMLP(dim, dim)
+        self.attn_temp = _Attention(dim, None, zero_out=True)
+        self.norm_temp = _Affine(dim)
+        self.norm3 = _Affine(dim)
+        self.ff = _FeedForward(dim)
+
+
+class _Transformer3D(nn.Module):
+    def __init__(self, dim: int, text_dim: int, audio_dim: Optional[int]):
+        super().__init__()
+        self.norm = _Affine(dim)
+        self.proj_in = _Conv(dim, dim, 1)
+        self.transformer_blocks = nn.ModuleList([_TransformerBlock(dim, text_dim, audio_dim)])
+        self.proj_out = _Conv(dim, dim, 1)
+
+
+class _ResBlock(nn.Module):
+    def __init__(self, cin: int, cout: int, temb: int):
+        super().__init__()
+        self.norm1 = _Affine(cin)
+        self.conv1 = _FFConv(cin, cout, 3)
+        self.time_emb_proj = _Linear(temb, cout)
+        self.norm2 = _Affine(cout)
+        self.conv2 = _FFConv(cout, cout, 3)
+        if cin != cout:
+            self.conv_shortcut = _FFConv(cin, cout, 1)
+
+
+class _Sampler(nn.Module):
+    def __init__(self, c: int):
+        super().__init__()
+        self.conv = _FFConv(c, c, 3)
+
+
+class _Block(nn.Module):
+    """resnets (+ attentions) (+ down/up sampler) — covers all down / mid / up block types."""
+
+    def __init__(self, res_io, temb, attn_dim=None, text_dim=None, audio_dim=None, down=None, up=None, n_attn=None):
+        super().__init__()
+        self.resnets = nn.ModuleList([_ResBlock(i, o, temb) for i, o in res_io])
+        if attn_dim is not None:
+            n = len(res_io) if n_attn is None else n_attn
+            self.attentions = nn.ModuleList([_Transformer3D(attn_dim, text_dim, audio_dim) for _ in range(n)])
+        if down:
+            self.downsamplers = nn.ModuleList([_Sampler(down)])
+        if up:
+            self.upsamplers = nn.ModuleList([_Sampler(up)])
+
+
+# ---- packed (kernel-layout) views ---------------------------------------------------------------------
+class _Pk:
+    """attribute bag of device tensors (views into the packed blob)."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class _Ref:
+    """placeholder for item `idx` of the packed blob until the blob exists"""
+
+    def __init__(self, idx: int):
+        self.idx = idx
+
+
+def _per_block(v, n):
+    return tuple(v) if isinstance(v, (list, tuple)) else (v,) * n
+
+
+class AudioUNet3DConditionModel(nn.Module):
+    config_name = CONFIG_NAME
+
+    def __init__(
+        self,
+        sample_size: Optional[int] = None,
+        in_channels: int = 4,
+        out_channels: int = 4,
+        center_input_sample: bool = False,
+        flip_sin_to_cos: bool = True,
+        freq_shift: int = 0,
+        down_block_types: Tuple[str, ...] = (
+            "FFSpatioAudioTempCrossAttnDownBlock3D",
+            "FFSpatioAudioTempCrossAttnDownBlock3D",
+            "FFSpatioAudioTempCrossAttnDownBlock3D",
+            "FFSpatioTempResDownBlock3D",
+        ),
+        mid_block_type: Optional[str] = "FFSpatioAudioTempCrossAttnUNetMidBlock3D",
+        up_block_types: Tuple[str, ...] = (
+            "FFSpatioTempResUpBlock3D",
+            "FFSpatioAudioTempCrossAttnUpBlock3D",
+            "FFSpatioAudioTempCrossAttnUpBlock3D",
+            "FFSpatioAudioTempCrossAttnUpBlock3D",
+        ),
+        only_cross_attention: Union[bool, Tuple[bool, ...]] = False,
+        block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280),
+        layers_per_block: Union[int, Tuple[int, ...]] = 2,
+        downsample_padding: int = 1,
+        mid_block_scale_factor: float = 1,
+        act_fn: str = "silu",
+        norm_num_groups: Optional[int] = 32,
+        norm_eps: float = 1e-5,
+        cross_attention_dim: Union[int, Tuple[int, ...]] = 1280,
+        encoder_hid_dim: Optional[int] = None,
+        attention_head_dim: Union[int, Tuple[int, ...]] = 8,
+        dual_cross_attention: bool = False,
+        use_linear_projection: bool = False,
+        class_embed_type: Optional[str] = None,
+        addition_embed_type: Optional[str] = None,
+        num_class_embeds: Optional[int] = None,
+        upcast_attention: bool = False,
+        resnet_time_scale_shift: str = "default",
+        resnet_skip_time_act: bool = False,
+        resnet_out_scale_factor: float = 1.0,
+        time_embedding_type: str = "positional",
+        time_embedding_dim: Optional[int] = None,
+        time_embedding_act_fn: Optional[str] = None,
+        timestep_post_act: Optional[str] = None,
+        time_cond_proj_dim: Optional[int] = None,
+        conv_in_kernel: int = 3,
+        conv_out_kernel: int = 3,
+        projection_class_embeddings_input_dim: Optional[int] = None,
+        class_embeddings_concat: bool = False,
+        mid_block_only_cross_attention: Optional[bool] = None,
+        cross_attention_norm: Optional[str] = None,
+        addition_embed_type_num_heads: int = 64,
+        audio_cross_attention_dim: int = 768,
+    ):
+        super().__init__()
+        frame = inspect.currentframe()
+        names = [p for p in inspect.signature(AudioUNet3DConditionModel.__init__).parameters if p != "self"]
+        cfg = {k: frame.f_locals[k] for k in names}
+        for k, v in list(cfg.items()):
+            if isinstance(v, list):
+                cfg[k] = tuple(v)
+        self._config = FrozenConfig(cfg)
+        self.sample_size = sample_size
+        self._check_supported(cfg)
+
+        ch = tuple(block_out_channels)
+        nblk = len(ch)
+        temb = time_embedding_dim or ch[0] * 4
+        layers = _per_block(layers_per_block, nblk)
+        text_dims = _per_block(cross_attention_dim, nblk)
+        adim = audio_cross_attention_dim
+
+        def audio_of(btype):
+            return adim if "Audio" in btype else None
+
+        self.conv_in = _FFConv(in_channels, ch[0], 3)
+        self.time_embedding = _TimestepMLP(ch[0], temb)
+
+        self.down_blocks = nn.ModuleList()
+        out_c = ch[0]
+        for i, bt in enumerate(down_block_types):
+            in_c, out_c = out_c, ch[i]
+            io = [(in_c if j == 0 else out_c, out_c) for j in range(layers[i])]
+            attn = out_c if "CrossAttn" in bt else None
+            self.down_blocks.append(_Block(io, temb, attn, text_dims[i], audio_of(bt),
+                                           down=out_c if i < nblk - 1 else None))
+
+        self.mid_block = _Block([(ch[-1], ch[-1]), (ch[-1], ch[-1])], temb, ch[-1], text_dims[-1],
+                                audio_of(mid_block_type), n_attn=1)
+
+        self.up_blocks = nn.ModuleList()
+        rch = ch[::-1]
+        rlayers = layers[::-1]
+        rtext = text_dims[::-1]
+        out_c = rch[0]
+        for i, bt in enumerate(up_block_types):
+            prev, out_c = out_c, rch[i]
+            in_c = rch[min(i + 1, nblk - 1)]
+            n = rlayers[i] + 1
+            io = []
+            for j in range(n):
+                skip = in_c if j == n - 1 else out_c
+                rin = prev if j == 0 else out_c
+                io.append((rin + skip, out_c))
+            attn = out_c if "CrossAttn" in bt else None
+            self.up_blocks.append(_Block(io, temb, attn, rtext[i], audio_of(bt), up=out_c if i < nblk - 1 else None))
+
+        self.conv_norm_out = _Affine(ch[0])
+        self.conv_out = _FFConv(ch[0], out_channels, 3)
+
+        self._packed = None
+        self._cond = None
+        self._cond_key = None
+
+    # ---- config / (de)serialisation surface ---------------------------------------------------------
+    @property
+    def config(self) -> FrozenConfig:
+        return self._config
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return next(self.parameters()).dtype
+
+    @property
+    def device(self) -> torch.device:
+        return next(self.parameters()).device
+
+    @staticmethod
+    def _check_supported(c):
+        def need(cond, msg):
+            if not cond:
+                raise NotImplementedError(f"AudioUNet3DConditionModel (MI355X path): {msg}")
+
+        need(all(t in DOWN_TYPES for t in c["down_block_types"]), f"down_block_types {c['down_block_types']}")
+        need(all(t in UP_TYPES for t in c["up_block_types"]), f"up_block_types {c['up_block_types']}")
+        need(c["mid_block_type"] in MID_TYPES, f"mid_block_type {c['mid_block_type']}")
+        need(len(c["down_block_types"]) == len(c["up_block_types"]) == len(c["block_out_channels"]), "block list lengths differ")
+        need(c["act_fn"] in ("silu", "swish"), "act_fn must be silu")
+        need(c["time_embedding_type"] == "positional" and c["flip_sin_to_cos"] and c["freq_shift"] == 0, "time embedding variant")
+        need(c["resnet_time_scale_shift"] == "default", "resnet_time_scale_shift")
+        need(not c["use_linear_projection"] and not c["dual_cross_attention"], "linear projection / dual cross attention")
+        need(c["class_embed_type"] is None and c["num_class_embeds"] is None and c["addition_embed_type"] is None, "class/addition embeddings")
+        need(c["encoder_hid_dim"] is None and c["time_embedding_act_fn"] is None and c["timestep_post_act"] is None and c["time_cond_proj_dim"] is None, "extra embedding options")
+        need(c["only_cross_attention"] is False and not c["center_input_sample"], "only_cross_attention / center_input_sample")
+        need(c["conv_in_kernel"] == 3 and c["conv_out_kernel"] == 3 and c["downsample_padding"] == 1, "conv kernel sizes")
+        need(c["norm_num_groups"] is not None, "norm_num_groups=None")
+        need(float(c["mid_block_scale_factor"]) == 1.0 and float(c["resnet_out_scale_factor"]) == 1.0, "output scale factors")
+        heads = _per_block(c["attention_head_dim"], len(c["block_out_channels"]))
+        for chn, h in zip(c["block_out_channels"], heads):
+            need(chn % 8 == 0 and chn % h == 0 and (chn // h) in (40, 64, 80, 128, 160), f"head dim {chn}/{h} not in 40/64/80/128/160")
+            need(chn % c["norm_num_groups"] == 0, "channels not divisible by norm groups")
+
+    @classmethod
+    def from_config(cls, config: Dict[str, Any], **kwargs):
+        sig = inspect.signature(cls.__init__).parameters
+        args = {k: v for k, v in dict(config).items() if k in sig and not k.startswith("_")}
+        args.update(kwargs)
+        return cls(**args)
+
+    @classmethod
+    def load_config(cls, path: str, subfolder: Optional[str] = None) -> Dict[str, Any]:
+        if subfolder:
+            path = os.path.join(path, subfolder)
+        with open(os.path.join(path, CONFIG_NAME)) as f:
+            return json.load(f)
+
+    @staticmethod
+    def _read_weights(path: str) -> Dict[str, torch.Tensor]:
+        st = os.path.join(path, SAFETENSORS_NAME)
+        if os.path.isfile(st):
+            from safetensors.torch import load_file
+
+            return load_file(st)
+        bn = os.path.join(path, BIN_NAME)
+        if os.path.isfile(bn):
+            return torch.load(bn, map_location="cpu", weights_only=True)
+        raise FileNotFoundError(f"no {SAFETENSORS_NAME} or {BIN_NAME} under {path}")
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_path: str, subfolder: Optional[str] = None, torch_dtype=None, **_):
+        """Reads the diffusers directory layout the reference trainer writes
+        (audio_cond_animation_trainer.py:152-155; loaded at pipeline_audio_cond_animation.py:516)."""
+        path = os.path.join(pretrained_model_path, subfolder) if subfolder else pretrained_model_path
+        model = cls.from_config(cls.load_config(path))
+        model.load_state_dict(cls._read_weights(path))
+        if torch_dtype is not None:
+            model = model.to(torch_dtype)
+        return model.eval()
+
+    @classmethod
+    def from_pretrained_2d(cls, config3d, pretrained_model_path: str, subfolder: Optional[str] = None):
+        """2-D -> 3-D inflation (audio_cond_unet_3d_condition.py:800-838): every key containing
+        '_temp', every key missing from the 2-D checkpoint and every shape mismatch keeps the fresh init."""
+        path = os.path.join(pretrained_model_path, subfolder) if subfolder else pretrained_model_path
+        cfg = cls.load_config(path)
+        cfg["_class_name"] = cls.__name__
+        cfg["down_block_types"] = tuple(config3d["down_block_types"])
+        cfg["up_block_types"] = tuple(config3d["up_block_types"])
+        cfg["mid_block_type"] = config3d["mid_block_type"]
+        for k in ("cross_attention_dim", "audio_cross_attention_dim"):
+            if k in config3d:
+                cfg[k] = config3d[k]
+        model = cls.from_config(cfg)
+        sd2d = cls._read_weights(path)
+        for k, v in model.state_dict().items():
+            if "_temp" in k or k not in sd2d or sd2d[k].shape != v.shape:
+                sd2d[k] = v
+        model.load_state_dict({k: sd2d[k] for k in model.state_dict()})
+        return model
+
+    def save_pretrained(self, save_directory: str, safe_serialization: bool = True):
+        os.makedirs(save_directory, exist_ok=True)
+        cfg = {"_class_name": type(self).__name__, "_diffusers_version": "0.29.2"}
+        cfg.update({k: (list(v) if isinstance(v, tuple) else v) for k, v in self.config.items()})
+        with open(os.path.join(save_directory, CONFIG_NAME), "w") as f:
+            json.dump(cfg, f, indent=2)
+        sd = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}
+        if safe_serialization:
+            from safetensors.torch import save_file
+
+            save_file(sd, os.path.join(save_directory, SAFETENSORS_NAME))
+        else:
+            torch.save(sd, os.path.join(save_directory, BIN_NAME))
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._invalidate()
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._invalidate()
+        return r
+
+    def _invalidate(self):
+        self._packed = None
+        self._cond = None
+        self._cond_key = None
+
+    # attention-processor plug-in protocol of the reference (:469-527).  The fused gfx950 kernels ARE the
+    # processor on this path; the hooks exist so callers that enumerate / reset processors keep working.
+    @property
+    def attn_processors(self) -> Dict[str, Any]:
+        return {f"{n}.processor": "avsd_hip" for n, m in self.named_modules() if isinstance(m, _Attention)}
+
+    def set_attn_processor(self, processor):
+        if isinstance(processor, dict) and len(processor) != len(self.attn_processors):
+            raise ValueError(f"expected {len(self.attn_processors)} processors, got {len(processor)}")
+
+    def set_default_attn_processor(self):
+        pass
+
+    def set_attention_slice(self, slice_size):
+        pass  # memory-saving knob of the reference (:529-592); the flash-style kernels never materialise L x L
+
+    # ---- packing ------------------------------------------------------------------------------------------
+    def pack(self, device: Optional[torch.device] = None):
+        """state_dict -> kernel layouts inside ONE device blob (so multi-GPU start-up is a single RCCL
+        broadcast, see asva_amd.dist).  Returns the structure of typed views."""
+        if self._packed is not None and (device is None or self._packed.blob.device == torch.device(device)):
+            return self._packed
+        device = torch.device(device) if device is not None else self.device
+        if device.type != "cuda" and not getattr(ops, "EMULATED", False):   # EMULATED: tests/emu_ops.py seam
+            raise RuntimeError("AudioUNet3DConditionModel.pack: the MI355X path needs a cuda (HIP) device; "
+                               "move the model with .to('cuda') first — there is no CPU compute path")
+        items = []   # (setter, cpu tensor)
+
+        def reg(t: torch.Tensor):
+            items.append(t.contiguous())
+            return _Ref(len(items) - 1)
+
+        def lin(m: _Linear):
+            return _Pk(w=reg(pack_linear(m.weight.float().cpu())), b=None if m.bias is None else reg(m.bias.detach().float().cpu()))
+
+        def aff(m: _Affine):
+            return _Pk(g=reg(m.weight.detach().float().cpu()), b=reg(m.bias.detach().float().cpu()))
+
+        def ffconv(m: _FFConv):
+            cout, cin = m.weight.shape[:2]
+            cop = (cout + 7) // 8 * 8
+            cip = (cin + 7) // 8 * 8
+            w = m.weight.detach().float().cpu()
+            if m.kernel == 3:
+                wp = pack_conv3x3(w, cip, cop)
+            else:
+                wp = torch.zeros(cop, cip, dtype=torch.bfloat16)
+                wp[:cout, :cin] = pack_conv1x1(w)
+            b = torch.zeros(cop)
+            b[:cout] = m.bias.detach().float().cpu()
+            wt = torch.zeros(cop, 3, cop)
+            wt[:cout, :, :cout] = m.conv_temp.weight.detach().float().cpu().reshape(cout, 3, cout)
+            bt = torch.zeros(cop)
+            bt[:cout] = m.conv_temp.bias.detach().float().cpu()
+            return _Pk(w=reg(wp), b=reg(b), wt=reg(wt.reshape(cop, 3 * cop).to(torch.bfloat16)), bt=reg(bt),
+                       cout=cop, cin=cip, k=m.kernel)
+
+        def conv1(m: _Conv):
+            return _Pk(w=reg(pack_conv1x1(m.weight.float().cpu())), b=reg(m.bias.detach().float().cpu()))
+
+        def attn(m: _Attention, fuse_qkv: bool):
+            wq, wk, wv = (x.weight.detach().float().cpu() for x in (m.to_q, m.to_k, m.to_v))
+            o = m.to_out[0]
+            p = _Pk(wo=reg(pack_linear(o.weight.float().cpu())), bo=reg(o.bias.detach().float().cpu()))
+            if fuse_qkv:
+                p.wqkv = reg(pack_linear(torch.cat([wq, wk, wv], 0)))
+            else:
+                p.wq = reg(pack_linear(wq))
+                p.wkv = reg(pack_linear(torch.cat([wk, wv], 0)))
+            return p
+
+        temb_w, temb_b, temb_off = [], [], [0]
+
+        def res(m: _ResBlock):
+            p = _Pk(norm1=aff(m.norm1), conv1=ffconv(m.conv1), norm2=aff(m.norm2), conv2=ffconv(m.conv2),
+                    shortcut=ffconv(m.conv_shortcut) if hasattr(m, "conv_shortcut") else None,
+                    temb_off=temb_off[0], cout=m.conv1.weight.shape[0])
+            temb_w.append(m.time_emb_proj.weight.detach().float().cpu())
+            temb_b.append(m.time_emb_proj.bias.detach().float().cpu())
+            temb_off[0] += p.cout
+            return p
+
+        def tr(m: _Transformer3D):
+            b = m.transformer_blocks[0]
+            w1, b1 = pack_geglu(b.ff.net[0].proj.weight.detach().float().cpu(), b.ff.net[0].proj.bias.detach().float().cpu())
+            p = _Pk(norm=aff(m.norm), proj_in=conv1(m.proj_in), proj_out=conv1(m.proj_out),
+                    norm1=aff(b.norm1), attn1=attn(b.attn1, False),
+                    norm2=aff(b.norm2), attn2=attn(b.attn2, False),
+                    norm_temp=aff(b.norm_temp), attn_temp=attn(b.attn_temp, True),
+                    pos1=lin(b.pos_embedding_temp.linear_1), pos2=lin(b.pos_embedding_temp.linear_2),
+                    norm3=aff(b.norm3), w1=reg(w1), b1=reg(b1), ff2=lin(b.ff.net[2]),
+                    dim=m.proj_in.weight.shape[0], audio=hasattr(b, "attn_audio"))
+            if p.audio:
+                p.norm_audio = aff(b.norm_audio)
+                p.attn_audio = attn(b.attn_audio, False)
+            return p
+
+        def block(m: _Block):
+            return _Pk(resnets=[res(r) for r in m.resnets],
+                       attentions=[tr(a) for a in m.attentions] if hasattr(m, "attentions") else None,
+                       down=ffconv(m.downsamplers[0].conv) if hasattr(m, "downsamplers") else None,
+                       up=ffconv(m.upsamplers[0].conv) if hasattr(m, "upsamplers") else None)
+
+        pk = _Pk(conv_in=ffconv(self.conv_in), t1=lin(self.time_embedding.linear_1), t2=lin(self.time_embedding.linear_2),
+                 down=[block(b) for b in self.down_blocks], mid=block(self.mid_block), up=[block(b) for b in self.up_blocks],
+                 norm_out=aff(self.conv_norm_out), conv_out=ffconv(self.conv_out))
+        pk.temb_w = reg(pack_linear(torch.cat(temb_w, 0)))
+        pk.temb_b = reg(torch.cat(temb_b, 0))
+        pk.temb_total = temb_off[0]
+
+        # lay the items out in one blob, 256-byte aligned
+        offs, total = [], 0
+        for t in items:
+            offs.append(total)
+            total += (t.numel() * t.element_size() + 255) // 256 * 256
+        host = torch.empty(total, dtype=torch.uint8)
+        for t, o in zip(items, offs):
+            nb = t.numel() * t.element_size()
+            host[o:o + nb] = t.reshape(-1).view(torch.uint8)
+        blob = host.to(device)
+        views = []
+        for t, o in zip(items, offs):
+            nb = t.numel() * t.element_size()
+            views.append(blob[o:o + nb].view(t.dtype).view(t.shape))
+
+        def resolve(obj):
+            if isinstance(obj, _Pk):
+                for k, v in list(obj.__dict__.items()):
+                    if isinstance(v, _Ref):
+                        obj.__dict__[k] = views[v.idx]
+                    else:
+                        resolve(v)
+            elif isinstance(obj, list):
+                for v in obj:
+                    resolve(v)
+
+        resolve(pk)
+        pk.blob = blob
+        self._packed = pk
+        return pk
+
+    # ---- conditioning (step-invariant work, once per clip) ---------------------------------------------
+    @torch.no_grad()
+    def set_conditioning(self, encoder_hidden_states: torch.Tensor, audio_encoder_hidden_states: Optional[torch.Tensor],
+                         audio_attention_mask: Optional[torch.Tensor], video_length: int):
+        """Caches everything that does not depend on the latents or the timestep: the audio / text K,V
+        projections of all 16 transformer blocks (ff_spatio_audio_temp_transformer_3d.py:319-341 recomputes
+        them every step from constant inputs), the temporal position MLP output (:348-349) and the key
+        gather list of the audio segment mask.
+
+        encoder_hidden_states (B, 77, D) or (B, F, 77, D); audio (B, 229, D) or (B, F, 229, D);
+        mask (F, 229) / (B, F, 229) bool, True = visible.  4-D inputs whose frame stride is 0 (the
+        pipeline's `repeat`) are treated as 3-D; genuinely per-frame inputs are projected per frame."""
+        pk = self.pack()
+        dev = pk.blob.device
+        Fr = video_length
+
+        def rows(x):
+            if x is None:
+                return None, 1
+            per_frame = 1
+            if x.dim() == 4:
+                if x.stride(1) == 0 or x.shape[1] == 1:
+                    x = x[:, 0]
+                else:
+                    per_frame = x.shape[1]
+                    x = x.reshape(x.shape[0] * x.shape[1], *x.shape[2:])
+            return x.to(device=dev, dtype=torch.bfloat16).contiguous(), per_frame
+
+        text, text_pf = rows(encoder_hidden_states)
+        audio, audio_pf = rows(audio_encoder_hidden_states)
+        key_index, idx_frames = None, Fr
+        if audio_attention_mask is not None:
+            m = audio_attention_mask.detach().to("cpu", torch.bool)
+            if m.dim() == 3:
+                if bool((m == m[:1]).all()):
+                    m = m[0]
+                else:
+                    m = m.reshape(-1, m.shape[-1])          # per (b, f) lists; kernel indexes qb % (B*F)
+            if not bool(m.all()):
+                key_index = mask_to_key_index(m).to(dev)
+                idx_frames = m.shape[0]
+        ar = torch.arange(Fr, dtype=torch.float32, device=dev)
+        blocks = []
+        for tp in self._transformers(pk):
+            C = tp.dim
+            c = _Pk()
+            tb = text.reshape(-1, text.shape[-1])
+            c.text_kv = ops.gemm(tb, tp.attn2.wkv)
+            c.text_len, c.text_pf = text.shape[1], text_pf
+            if tp.audio:
+                if audio is None:
+                    raise ValueError("audio_encoder_hidden_states is required by the audio cross-attention blocks")
+                ab = audio.reshape(-1, audio.shape[-1])
+                c.audio_kv = ops.gemm(ab, tp.attn_audio.wkv)
+                c.audio_len, c.audio_pf = audio.shape[1], audio_pf
+            emb = ops.timestep_embedding(ar, C)
+            hid = ops.linear_small_m(emb, tp.pos1.w, tp.pos1.b, act_out=True)
+            c.pos = ops.linear_small_m(hid, tp.pos2.w, tp.pos2.b)
+            blocks.append(c)
+        self._cond = _Pk(blocks=blocks, key_index=key_index, idx_frames=idx_frames, frames=Fr,
+                         batch=text.shape[0] // text_pf)
+        return self._cond
+
+    @staticmethod
+    def _transformers(pk):
+        for b in list(pk.down) + [pk.mid] + list(pk.up):
+            if b.attentions:
+                yield from b.attentions
+
+    # ---- forward ------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(
+        self,
+        sample: torch.Tensor,
+        timestep: Union[torch.Tensor, float, int],
+        encoder_hidden_states: Optional[torch.Tensor] = None,
+        audio_encoder_hidden_states: Optional[torch.Tensor] = None,
+        class_labels=None,
+        timestep_cond=None,
+        attention_mask=None,
+        audio_attention_mask: Optional[torch.Tensor] = None,
+        cross_attention_kwargs=None,
+        down_block_additional_residuals=None,
+        mid_block_additional_residual=None,
+        return_dict: bool = True,
+    ):
+        """Same contract as the reference forward (audio_cond_unet_3d_condition.py:598-798): sample
+        (B, C, F, H, W), timestep scalar or (B,), conditioning as the pipeline passes it.  When the
+        conditioning arguments are omitted the cache of `set_conditioning` is used (the denoising loop
+        passes constant conditioning 50 times)."""
+        for name, v in (("class_labels", class_labels), ("timestep_cond", timestep_cond), ("attention_mask", attention_mask),
+                        ("cross_attention_kwargs", cross_attention_kwargs),
+                        ("down_block_additional_residuals", down_block_additional_residuals),
+                        ("mid_block_additional_residual", mid_block_additional_residual)):
+            if v is not None:
+                raise NotImplementedError(f"{name} is not on the AVSyncD inference path")
+        assert sample.ndim == 5, sample.size()
+        pk = self.pack()
+        B, Cin, Fr, H, W = sample.shape
+        nblk = len(self.config.block_out_channels)
+        if H % (1 << (nblk - 1)) or W % (1 << (nblk - 1)):
+            raise NotImplementedError("latent H, W must be multiples of 2**(num_blocks-1)")
+        if encoder_hidden_states is not None:
+            key = tuple((t.data_ptr(), tuple(t.shape), t._version) if t is not None else None
+                        for t in (encoder_hidden_states, audio_encoder_hidden_states, audio_attention_mask)) + (Fr,)
+            if self._cond is None or self._cond_key != key:
+                self.set_conditioning(encoder_hidden_states, audio_encoder_hidden_states, audio_attention_mask, Fr)
+                self._cond_key = key
+        if self._cond is None:
+            raise RuntimeError("no conditioning: pass encoder_hidden_states or call set_conditioning first")
+        cond = self._cond
+        if cond.frames != Fr or cond.batch != B:
+            raise ValueError(f"conditioning was prepared for batch {cond.batch} x {cond.frames} frames, sample has {B} x {Fr}")
+        dev = pk.blob.device
+        in_dtype = sample.dtype
+        x32 = sample.to(device=dev, dtype=torch.float32).contiguous()
+
+        # -- time embedding: sinusoid -> MLP -> all 22 time_emb_proj at once (:657-681, resnet :170)
+        if torch.is_tensor(timestep):
+            t = timestep.to(device=dev, dtype=torch.float32).reshape(-1)
+        else:
+            t = torch.full((1,), float(timestep), dtype=torch.float32, device=dev)
+        if t.numel() not in (1, B):
+            raise ValueError("timestep must be a scalar or have one entry per batch element")
+        ch0 = self.config.block_out_channels[0]
+        e = ops.timestep_embedding(t, ch0)
+        e = ops.linear_small_m(e, pk.t1.w, pk.t1.b, act_out=True)
+        e = ops.linear_small_m(e, pk.t2.w, pk.t2.b)
+        temb = ops.linear_small_m(e, pk.temb_w, pk.temb_b, act_in=True)          # [1 or B, sum(Cout)]
+        st = _Pk(B=B, F=Fr, temb=temb, temb_rows=(Fr if t.numel() == B else B * Fr), cond=cond, tr_i=0,
+                 groups=self.config.norm_num_groups, eps=float(self.config.norm_eps),
+                 heads=_per_block(self.config.attention_head_dim, nblk))
+
+        h = ops.ncfhw_to_rows(x32, cpad=pk.conv_in.cin)
+        hw = (H, W)
+        h = self._ffconv(st, h, pk.conv_in, hw)
+        skips = [h]
+        for i, blk in enumerate(pk.down):
+            for j, r in enumerate(blk.resnets):
+                h = self._resblock(st, h, None, r, hw)
+                if blk.attentions:
+                    h = self._transformer(st, h, blk.attentions[j], hw, st.heads[i])
+                skips.append(h)
+            if blk.down is not None:
+                h = self._ffconv(st, h, blk.down, hw, stride=2)
+                hw = (hw[0] // 2, hw[1] // 2)
+                skips.append(h)
+        h = self._resblock(st, h, None, pk.mid.resnets[0], hw)
+        h = self._transformer(st, h, pk.mid.attentions[0], hw, st.heads[-1])
+        h = self._resblock(st, h, None, pk.mid.resnets[1], hw)
+        rheads = st.heads[::-1]
+        for i, blk in enumerate(pk.up):
+            for j, r in enumerate(blk.resnets):
+                h = self._resblock(st, h, skips.pop(), r, hw)
+                if blk.attentions:
+                    h = self._transformer(st, h, blk.attentions[j], hw, rheads[i])
+            if blk.up is not None:
+                h = self._ffconv(st, h, blk.up, hw, ups=1)
+                hw = (hw[0] * 2, hw[1] * 2)
+        a = ops.groupnorm(h, None, B, Fr * hw[0] * hw[1], st.groups, pk.norm_out.g, pk.norm_out.b, st.eps, True)
+        o = self._ffconv(st, a, pk.conv_out, hw, out_f32=True)
+        out = ops.rows_to_ncfhw(o, B, self.config.out_channels, Fr, H, W)
+        if in_dtype != torch.float32:
+            out = out.to(in_dtype)
+        if not return_dict:
+            return (out,)
+        return UNet3DConditionOutput(sample=out)
+
+    # FFInflatedConv3d (utils.py:34-57): conv GEMM, then the temporal-mix GEMM whose epilogue also adds the
+    # time embedding (resnet :173) and the residual / shortcut (resnet :189)
+    def _ffconv(self, st, x, p, hw, stride=1, ups=0, temb=None, res=None, out_f32=False, x2=None):
+        n_img = st.B * st.F
+        if p.k == 3:
+            y = ops.gemm(x, p.w, bias=p.b, mode=ops.CONV3, conv=(n_img, hw[0], hw[1], stride, ups))
+            ho = ((hw[0] << ups) + 2 - 3) // stride + 1
+            wo = ((hw[1] << ups) + 2 - 3) // stride + 1
+        else:
+            y = ops.gemm(x, p.w, a2=x2, bias=p.b)
+            ho, wo = hw
+        return ops.gemm(y, p.wt, bias=p.bt, res1=y, res2=res, rowvec=temb,
+                        rows_per_vec=(st.temb_rows * ho * wo) if temb is not None else 0,
+                        mode=ops.TMIX, tmix=(ho * wo, st.F), out_f32=out_f32)
+
+    # FFSpatioTempResnetBlock3D.forward (ff_spatio_temp_resnet_3d.py:161-191); `skip` is the UNet skip tensor
+    # that the reference torch.cat's onto x (unet_3d_blocks.py:358,1038) — never materialised here
+    def _resblock(self, st, x, skip, p, hw):
+        rows_b = st.F * hw[0] * hw[1]
+        a = ops.groupnorm(x, skip, st.B, rows_b, st.groups, p.norm1.g, p.norm1.b, st.eps, True)
+        tv = st.temb[:, p.temb_off:p.temb_off + p.cout]
+        h = self._ffconv(st, a, p.conv1, hw, temb=tv)
+        a2 = ops.groupnorm(h, None, st.B, rows_b, st.groups, p.norm2.g, p.norm2.b, st.eps, True)
+        if p.shortcut is not None:
+            s = self._ffconv(st, x, p.shortcut, hw, x2=skip)
+        else:
+            assert skip is None
+            s = x
+        return self._ffconv(st, a2, p.conv2, hw, res=s)
+
+    # FFSpatioAudioTempTransformer3DModel.forward + BasicTransformerBlock.forward
+    # (ff_spatio_audio_temp_transformer_3d.py:94-158, :278-373)
+    def _transformer(self, st, x, p, hw, heads):
+        B, Fr = st.B, st.F
+        L = hw[0] * hw[1]
+        C = p.dim
+        c = st.cond.blocks[st.tr_i]
+        st.tr_i += 1
+        n = ops.groupnorm(x, None, B * Fr, L, st.groups, p.norm.g, p.norm.b, 1e-6, False)
+        h = ops.gemm(n, p.proj_in.w, bias=p.proj_in.b)
+        # 1. first-frame attention: Q from every frame, K/V projected for frame 0 only (utils.py:133-143)
+        n1 = ops.layernorm(h, p.norm1.g, p.norm1.b)
+        q = ops.gemm(n1, p.attn1.wq)
+        kv = ops.gemm_batched(n1.view(B, Fr * L, C)[:, :L], p.attn1.wkv.unsqueeze(0).expand(B, 2 * C, C)).view(B * L, 2 * C)
+        o = ops.attention(q, kv[:, :C], kv[:, C:], bq=B * Fr, lq=L, lk=L, kv_rows=L, heads=heads, q_per_kv=Fr, frames=Fr)
+        h = ops.gemm(o, p.attn1.wo, bias=p.attn1.bo, res1=h)
+        # 2. audio cross-attention: cached K/V, segment mask as a key gather (:315-325)
+        if p.audio:
+            na = ops.layernorm(h, p.norm_audio.g, p.norm_audio.b)
+            q = ops.gemm(na, p.attn_audio.wq)
+            idx = st.cond.key_index
+            o = ops.attention(q, c.audio_kv[:, :C], c.audio_kv[:, C:], bq=B * Fr, lq=L,
+                              lk=idx.shape[1] if idx is not None else c.audio_len, kv_rows=c.audio_len, heads=heads,
+                              q_per_kv=Fr if c.audio_pf == 1 else 1, frames=st.cond.idx_frames if idx is not None else Fr,
+                              key_index=idx)
+            h = ops.gemm(o, p.attn_audio.wo, bias=p.attn_audio.bo, res1=h)
+        # 3. text cross-attention: cached K/V (:328-341)
+        n2 = ops.layernorm(h, p.norm2.g, p.norm2.b)
+        q = ops.gemm(n2, p.attn2.wq)
+        o = ops.attention(q, c.text_kv[:, :C], c.text_kv[:, C:], bq=B * Fr, lq=L, lk=c.text_len, kv_rows=c.text_len,
+                          heads=heads, q_per_kv=Fr if c.text_pf == 1 else 1, frames=Fr)
+        h = ops.gemm(o, p.attn2.wo, bias=p.attn2.bo, res1=h)
+        # 4. temporal attention across frames per pixel; LN(h + pos[f]); residual is h itself (:346-358)
+        nt = ops.layernorm(h, p.norm_temp.g, p.norm_temp.b, pos=c.pos, hw=L, frames=Fr)
+        qkv = ops.gemm(nt, p.attn_temp.wqkv)
+        o = ops.temporal_attention(qkv, b=B, frames=Fr, hw=L, heads=heads)
+        h = ops.gemm(o, p.attn_temp.wo, bias=p.attn_temp.bo, res1=h)
+        # 5. GEGLU feed-forward, activation fused in the first GEMM's epilogue (:361-371)
+        n3 = ops.layernorm(h, p.norm3.g, p.norm3.b)
+        g = ops.gemm(n3, p.w1, bias=p.b1, geglu=True)
+        h = ops.gemm(g, p.ff2.w, bias=p.ff2.b, res1=h)
+        return ops.gemm(h, p.proj_out.w, bias=p.proj_out.b, res1=x)

@@ -1,0 +1,44 @@
+"""Closed-form deterministic parameter filler shared by oracle/gen_golden.py (which fills the
+REFERENCE model) and the tests / bench (which fill the oracle's and the product's state_dict), so no
+weight file ever needs to be committed: a parameter's values depend only on its name and shape.
+
+The reference zero-initialises every temporal path (conv_temp: utils.py:31-32; attn_temp.to_out:
+ff_spatio_audio_temp_transformer_3d.py:267); the filler randomises them like everything else, so the
+golden vectors exercise those paths.
+"""
+from __future__ import annotations
+
+import math
+import zlib
+
+import torch
+
+
+def fill_tensor(name: str, shape, dtype=torch.float32) -> torch.Tensor:
+    g = torch.Generator(device="cpu").manual_seed(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+    shape = tuple(shape)
+    if len(shape) >= 2:                       # linear / conv weight: keep activations O(1)
+        fan_in = 1
+        for s in shape[1:]:
+            fan_in *= s
+        t = torch.randn(shape, generator=g) * (1.0 / math.sqrt(fan_in))
+    elif name.endswith("weight"):             # norm scale
+        t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+    else:                                     # bias / norm shift
+        t = 0.05 * torch.randn(shape, generator=g)
+    return t.to(dtype)
+
+
+def fill_state_dict(shapes: dict, dtype=torch.float32) -> dict:
+    """shapes: name -> shape (e.g. tests/golden/unet_sd15_state_dict_shapes.json)."""
+    return {k: fill_tensor(k, v, dtype) for k, v in shapes.items()}
+
+
+def fill_module_(module: torch.nn.Module, prefix: str = "") -> None:
+    with torch.no_grad():
+        for k, p in module.state_dict().items():
+            p.copy_(fill_tensor(prefix + k, p.shape, p.dtype))
+
+
+def seeded_randn(seed: int, *shape) -> torch.Tensor:
+    return torch.randn(*shape, generator=torch.Generator(device="cpu").manual_seed(seed))

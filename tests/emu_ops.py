@@ -1,0 +1,158 @@
+"""CPU emulation of the kernel CONTRACTS of asva_amd.ops (same signatures, torch fp32 math, bf16
+storage rounding at the same points).  TEST INFRASTRUCTURE ONLY: it lets the host orchestration
+(weight packing, layer sequencing, conditioning cache, scheduler glue) be checked against the oracle
+in the GPU-less build container by monkeypatching `asva_amd.unet.ops`.  The product never imports it;
+the real parity tests (-m gpu) run the HIP kernels.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+EMULATED = True
+PLAIN, TMIX, CONV3 = 0, 1, 2
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def gemm(a, w, *, n=None, k=None, a2=None, bias=None, rowvec=None, rows_per_vec=0, res1=None, res2=None, alpha=1.0,
+         geglu=False, out_f32=False, out=None, mode=PLAIN, tmix=None, conv=None, m=None, tile=0):
+    assert a.dtype == BF16 and w.dtype == BF16
+    wf = w.float()
+    if mode == PLAIN:
+        x = a.float() if a2 is None else torch.cat([a.float(), a2.float()], 1)
+    elif mode == TMIX:
+        hw, frames = tmix
+        C = a.shape[1]
+        y = a.float().reshape(-1, frames, hw, C)
+        prev = torch.cat([y[:, :1], y[:, :-1]], 1)
+        x = torch.cat([y[:, :1].expand_as(y), prev, y], -1).reshape(-1, 3 * C)
+    else:
+        n_img, hs, ws, stride, ups = conv
+        cin = a.shape[1]
+        xi = a.float().reshape(n_img, hs, ws, cin).permute(0, 3, 1, 2)
+        if ups:
+            xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
+        cols = F.unfold(xi, 3, padding=1, stride=stride)                      # [n, cin*9, L] (c-major, tap-minor)
+        L = cols.shape[-1]
+        x = cols.reshape(n_img, cin, 9, L).permute(0, 3, 2, 1).reshape(n_img * L, 9 * cin)   # tap-major, c-minor
+    assert x.shape[1] == wf.shape[1], (x.shape, wf.shape)
+    acc = alpha * (x @ wf.T)
+    if not geglu:
+        v = acc
+        if bias is not None:
+            v = v + bias
+        if rowvec is not None:
+            v = v + rowvec.repeat_interleave(rows_per_vec, 0)[: v.shape[0]]
+        if res1 is not None:
+            v = v + res1.float()
+        if res2 is not None:
+            v = v + res2.float()
+    else:
+        if bias is not None:
+            acc = acc + bias
+        blk = acc.reshape(acc.shape[0], -1, 32)
+        v = (blk[:, :, :16] * F.gelu(blk[:, :, 16:])).reshape(acc.shape[0], -1)
+    return v if out_f32 else v.to(BF16)
+
+
+def gemm_batched(a, w, *, alpha=1.0, out_f32=False, tile=0):
+    v = alpha * torch.einsum("bmk,bnk->bmn", a.float(), w.float())
+    return v if out_f32 else v.to(BF16)
+
+
+def linear_small_m(x, w, bias, *, act_in=False, act_out=False, out=None):
+    assert x.dtype == F32 and w.dtype == BF16
+    v = (F.silu(x) if act_in else x) @ w.float().T
+    if bias is not None:
+        v = v + bias
+    return F.silu(v) if act_out else v
+
+
+def groupnorm(x1, x2, nb, rows_per_batch, groups, gamma, beta, eps, act, out=None):
+    x = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], 1)
+    C = x.shape[1]
+    y = F.group_norm(x.reshape(nb, rows_per_batch, C).permute(0, 2, 1), groups, gamma, beta, eps)
+    y = F.silu(y) if act else y
+    return y.permute(0, 2, 1).reshape(-1, C).to(BF16)
+
+
+def layernorm(x, gamma, beta, eps=1e-5, pos=None, hw=1, frames=1, out=None):
+    v = x.float()
+    if pos is not None:
+        f = (torch.arange(v.shape[0]) // hw) % frames
+        v = v + pos[f]
+    return F.layer_norm(v, (v.shape[1],), gamma, beta, eps).to(BF16)
+
+
+def softmax_rows(s):
+    return torch.softmax(s, -1).to(BF16)
+
+
+def attention(q, k, v, *, bq, lq, lk, kv_rows, heads, q_per_kv, frames, key_index=None, scale=None, out=None):
+    C = q.shape[1]
+    d = C // heads
+    scale = scale if scale is not None else d ** -0.5
+    qh = q.float().reshape(bq, lq, heads, d).transpose(1, 2)
+    bk = bq // q_per_kv
+    kk = k.float().reshape(bk, kv_rows, -1)[..., :C]
+    vv = v.float().reshape(bk, kv_rows, -1)[..., :C]
+    outs = []
+    for qb in range(bq):
+        kb = qb // q_per_kv
+        if key_index is not None:
+            rows = key_index[qb % frames].long()
+        else:
+            rows = torch.arange(lk)
+        kh = kk[kb, rows].reshape(-1, heads, d).transpose(0, 1)
+        vh = vv[kb, rows].reshape(-1, heads, d).transpose(0, 1)
+        p = torch.softmax(qh[qb] @ kh.transpose(1, 2) * scale, -1).to(BF16).float()
+        outs.append((p @ vh).transpose(0, 1).reshape(lq, C))
+    return torch.cat(outs, 0).to(BF16)
+
+
+def temporal_attention(qkv, *, b, frames, hw, heads, scale=None, out=None):
+    C = qkv.shape[1] // 3
+    d = C // heads
+    x = qkv.float().reshape(b, frames, hw, 3, heads, d).permute(3, 0, 2, 4, 1, 5)
+    o = F.scaled_dot_product_attention(x[0], x[1], x[2], scale=scale)
+    return o.permute(0, 3, 1, 2, 4).reshape(b * frames * hw, C).to(BF16)
+
+
+def ncfhw_to_rows(x, cpad, rep=1, scale=1.0):
+    B, C, Fr, H, W = x.shape
+    r = (x * scale).permute(0, 2, 3, 4, 1).reshape(-1, C)
+    out = torch.zeros(r.shape[0], cpad)
+    out[:, :C] = r
+    return out.repeat(rep, 1).to(BF16)
+
+
+def rows_to_ncfhw(rows, B, C, Fr, H, W):
+    return rows[:, :C].reshape(B, Fr, H, W, C).permute(0, 4, 1, 2, 3).contiguous()
+
+
+def timestep_embedding(t, dim):
+    half = dim // 2
+    w = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    a = t[:, None] * w[None]
+    return torch.cat([torch.cos(a), torch.sin(a)], -1)
+
+
+def guided_step(noise_pred, n_branch, g, x_in, x_out, ca, cb, *, eps_hist=None, store_slot=-1, w_cur=1.0, hist_idx=(), w=()):
+    B = x_in.shape[0]
+    eps = noise_pred[:B]
+    if n_branch == 2:
+        eps = eps + g * (noise_pred[B:] - eps)
+    if store_slot >= 0:
+        eps_hist[store_slot] = eps
+    e = w_cur * eps
+    for i, wk in zip(hist_idx, w):
+        e = e + wk * eps_hist[i]
+    new = ca * x_in + cb * e
+    new[:, :, 0] = x_in[:, :, 0]
+    x_out.copy_(new)
+
+
+def vae_postprocess(rows, n_img, H, W):
+    return (rows[:, :3].float().reshape(n_img, H, W, 3).permute(0, 3, 1, 2) / 2 + 0.5).clamp(0, 1).contiguous()

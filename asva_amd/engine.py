@@ -1,0 +1,104 @@
+"""DenoiseEngine — the denoising loop of the reference pipeline
+(AudioCondAnimationPipeline.__call__, pipeline_audio_cond_animation.py:325-365) as the MI355X hot path:
+
+  per step:  latents --(replicated k times in the layout kernel)--> UNet forward --> noise_pred
+             guidance combine + multistep scheduler update + first-frame pinning in ONE kernel
+  per clip:  conditioning K/V, position tables and the mask gather list computed once (set_conditioning)
+
+The UNet forward of one step (~650 kernel launches) is captured once into a hipGraph and replayed, so the
+host contributes one graph launch + one tiny launch per step instead of ~650 ctypes calls.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+from .schedulers import StepPlan
+
+
+class DenoiseEngine:
+    def __init__(self, unet, scheduler, audio_guidance_scale: float = 4.0, text_guidance_scale: float = 1.0,
+                 use_graph: bool = True):
+        if text_guidance_scale > 1.0:
+            raise NotImplementedError("text guidance (3-branch CFG) is off in every reference script "
+                                      "(scripts/animation_test_*.sh: text_guidance_scale 1.0)")
+        self.unet = unet
+        self.scheduler = scheduler
+        self.g = float(audio_guidance_scale)
+        self.n_branch = 2 if audio_guidance_scale > 1.0 else 1
+        self.use_graph = use_graph
+        self._graph = None
+        self._graph_key = None
+
+    # -- once per clip ---------------------------------------------------------------------------------
+    def set_conditioning(self, text: torch.Tensor, audio: torch.Tensor, null_audio: Optional[torch.Tensor],
+                         audio_mask: torch.Tensor, video_length: int):
+        """text (b, 77, D); audio (b, 229, D); null_audio (1 or b, 229, D) = encoding of the all-zero
+        mel-spectrogram (pipeline :180-184); mask (F, 229).  Builds the CFG batch exactly as encode_text /
+        encode_audio do for audio-only guidance (:155, :193-194): text [t, t], audio [null, audio]."""
+        b = text.shape[0]
+        if self.n_branch == 2:
+            if null_audio is None:
+                raise ValueError("audio guidance needs the null-audio encoding")
+            null_audio = null_audio.expand(b, *null_audio.shape[1:])
+            text = torch.cat([text, text], 0)
+            audio = torch.cat([null_audio, audio], 0)
+        self.unet.set_conditioning(text, audio, audio_mask, video_length)
+        self._graph = None
+
+    # -- hot loop -----------------------------------------------------------------------------------------
+    def _capture(self, latents: torch.Tensor):
+        key = (tuple(latents.shape), latents.device)
+        if self._graph is not None and self._graph_key == key:
+            return
+        self._x_static = torch.zeros_like(latents)
+        self._t_static = torch.zeros(1, dtype=torch.float32, device=latents.device)
+        # warm-up on a side stream (allocator + lazy module loading), then capture
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self.unet.denoise_forward(self._x_static, self._t_static, rep=self.n_branch)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._noise_static = self.unet.denoise_forward(self._x_static, self._t_static, rep=self.n_branch)
+        self._graph, self._graph_key = g, key
+
+    def unet_step(self, latents: torch.Tensor, t_dev: torch.Tensor) -> torch.Tensor:
+        """noise prediction for the CFG batch; t_dev is a 1-element device f32 tensor."""
+        if not self.use_graph:
+            return self.unet.denoise_forward(latents, t_dev, rep=self.n_branch)
+        self._capture(latents)
+        self._x_static.copy_(latents)
+        self._t_static.copy_(t_dev)
+        self._graph.replay()
+        return self._noise_static
+
+    def prepare(self, latents: torch.Tensor, num_inference_steps: int):
+        dev = latents.device
+        self.scheduler.set_timesteps(num_inference_steps, device=dev)
+        self._ts = self.scheduler.timesteps.to(dev, torch.float32)
+        self._plans = [self.scheduler.plan_step(i) for i in range(self.scheduler.num_forwards())]
+        self._hist = torch.zeros((4,) + tuple(latents.shape), dtype=torch.float32, device=dev)
+        self._saved = torch.empty_like(latents)
+
+    def step(self, latents: torch.Tensor, i: int) -> None:
+        """One denoising step in place on `latents` (b, 4, F, H, W) f32: UNet on the CFG batch, then
+        eps = e_text + g (e_text_audio - e_text), scheduler update of frames 1.., frame 0 untouched."""
+        p: StepPlan = self._plans[i]
+        noise = self.unet_step(latents, self._ts[i:i + 1])
+        if p.save_sample:
+            self._saved.copy_(latents)
+        ops.guided_step(noise, self.n_branch, self.g, self._saved if p.use_saved_sample else latents, latents, p.ca, p.cb,
+                        eps_hist=self._hist, store_slot=p.store_slot, w_cur=p.w_cur, hist_idx=p.hist_idx, w=p.hist_w)
+
+    @torch.no_grad()
+    def run(self, latents: torch.Tensor, num_inference_steps: int) -> torch.Tensor:
+        latents = latents.to(torch.float32).contiguous().clone()
+        self.prepare(latents, num_inference_steps)
+        for i in range(len(self._plans)):
+            self.step(latents, i)
+        return latents

@@ -19,6 +19,48 @@ GEGLU, OUT_F32 = 1, 2
 BF16, F32 = torch.bfloat16, torch.float32
 
 
+class KernelTimer:
+    """Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg): while
+    installed via `set_timer`, every wrapper below brackets its launch with two events and records
+    (family, algorithmic flops, algorithmic bytes).  Off (None) in the product path."""
+
+    def __init__(self):
+        self.records = []
+
+    def start(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def stop(self, ev0, family: str, flops: float, nbytes: float):
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        self.records.append((family, flops, nbytes, ev0, ev1))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for fam, fl, nb, e0, e1 in self.records:
+            d = out.setdefault(fam, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+            d["bytes"] += nb
+        return out
+
+
+_TIMER: Optional[KernelTimer] = None
+
+
+def set_timer(t: Optional[KernelTimer]) -> None:
+    global _TIMER
+    _TIMER = t
+
+
+def _nbytes(*ts) -> float:
+    return float(sum(t.numel() * t.element_size() for t in ts if t is not None))
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -120,7 +162,12 @@ def gemm(
     d.flags = (GEGLU if geglu else 0) | (OUT_F32 if out_f32 else 0)
     d.batch = 1
     d.tile = tile
+    ev = _TIMER.start() if _TIMER is not None else None
     check(_lib.lib().avsd_gemm_bf16(C.byref(d), _stream()), "avsd_gemm_bf16")
+    if ev is not None:
+        fam = ("gemm_plain", "gemm_tmix", "gemm_conv3")[mode]
+        _TIMER.stop(ev, fam, 2.0 * M * N * K, 2.0 * M * K * (1.0 / 9 if mode == CONV3 else 1.0 / 3 if mode == TMIX else 1.0)
+                    + 2.0 * N * K + _nbytes(out, res1, res2))
     return out
 
 
@@ -138,7 +185,10 @@ def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, alpha: float = 1.0, out_f3
     d.lda, d.ldw, d.ldc = a.stride(1), w.stride(1), out.stride(1)
     d.alpha, d.mode, d.flags, d.batch, d.tile = alpha, PLAIN, (OUT_F32 if out_f32 else 0), B, tile
     d.batch_stride_a, d.batch_stride_w, d.batch_stride_out = a.stride(0), w.stride(0), out.stride(0)
+    ev = _TIMER.start() if _TIMER is not None else None
     check(_lib.lib().avsd_gemm_bf16(C.byref(d), _stream()), "avsd_gemm_bf16(batched)")
+    if ev is not None:
+        _TIMER.stop(ev, "gemm_plain", 2.0 * B * M * N * K, 2.0 * B * (M * K + N * K) + _nbytes(out))
     return out
 
 
@@ -177,11 +227,14 @@ def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], nb: int, rows_per_ba
     if out is None:
         out = torch.empty((rows, c1 + c2), dtype=BF16, device=x1.device)
     s = _stream()
+    ev = _TIMER.start() if _TIMER is not None else None
     check(L.avsd_groupnorm_stats(_p(x1), _ld(x1), c1, _p(x2), _ld(x2) if x2 is not None else 0, c2, nb, rows_per_batch,
                                  groups, _p(partial), nchunks, s), "avsd_groupnorm_stats")
     check(L.avsd_groupnorm_apply(_p(x1), _ld(x1), c1, _p(x2), _ld(x2) if x2 is not None else 0, c2, nb, rows_per_batch,
                                  groups, _p(partial), nchunks, _p(gamma), _p(beta), float(eps), int(act), _p(out),
                                  _ld(out), s), "avsd_groupnorm_apply")
+    if ev is not None:
+        _TIMER.stop(ev, "groupnorm", 0.0, 2.0 * _nbytes(x1, x2) + _nbytes(out))
     return out
 
 
@@ -198,8 +251,11 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
             raise ValueError("layernorm: pos must be contiguous [frames, C]")
     if out is None:
         out = torch.empty((M, Cc), dtype=BF16, device=x.device)
+    ev = _TIMER.start() if _TIMER is not None else None
     check(_lib.lib().avsd_layernorm(_p(x), _ld(x), _p(out), _ld(out), M, Cc, _p(gamma), _p(beta), float(eps), _p(pos),
                                     hw, frames, _stream()), "avsd_layernorm")
+    if ev is not None:
+        _TIMER.stop(ev, "layernorm", 0.0, _nbytes(x, out))
     return out
 
 
@@ -227,9 +283,12 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, bq: int, lq:
         out = torch.empty((bq * lq, Cc), dtype=BF16, device=q.device)
     if scale is None:
         scale = float(d) ** -0.5
+    ev = _TIMER.start() if _TIMER is not None else None
     check(_lib.lib().avsd_attention(_p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(out), _ld(out), bq, lq, lk, kv_rows,
                                     heads, d, q_per_kv, _p(key_index), frames, float(scale), _stream()),
           "avsd_attention")
+    if ev is not None:
+        _TIMER.stop(ev, "attention", 4.0 * bq * heads * lq * lk * d, _nbytes(q, out) + 4.0 * (bq // q_per_kv) * lk * Cc)
     return out
 
 
@@ -242,8 +301,11 @@ def temporal_attention(qkv: torch.Tensor, *, b: int, frames: int, hw: int, heads
         out = torch.empty((qkv.shape[0], Cc), dtype=BF16, device=qkv.device)
     if scale is None:
         scale = float(d) ** -0.5
+    ev = _TIMER.start() if _TIMER is not None else None
     check(_lib.lib().avsd_temporal_attention(_p(qkv), _ld(qkv), _p(out), _ld(out), b, frames, hw, heads, d, float(scale),
                                              _stream()), "avsd_temporal_attention")
+    if ev is not None:
+        _TIMER.stop(ev, "temporal_attention", 4.0 * b * hw * heads * frames * frames * d, _nbytes(qkv, out))
     return out
 
 

@@ -474,50 +474,57 @@ class AudioUNet3DConditionModel(nn.Module):
     def pack(self, device: Optional[torch.device] = None):
         """state_dict -> kernel layouts inside ONE device blob (so multi-GPU start-up is a single RCCL
         broadcast, see asva_amd.dist).  Returns the structure of typed views."""
-        if self._packed is not None and (device is None or self._packed.blob.device == torch.device(device)):
+        if device is not None:
+            device = torch.device(device)
+            if device.type == "cuda" and device.index is None:
+                device = torch.device("cuda", torch.cuda.current_device())
+        if self._packed is not None and (device is None or self._packed.blob.device == device):
             return self._packed
-        device = torch.device(device) if device is not None else self.device
+        device = device if device is not None else self.device
+        if device.type == "meta":
+            raise RuntimeError("pack: pass the target device explicitly for a meta-initialised model")
         if device.type != "cuda" and not getattr(ops, "EMULATED", False):   # EMULATED: tests/emu_ops.py seam
             raise RuntimeError("AudioUNet3DConditionModel.pack: the MI355X path needs a cuda (HIP) device; "
                                "move the model with .to('cuda') first — there is no CPU compute path")
-        items = []   # (setter, cpu tensor)
+        items = []   # packed tensors, on the parameters' device (or meta: layout only)
+        meta = next(self.parameters()).is_meta
 
         def reg(t: torch.Tensor):
             items.append(t.contiguous())
             return _Ref(len(items) - 1)
 
         def lin(m: _Linear):
-            return _Pk(w=reg(pack_linear(m.weight.float().cpu())), b=None if m.bias is None else reg(m.bias.detach().float().cpu()))
+            return _Pk(w=reg(pack_linear(m.weight.float())), b=None if m.bias is None else reg(m.bias.detach().float()))
 
         def aff(m: _Affine):
-            return _Pk(g=reg(m.weight.detach().float().cpu()), b=reg(m.bias.detach().float().cpu()))
+            return _Pk(g=reg(m.weight.detach().float()), b=reg(m.bias.detach().float()))
 
         def ffconv(m: _FFConv):
             cout, cin = m.weight.shape[:2]
             cop = (cout + 7) // 8 * 8
             cip = (cin + 7) // 8 * 8
-            w = m.weight.detach().float().cpu()
+            w = m.weight.detach().float()
             if m.kernel == 3:
                 wp = pack_conv3x3(w, cip, cop)
             else:
-                wp = torch.zeros(cop, cip, dtype=torch.bfloat16)
+                wp = torch.zeros(cop, cip, dtype=torch.bfloat16, device=w.device)
                 wp[:cout, :cin] = pack_conv1x1(w)
-            b = torch.zeros(cop)
-            b[:cout] = m.bias.detach().float().cpu()
-            wt = torch.zeros(cop, 3, cop)
-            wt[:cout, :, :cout] = m.conv_temp.weight.detach().float().cpu().reshape(cout, 3, cout)
-            bt = torch.zeros(cop)
-            bt[:cout] = m.conv_temp.bias.detach().float().cpu()
+            b = torch.zeros(cop, device=w.device)
+            b[:cout] = m.bias.detach().float()
+            wt = torch.zeros(cop, 3, cop, device=w.device)
+            wt[:cout, :, :cout] = m.conv_temp.weight.detach().float().reshape(cout, 3, cout)
+            bt = torch.zeros(cop, device=w.device)
+            bt[:cout] = m.conv_temp.bias.detach().float()
             return _Pk(w=reg(wp), b=reg(b), wt=reg(wt.reshape(cop, 3 * cop).to(torch.bfloat16)), bt=reg(bt),
                        cout=cop, cin=cip, k=m.kernel)
 
         def conv1(m: _Conv):
-            return _Pk(w=reg(pack_conv1x1(m.weight.float().cpu())), b=reg(m.bias.detach().float().cpu()))
+            return _Pk(w=reg(pack_conv1x1(m.weight.float())), b=reg(m.bias.detach().float()))
 
         def attn(m: _Attention, fuse_qkv: bool):
-            wq, wk, wv = (x.weight.detach().float().cpu() for x in (m.to_q, m.to_k, m.to_v))
+            wq, wk, wv = (x.weight.detach().float() for x in (m.to_q, m.to_k, m.to_v))
             o = m.to_out[0]
-            p = _Pk(wo=reg(pack_linear(o.weight.float().cpu())), bo=reg(o.bias.detach().float().cpu()))
+            p = _Pk(wo=reg(pack_linear(o.weight.float())), bo=reg(o.bias.detach().float()))
             if fuse_qkv:
                 p.wqkv = reg(pack_linear(torch.cat([wq, wk, wv], 0)))
             else:
@@ -531,14 +538,14 @@ class AudioUNet3DConditionModel(nn.Module):
             p = _Pk(norm1=aff(m.norm1), conv1=ffconv(m.conv1), norm2=aff(m.norm2), conv2=ffconv(m.conv2),
                     shortcut=ffconv(m.conv_shortcut) if hasattr(m, "conv_shortcut") else None,
                     temb_off=temb_off[0], cout=m.conv1.weight.shape[0])
-            temb_w.append(m.time_emb_proj.weight.detach().float().cpu())
-            temb_b.append(m.time_emb_proj.bias.detach().float().cpu())
+            temb_w.append(m.time_emb_proj.weight.detach().float())
+            temb_b.append(m.time_emb_proj.bias.detach().float())
             temb_off[0] += p.cout
             return p
 
         def tr(m: _Transformer3D):
             b = m.transformer_blocks[0]
-            w1, b1 = pack_geglu(b.ff.net[0].proj.weight.detach().float().cpu(), b.ff.net[0].proj.bias.detach().float().cpu())
+            w1, b1 = pack_geglu(b.ff.net[0].proj.weight.detach().float(), b.ff.net[0].proj.bias.detach().float())
             p = _Pk(norm=aff(m.norm), proj_in=conv1(m.proj_in), proj_out=conv1(m.proj_out),
                     norm1=aff(b.norm1), attn1=attn(b.attn1, False),
                     norm2=aff(b.norm2), attn2=attn(b.attn2, False),
@@ -569,11 +576,11 @@ class AudioUNet3DConditionModel(nn.Module):
         for t in items:
             offs.append(total)
             total += (t.numel() * t.element_size() + 255) // 256 * 256
-        host = torch.empty(total, dtype=torch.uint8)
-        for t, o in zip(items, offs):
-            nb = t.numel() * t.element_size()
-            host[o:o + nb] = t.reshape(-1).view(torch.uint8)
-        blob = host.to(device)
+        blob = torch.zeros(total, dtype=torch.uint8, device=device)
+        if not meta:   # meta parameters: layout only — the bytes arrive by broadcast (asva_amd.dist)
+            for t, o in zip(items, offs):
+                nb = t.numel() * t.element_size()
+                blob[o:o + nb].copy_(t.reshape(-1).view(torch.uint8))
         views = []
         for t, o in zip(items, offs):
             nb = t.numel() * t.element_size()
@@ -705,30 +712,49 @@ class AudioUNet3DConditionModel(nn.Module):
                 self._cond_key = key
         if self._cond is None:
             raise RuntimeError("no conditioning: pass encoder_hidden_states or call set_conditioning first")
-        cond = self._cond
-        if cond.frames != Fr or cond.batch != B:
-            raise ValueError(f"conditioning was prepared for batch {cond.batch} x {cond.frames} frames, sample has {B} x {Fr}")
         dev = pk.blob.device
         in_dtype = sample.dtype
         x32 = sample.to(device=dev, dtype=torch.float32).contiguous()
-
-        # -- time embedding: sinusoid -> MLP -> all 22 time_emb_proj at once (:657-681, resnet :170)
         if torch.is_tensor(timestep):
             t = timestep.to(device=dev, dtype=torch.float32).reshape(-1)
         else:
             t = torch.full((1,), float(timestep), dtype=torch.float32, device=dev)
+        out = self.denoise_forward(x32, t, rep=1)
+        if in_dtype != torch.float32:
+            out = out.to(in_dtype)
+        if not return_dict:
+            return (out,)
+        return UNet3DConditionOutput(sample=out)
+
+    @torch.no_grad()
+    def denoise_forward(self, x32: torch.Tensor, t: torch.Tensor, rep: int = 1) -> torch.Tensor:
+        """The per-step hot path (allocation-free apart from torch's caching allocator, no host sync, all
+        launches on the current stream -> capturable in a hipGraph).  x32: (b, C, F, H, W) f32 device latents,
+        replicated `rep` times along the batch inside the layout kernel (torch.cat([latents] * k),
+        pipeline_audio_cond_animation.py:331-336); t: device f32 tensor with 1 or rep*b entries.
+        Conditioning comes from `set_conditioning`.  Returns the f32 noise prediction (rep*b, C, F, H, W)."""
+        pk = self.pack()
+        cond = self._cond
+        if cond is None:
+            raise RuntimeError("no conditioning: call set_conditioning first")
+        b, Cin, Fr, H, W = x32.shape
+        B = rep * b
+        nblk = len(self.config.block_out_channels)
+        if cond.frames != Fr or cond.batch != B:
+            raise ValueError(f"conditioning was prepared for batch {cond.batch} x {cond.frames} frames, sample has {B} x {Fr}")
         if t.numel() not in (1, B):
             raise ValueError("timestep must be a scalar or have one entry per batch element")
+        # -- time embedding: sinusoid -> MLP -> all ResBlock time_emb_proj at once (:657-681, resnet :170)
         ch0 = self.config.block_out_channels[0]
         e = ops.timestep_embedding(t, ch0)
         e = ops.linear_small_m(e, pk.t1.w, pk.t1.b, act_out=True)
         e = ops.linear_small_m(e, pk.t2.w, pk.t2.b)
         temb = ops.linear_small_m(e, pk.temb_w, pk.temb_b, act_in=True)          # [1 or B, sum(Cout)]
-        st = _Pk(B=B, F=Fr, temb=temb, temb_rows=(Fr if t.numel() == B else B * Fr), cond=cond, tr_i=0,
+        st = _Pk(B=B, F=Fr, temb=temb, temb_rows=(Fr if (t.numel() == B and B > 1) else B * Fr), cond=cond, tr_i=0,
                  groups=self.config.norm_num_groups, eps=float(self.config.norm_eps),
                  heads=_per_block(self.config.attention_head_dim, nblk))
 
-        h = ops.ncfhw_to_rows(x32, cpad=pk.conv_in.cin)
+        h = ops.ncfhw_to_rows(x32, cpad=pk.conv_in.cin, rep=rep)
         hw = (H, W)
         h = self._ffconv(st, h, pk.conv_in, hw)
         skips = [h]
@@ -756,12 +782,7 @@ class AudioUNet3DConditionModel(nn.Module):
                 hw = (hw[0] * 2, hw[1] * 2)
         a = ops.groupnorm(h, None, B, Fr * hw[0] * hw[1], st.groups, pk.norm_out.g, pk.norm_out.b, st.eps, True)
         o = self._ffconv(st, a, pk.conv_out, hw, out_f32=True)
-        out = ops.rows_to_ncfhw(o, B, self.config.out_channels, Fr, H, W)
-        if in_dtype != torch.float32:
-            out = out.to(in_dtype)
-        if not return_dict:
-            return (out,)
-        return UNet3DConditionOutput(sample=out)
+        return ops.rows_to_ncfhw(o, B, self.config.out_channels, Fr, H, W)
 
     # FFInflatedConv3d (utils.py:34-57): conv GEMM, then the temporal-mix GEMM whose epilogue also adds the
     # time embedding (resnet :173) and the residual / shortcut (resnet :189)

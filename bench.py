@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""bench.py — UNet denoising steps/sec on synthetic 12x256x256 clips (BASELINE.json metric).
+
+A *step* = one classifier-free-guidance UNet forward for one clip (UNet batch 2 = [null-audio, audio]) +
+guidance combine + scheduler update (DDIM-50 coefficients), i.e. one iteration of the loop at
+pipeline_audio_cond_animation.py:330-365.  Workload = BASELINE.json configs[1] (AVSync15 shape: SD1.5-shaped
+1.17 B-parameter AudioUNet3D, random-init weights, latents 12x32x32, audio guidance 4.0, bf16).
+Inputs are resident in HBM before the timed region.  One process per GPU; clips are independent, so N GPUs
+run N clips with no collective in the loop (weak scaling): RCCL is used once for the packed-weight broadcast
+and once for the metric all-gather.
+
+    python bench.py [--gpus N --steps K --warmup W]                      # N=1
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement) including
+  roofline      dominant kernel family = the bf16 MFMA GEMM/conv kernels: algorithmic FLOPs of all their
+                launches in one step / their summed HIP-event durations (instrumented eager step)
+  cpu_baseline  the oracle (oracle/unet_ref.py, fp32, torch CPU) timed on this box's host cores on the same
+                CFG forward (rank 0, N=1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SD15 = dict(block_out_channels=(320, 640, 1280, 1280), attention_head_dim=8, norm_num_groups=32,
+            cross_attention_dim=768, audio_cross_attention_dim=768, sample_size=32)
+ALGORITHMIC_TFLOP_PER_STEP = 5.427     # SURVEY.md §8(d), (2,12,32x32)
+PEAK_BF16_TFLOPS = 2500.0              # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def build_unet(device, rank, world, seed=0):
+    """Rank 0 creates random-init weights on its GPU and packs them; the other ranks build the layout only
+    (meta parameters) and receive the packed blob by one RCCL broadcast."""
+    from asva_amd import dist as adist
+    from asva_amd.unet import AudioUNet3DConditionModel
+
+    if rank == 0:
+        torch.manual_seed(seed)
+        with torch.device(device):
+            unet = AudioUNet3DConditionModel(**SD15).eval()
+            # the reference zero-initialises its temporal paths; give them weights so no product is trivially 0
+            with torch.no_grad():
+                for n, p in unet.named_parameters():
+                    if "conv_temp" in n or n.endswith("attn_temp.to_out.0.weight"):
+                        p.normal_(0.0, 0.02)
+        pk = unet.pack(device)
+    else:
+        with torch.device("meta"):
+            unet = AudioUNet3DConditionModel(**SD15).eval()
+        pk = unet.pack(device)
+    adist.broadcast_blob(pk.blob, src=0)
+    return unet
+
+
+def synthetic_clip(device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    lat = torch.randn(1, 4, 12, 32, 32, generator=g)
+    lat[:, :, 0] *= 0.18215                       # frame 0 = VAE image latent scale
+    text = torch.randn(1, 77, 768, generator=g)
+    audio = torch.randn(1, 229, 768, generator=g)
+    null_audio = torch.randn(1, 229, 768, generator=g)
+    return [t.to(device) for t in (lat, text, audio, null_audio)]
+
+
+def cpu_baseline(unet, clip):
+    """Oracle (fp32 torch CPU restatement of the reference UNet) on the same CFG forward: 1 warm-up + 1 timed."""
+    from asva_amd.conditioning import audio_segment_mask
+    from oracle.unet_ref import unet_forward
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
+    lat, text, audio, null_audio = [t.float().cpu() for t in clip]
+    x = torch.cat([lat, lat])
+    txt = torch.cat([text, text])[:, None].expand(2, 12, 77, 768)
+    aud = torch.cat([null_audio, audio])[:, None].expand(2, 12, 229, 768)
+    mask = audio_segment_mask(12)[None].expand(2, -1, -1)
+    cfg = dict(unet.config)
+    times = []
+    with torch.no_grad():
+        for _ in range(2):
+            t0 = time.perf_counter()
+            unet_forward(sd, cfg, x, 981, txt, aud, mask)
+            times.append(time.perf_counter() - t0)
+    return {"value": 1.0 / times[-1], "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": "oracle/unet_ref.py fp32 torch-CPU CFG UNet forward (B=2x12x32x32), 1 warm-up + 1 timed",
+            "seconds_per_step": times[-1]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    from asva_amd import dist as adist
+    from asva_amd import ops
+    from asva_amd.conditioning import audio_segment_mask
+    from asva_amd.engine import DenoiseEngine
+    from asva_amd.schedulers import DDIMScheduler
+
+    rank, local_rank, world = adist.env_rank_world()
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    adist.init_process_group("nccl")
+
+    unet = build_unet(device, rank, world)
+    clip = synthetic_clip(device, seed=1000 + rank)
+    lat, text, audio, null_audio = clip
+    sched = DDIMScheduler()
+    eng = DenoiseEngine(unet, sched, audio_guidance_scale=4.0, use_graph=not a.no_graph)
+    eng.set_conditioning(text, audio, null_audio, audio_segment_mask(12), 12)
+    latents = lat.clone()
+    n_sched = 50
+    eng.prepare(latents, n_sched)
+
+    for i in range(a.warmup):
+        eng.step(latents, i % n_sched)
+    torch.cuda.synchronize()
+    adist.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(a.steps):
+        eng.step(latents, (a.warmup + i) % n_sched)
+    ev1.record()
+    torch.cuda.synchronize()
+    adist.barrier()
+    wall = time.perf_counter() - t0
+    gpu_ms = ev0.elapsed_time(ev1)
+    finite = bool(torch.isfinite(latents).all())
+
+    rows = adist.gather_metrics([wall, gpu_ms, float(a.steps), float(finite)], device=device)
+    if rank != 0:
+        return
+    max_wall = max(r[0] for r in rows)
+    total_steps = sum(r[2] for r in rows)
+    value = total_steps / max_wall
+    ms_per_step = max_wall / a.steps * 1e3
+    out = {
+        "metric": "UNet denoising steps/sec, 12x256x256 bf16, CFG on",
+        "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: AVSync15 shape, 1 clip per GPU, 12x256x256 (latent 12x32x32), "
+                               "SD1.5-shaped AudioUNet3D 1.17B params random-init, CFG batch 2 (audio guidance 4.0), "
+                               "DDIM-50 schedule, step = UNet forward + guidance + scheduler update",
+                   "clips_per_gpu": 1, "unet_batch": 2, "frames": 12, "latent_hw": [32, 32],
+                   "launch": "eager" if a.no_graph else "hipGraph replay", "parallelism": f"dp{world} (independent clips)"},
+        "gpu_ms_per_step_rank0": round(rows[0][1] / a.steps, 4),
+        "all_finite": all(r[3] == 1.0 for r in rows),
+        "step_tflops": round(ALGORITHMIC_TFLOP_PER_STEP / (ms_per_step * 1e-3), 2),
+        "step_mfma_frac": round(ALGORITHMIC_TFLOP_PER_STEP / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS, 4),
+    }
+
+    if not a.no_roofline:
+        timer = ops.KernelTimer()
+        ops.set_timer(timer)
+        unet.denoise_forward(latents, torch.full((1,), 501.0, device=device), rep=2)
+        ops.set_timer(None)
+        fam = timer.summary()
+        mm = [fam[k] for k in ("gemm_plain", "gemm_tmix", "gemm_conv3") if k in fam]
+        ms = sum(f["ms"] for f in mm)
+        fl = sum(f["flops"] for f in mm)
+        launches = sum(f["launches"] for f in mm)
+        ach = fl / (ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<BM,BN,MODE> family (linear / temporal-mix / conv3x3 implicit GEMM)",
+                           "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                           "traffic": None, "launches_per_step": launches, "ms_per_step": round(ms, 4),
+                           "avg_launch_us": round(ms * 1e3 / launches, 2), "tflop_per_step": round(fl / 1e12, 4)}
+        out["kernel_families"] = {
+            k: {"launches": v["launches"], "ms": round(v["ms"], 4),
+                "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
+                "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in fam.items()}
+
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(unet, clip)
+        out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

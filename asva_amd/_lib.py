@@ -8,6 +8,9 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  — must be imported BEFORE the .so is loaded: libavsd_hip.so then binds to the HIP
+#                runtime torch already mapped (one runtime, one device context) instead of a second copy
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libavsd_hip.so")
 

@@ -66,7 +66,7 @@ __device__ __forceinline__ uint4 load_a(const avsd_gemm_desc& p, const bf16_t* A
   } else if (MODE == AVSD_GEMM_TMIX) {
     const int seg = k0 / p.cseg;
     const int kk = k0 - seg * p.cseg;
-    const int64_t o = seg == 0 ? r.o0 : (seg == 1 ? r.o1 : r.o2);
+    const int64_t o = r.o2 + (seg == 0 ? r.o0 - r.o2 : 0) + (seg == 1 ? r.o1 - r.o2 : 0);
     ptr = A + o + kk;
   } else {
     const int tap = k0 / p.cin;
@@ -82,6 +82,95 @@ __device__ __forceinline__ uint4 load_a(const avsd_gemm_desc& p, const bf16_t* A
     ptr = A + pix * p.lda + c;
   }
   return *reinterpret_cast<const uint4*>(ptr);
+}
+
+// ---- shared f32 epilogue: lane holds row m = m_base + (lane&31) of fragment b, and columns
+// n = n_base + 32*a + 8q + 4*(lane>>5) + {0..3} of fragment a (see header of this file) ----------------
+template <int FN, int FM>
+__device__ __forceinline__ void epilogue(const avsd_gemm_desc& p, f32x16 (&acc)[FN][FM], int m_base, int n_base,
+                                         int lane, int64_t bz) {
+  const int frow = lane & 31;
+  const bool geglu = (p.flags & AVSD_GEMM_GEGLU) != 0;
+  const bool out_f32 = (p.flags & AVSD_GEMM_OUT_F32) != 0;
+  const bf16_t* R1 = reinterpret_cast<const bf16_t*>(p.res1);
+  const bf16_t* R2 = reinterpret_cast<const bf16_t*>(p.res2);
+  const int hsel = (lane >> 5) * 4;
+#pragma unroll
+  for (int b = 0; b < FM; ++b) {
+    const int m = m_base + b * 32 + frow;
+    if (m >= p.M) continue;
+    const float* rv = p.rowvec ? p.rowvec + (int64_t)(m / p.rows_per_vec) * p.ldv : nullptr;
+#pragma unroll
+    for (int a = 0; a < FN; ++a) {
+      const int nb = n_base + a * 32;  // first packed column of this fragment
+      if (nb >= p.N) continue;
+      if (!geglu) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = nb + 8 * q + hsel;
+          if (n >= p.N) continue;
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = p.alpha * acc[a][b][4 * q + i];
+          if (p.bias) {
+            const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+            v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+          }
+          if (rv) {
+            const float4 bb = *reinterpret_cast<const float4*>(rv + n);
+            v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+          }
+          if (R1) {
+            const uint2 rr = *reinterpret_cast<const uint2*>(R1 + bz * p.batch_stride_out + (int64_t)m * p.ldr1 + n);
+            v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+            v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+          }
+          if (R2) {
+            const uint2 rr = *reinterpret_cast<const uint2*>(R2 + bz * p.batch_stride_out + (int64_t)m * p.ldr2 + n);
+            v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+            v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+          }
+          const int64_t o = bz * p.batch_stride_out + (int64_t)m * p.ldc + n;
+          if (out_f32) {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            uint2 st;
+            st.x = pack2bf(v[0], v[1]);
+            st.y = pack2bf(v[2], v[3]);
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + o) = st;
+          }
+        }
+      } else {
+        // packed 32-row block = [16 value rows | 16 gate rows]; quads 0,1 hold values, 2,3 gates
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int nval = nb + 8 * q + hsel;   // packed column of the value
+          const int ngate = nval + 16;
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float val = p.alpha * acc[a][b][4 * q + i];
+            float gate = p.alpha * acc[a][b][4 * (q + 2) + i];
+            if (p.bias) {
+              val += p.bias[nval + i];
+              gate += p.bias[ngate + i];
+            }
+            v[i] = val * gelu_erf_f(gate);
+          }
+          const int no = (nb >> 1) + 8 * q + hsel;  // output feature
+          const int64_t o = bz * p.batch_stride_out + (int64_t)m * p.ldc + no;
+          if (out_f32) {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            uint2 st;
+            st.x = pack2bf(v[0], v[1]);
+            st.y = pack2bf(v[2], v[3]);
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + o) = st;
+          }
+        }
+      }
+    }
+  }
 }
 
 template <int BM, int BN, int MODE>
@@ -191,88 +280,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const avsd_gemm_desc p) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds row m = ..+(lane&31), columns n = ..+8q+4*(lane>>5)+{0..3} ----------
-  const bool geglu = (p.flags & AVSD_GEMM_GEGLU) != 0;
-  const bool out_f32 = (p.flags & AVSD_GEMM_OUT_F32) != 0;
-  const bf16_t* R1 = reinterpret_cast<const bf16_t*>(p.res1);
-  const bf16_t* R2 = reinterpret_cast<const bf16_t*>(p.res2);
-  const int hsel = (lane >> 5) * 4;
-#pragma unroll
-  for (int b = 0; b < FM; ++b) {
-    const int m = tm * BM + wm * (BM / 2) + b * 32 + frow;
-    if (m >= p.M) continue;
-    const float* rv = p.rowvec ? p.rowvec + (int64_t)(m / p.rows_per_vec) * p.ldv : nullptr;
-#pragma unroll
-    for (int a = 0; a < FN; ++a) {
-      const int nb = tn * BN + wn * (BN / 2) + a * 32;  // first packed column of this fragment
-      if (nb >= p.N) continue;
-      if (!geglu) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = nb + 8 * q + hsel;
-          if (n >= p.N) continue;
-          float v[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = p.alpha * acc[a][b][4 * q + i];
-          if (p.bias) {
-            const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-            v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-          }
-          if (rv) {
-            const float4 bb = *reinterpret_cast<const float4*>(rv + n);
-            v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-          }
-          if (R1) {
-            const uint2 rr = *reinterpret_cast<const uint2*>(R1 + bz * p.batch_stride_out + (int64_t)m * p.ldr1 + n);
-            v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-            v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
-          }
-          if (R2) {
-            const uint2 rr = *reinterpret_cast<const uint2*>(R2 + bz * p.batch_stride_out + (int64_t)m * p.ldr2 + n);
-            v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-            v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
-          }
-          const int64_t o = bz * p.batch_stride_out + (int64_t)m * p.ldc + n;
-          if (out_f32) {
-            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-            uint2 st;
-            st.x = pack2bf(v[0], v[1]);
-            st.y = pack2bf(v[2], v[3]);
-            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + o) = st;
-          }
-        }
-      } else {
-        // packed 32-row block = [16 value rows | 16 gate rows]; quads 0,1 hold values, 2,3 gates
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int nval = nb + 8 * q + hsel;   // packed column of the value
-          const int ngate = nval + 16;
-          float v[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            float val = p.alpha * acc[a][b][4 * q + i];
-            float gate = p.alpha * acc[a][b][4 * (q + 2) + i];
-            if (p.bias) {
-              val += p.bias[nval + i];
-              gate += p.bias[ngate + i];
-            }
-            v[i] = val * gelu_erf_f(gate);
-          }
-          const int no = (nb >> 1) + 8 * q + hsel;  // output feature
-          const int64_t o = bz * p.batch_stride_out + (int64_t)m * p.ldc + no;
-          if (out_f32) {
-            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-            uint2 st;
-            st.x = pack2bf(v[0], v[1]);
-            st.y = pack2bf(v[2], v[3]);
-            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + o) = st;
-          }
-        }
-      }
-    }
-  }
+  epilogue<FN, FM>(p, acc, tm * BM + wm * (BM / 2), tn * BN + wn * (BN / 2), lane, bz);
 }
 
 template <int BM, int BN, int MODE>
@@ -295,11 +303,341 @@ int launch(const avsd_gemm_desc& d, hipStream_t s) {
   return AVSD_OK;
 }
 
+
+// =====================================================================================================
+// v2 main loop: LDS-direct loads (buffer_load_dwordx4 ... lds), STAGES-deep LDS ring, counted vmcnt.
+//
+//  * every wave-instruction moves 64 lanes x 16 B = 1 KiB from global straight into LDS at
+//    M0 + lane*16 (no VGPR staging, asynchronous); out-of-range lanes (row >= M, conv padding, K tail)
+//    use a voffset beyond num_records and the hardware writes zeros (probed: tools/probes/glds_probe.hip)
+//  * LDS tile image: rows unpadded (128 B per row of 64 bf16), two rows = one 256-B line L; the 16-byte
+//    slot index inside a line is XOR-ed with (L & 15).  The permutation is applied on the SOURCE side
+//    (which (row, k-chunk) a lane fetches) and again on the fragment read, so the LDS destination stays
+//    lane-linear as the instruction requires, and ds_read_b128's 16-lane groups hit 16 distinct slots.
+//  * tile kt+STAGES-1 is issued while tile kt is consumed: s_waitcnt vmcnt(N) with N = loads of the
+//    tiles still allowed in flight, then ONE s_barrier per K tile (raw, so the compiler adds no vmcnt(0)).
+// =====================================================================================================
+constexpr unsigned OOB = 0x80000000u;   // every tensor handed to v2 is < 2 GiB (checked on the host)
+
+struct RowInfo32 {
+  int o0, o1, o2;   // element offsets (PLAIN: m*lda, m*lda2; TMIX: three source rows; CONV3: image index)
+  int hb, wb;
+  bool valid;
+};
+
+template <int MODE>
+__device__ __forceinline__ RowInfo32 make_row32(const avsd_gemm_desc& p, int m) {
+  RowInfo32 r;
+  r.valid = m < p.M;
+  r.o0 = r.o1 = r.o2 = r.hb = r.wb = 0;
+  if (!r.valid) return r;
+  if (MODE == AVSD_GEMM_PLAIN) {
+    r.o0 = m * p.lda;
+    r.o1 = m * p.lda2;
+  } else if (MODE == AVSD_GEMM_TMIX) {
+    const int f = (m / p.hw) % p.frames;
+    r.o0 = (m - f * p.hw) * p.lda;
+    r.o1 = (f > 0 ? m - p.hw : m) * p.lda;
+    r.o2 = m * p.lda;
+  } else {
+    const int per = p.ho * p.wo;
+    const int n = m / per;
+    const int rem = m - n * per;
+    const int oh = rem / p.wo;
+    r.o0 = n;
+    r.hb = oh * p.stride - 1;
+    r.wb = (rem - oh * p.wo) * p.stride - 1;
+  }
+  return r;
+}
+
+// byte offset of the 16-byte vector (row r, k0..k0+7) inside the A buffer, or OOB
+template <int MODE>
+__device__ __forceinline__ unsigned a_voffset(const avsd_gemm_desc& p, const RowInfo32& r, int k0) {
+  if (!r.valid || k0 >= p.K) return OOB;
+  if (MODE == AVSD_GEMM_PLAIN) {
+    return (unsigned)((k0 < p.k_split) ? (r.o0 + k0) : (r.o1 + (k0 - p.k_split))) * 2u;
+  } else if (MODE == AVSD_GEMM_TMIX) {
+    const int seg = k0 / p.cseg;
+    const int kk = k0 - seg * p.cseg;
+    // (two independent selects against 0: a 3-way select over struct fields is lowered to an indexed stack load)
+    const int o = r.o2 + (seg == 0 ? r.o0 - r.o2 : 0) + (seg == 1 ? r.o1 - r.o2 : 0);
+    return (unsigned)(o + kk) * 2u;
+  } else {
+    const int tap = k0 / p.cin;
+    const int c = k0 - tap * p.cin;
+    const int kh = tap / 3;
+    const int kw = tap - kh * 3;
+    const int hi = r.hb + kh;
+    const int wi = r.wb + kw;
+    if (tap >= 9 || hi < 0 || hi >= (p.hs << p.ups) || wi < 0 || wi >= (p.ws << p.ups)) return OOB;
+    return (unsigned)(((r.o0 * p.hs + (hi >> p.ups)) * p.ws + (wi >> p.ups)) * p.lda + c) * 2u;
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else static_assert(N < 0, "add the vmcnt literal");
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int BM, int BN, int WM, int WN, int STAGES, int MODE>
+__global__ __launch_bounds__(64 * WM * WN) void gemm2_kernel(const avsd_gemm_desc p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem2[];
+  constexpr int NWAVES = WM * WN;
+  constexpr int NT = 64 * NWAVES;
+  constexpr int A_BYTES = BM * 128;
+  constexpr int W_BYTES = BN * 128;
+  constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
+  constexpr int PA = (BM / 8) / NWAVES;   // 1-KiB pieces of the A tile per wave
+  constexpr int PW = (BN / 8) / NWAVES;
+  static_assert(PA * NWAVES * 8 == BM && PW * NWAVES * 8 == BN, "tile rows must split evenly into 1-KiB pieces per wave");
+  constexpr int LPT = PA + PW;            // loads per tile per wave
+  constexpr int FM = BM / WM / 32;
+  constexpr int FN = BN / WN / 32;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WM;
+  const int wn = wave / WM;
+
+  const int ntm = (p.M + BM - 1) / BM;
+  const int ntn = (p.N + BN - 1) / BN;
+  const int nwg = ntm * ntn;
+  int wg;
+  {
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tn = wg % ntn;
+  const int tm = wg / ntn;
+  const int64_t bz = blockIdx.z;
+
+  const bf16_t* Ab = reinterpret_cast<const bf16_t*>(p.A) + bz * p.batch_stride_a;
+  const bf16_t* A2b = p.A2 ? reinterpret_cast<const bf16_t*>(p.A2) + bz * p.batch_stride_a : Ab;
+  const bf16_t* Wb = reinterpret_cast<const bf16_t*>(p.W) + bz * p.batch_stride_w;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)A2b, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, 0x7fffffff, 0x00020000);
+
+  // ---- this lane's (row, k-chunk) for each of its pieces: line L = piece*4 + lane/16, slot = lane%16 ----
+  // (scalars in separate statically-indexed arrays: a struct array selected by a runtime field goes to scratch)
+  int ro0[PA], ro1[PA], ro2[PA], rhb[PA], rwb[PA], kca[PA];
+  bool rvalid[PA];
+#pragma unroll
+  for (int j = 0; j < PA; ++j) {
+    const int L = (wave + j * NWAVES) * 4 + (lane >> 4);
+    const int x = (lane & 15) ^ (L & 15);
+    const RowInfo32 r = make_row32<MODE>(p, tm * BM + 2 * L + (x >> 3));
+    ro0[j] = r.o0; ro1[j] = r.o1; ro2[j] = r.o2; rhb[j] = r.hb; rwb[j] = r.wb; rvalid[j] = r.valid;
+    kca[j] = (x & 7) * 8;
+  }
+  int wo[PW], kcw[PW];
+  bool wv[PW];
+#pragma unroll
+  for (int j = 0; j < PW; ++j) {
+    const int L = (wave + j * NWAVES) * 4 + (lane >> 4);
+    const int x = (lane & 15) ^ (L & 15);
+    const int n = tn * BN + 2 * L + (x >> 3);
+    wv[j] = n < p.N;
+    kcw[j] = (x & 7) * 8;
+    wo[j] = n * p.ldw + kcw[j];
+  }
+
+  // K-tile decode state of the NEXT tile to issue, kept wave-uniform (scalar registers) and advanced
+  // incrementally.  Per piece, (abase, aok) = element offset of the lane's vector at channel/segment offset 0
+  // and its validity; they change only when the tile enters a new conv tap / temporal segment / second
+  // source (`rebase`, a wave-uniform branch), so the per-tile address work is one add per load.
+  // Fast path needs every K tile inside one tap / segment (cin % 64 == 0, cseg % 64 == 0).
+  const bool fast = (MODE == AVSD_GEMM_PLAIN) || (MODE == AVSD_GEMM_TMIX && p.cseg % BK == 0) ||
+                    (MODE == AVSD_GEMM_CONV3 && p.cin % BK == 0);
+  int i_kbase = 0;      // first k of the tile
+  int i_c0 = 0;         // PLAIN: = kbase; CONV3: channel offset inside the tap; TMIX: offset inside the segment
+  int i_kh = 0, i_kw = 0, i_seg = 0;
+  bool i_second = false;
+  const int hin = p.hs << p.ups, win = p.ws << p.ups;
+  int abase[PA];
+  bool aok[PA];
+
+  auto rebase = [&]() {
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+      if (MODE == AVSD_GEMM_PLAIN) {
+        abase[j] = (i_second ? ro1[j] - p.k_split : ro0[j]) + kca[j];
+        aok[j] = rvalid[j];
+      } else if (MODE == AVSD_GEMM_TMIX) {
+        const int o = ro2[j] + (i_seg == 0 ? ro0[j] - ro2[j] : 0) + (i_seg == 1 ? ro1[j] - ro2[j] : 0);
+        abase[j] = o + kca[j];
+        aok[j] = rvalid[j] && i_seg < 3;
+      } else {
+        const int hi = rhb[j] + i_kh;
+        const int wi = rwb[j] + i_kw;
+        aok[j] = rvalid[j] && i_kh < 3 && (unsigned)hi < (unsigned)hin && (unsigned)wi < (unsigned)win;
+        abase[j] = ((ro0[j] * p.hs + (hi >> p.ups)) * p.ws + (wi >> p.ups)) * p.lda + kca[j];
+      }
+    }
+  };
+  rebase();
+
+  auto issue = [&](int stage) {
+    unsigned char* sb = smem2 + stage * STAGE_BYTES;
+    const int kbase = i_kbase;
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+      unsigned vo;
+      if (!fast) {
+        RowInfo32 r;
+        r.o0 = ro0[j]; r.o1 = ro1[j]; r.o2 = ro2[j]; r.hb = rhb[j]; r.wb = rwb[j]; r.valid = rvalid[j];
+        vo = a_voffset<MODE>(p, r, kbase + kca[j]);
+      } else {
+        const bool ok = aok[j] && (kbase + kca[j] < p.K);
+        vo = ok ? (unsigned)(abase[j] + i_c0) * 2u : OOB;
+      }
+      lds_ptr_t dst = (lds_ptr_t)(sb + (wave + j * NWAVES) * 1024);
+      if (i_second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, dst, 16, (int)vo, 0, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, dst, 16, (int)vo, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      const unsigned vo = (wv[j] && kbase + kcw[j] < p.K) ? (unsigned)(wo[j] + kbase) * 2u : OOB;
+      lds_ptr_t dst = (lds_ptr_t)(sb + A_BYTES + (wave + j * NWAVES) * 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, dst, 16, (int)vo, 0, 0, 0);
+    }
+    // advance the decode state to the next K tile
+    i_kbase += BK;
+    if (MODE == AVSD_GEMM_PLAIN) {
+      i_c0 = i_kbase;
+      if (!i_second && i_kbase >= p.k_split && i_kbase < p.K) { i_second = true; rebase(); }
+    } else if (MODE == AVSD_GEMM_TMIX) {
+      i_c0 += BK;
+      if (i_c0 >= p.cseg) { i_c0 = 0; ++i_seg; rebase(); }
+    } else {
+      i_c0 += BK;
+      if (i_c0 >= p.cin) {
+        i_c0 = 0;
+        if (++i_kw == 3) { i_kw = 0; ++i_kh; }
+        rebase();
+      }
+    }
+  };
+
+  f32x16 acc[FN][FM];
+#pragma unroll
+  for (int a = 0; a < FN; ++a)
+#pragma unroll
+    for (int b = 0; b < FM; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // fragment read addressing: row r of a tile -> line r>>1, slot ((r&1)<<3 | chunk) ^ (line & 15)
+  int a_line[FM], a_sw[FM], a_hi[FM];
+#pragma unroll
+  for (int b = 0; b < FM; ++b) {
+    const int r = wm * (BM / WM) + b * 32 + (lane & 31);
+    a_line[b] = (r >> 1) * 256;
+    a_sw[b] = (r >> 1) & 15;
+    a_hi[b] = (r & 1) << 3;
+  }
+  int w_line[FN], w_sw[FN], w_hi[FN];
+#pragma unroll
+  for (int a = 0; a < FN; ++a) {
+    const int r = wn * (BN / WN) + a * 32 + (lane & 31);
+    w_line[a] = (r >> 1) * 256;
+    w_sw[a] = (r >> 1) & 15;
+    w_hi[a] = (r & 1) << 3;
+  }
+  const int chalf = lane >> 5;
+
+  const int nk = (p.K + BK - 1) / BK;
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) issue(s);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    // tiles kt+1 .. kt+STAGES-2 may stay in flight
+    if constexpr (STAGES == 3) {
+      if (kt + 1 < nk) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+    } else if constexpr (STAGES == 4) {
+      if (kt + 2 < nk) wait_vmcnt<2 * LPT>(); else if (kt + 1 < nk) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (kt + STAGES - 1 < nk) issue((kt + STAGES - 1) % STAGES);
+
+    const unsigned char* sA = smem2 + (kt % STAGES) * STAGE_BYTES;
+    const unsigned char* sW = sA + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int c = ks * 2 + chalf;
+      bf16x8 xf[FM], wf[FN];
+#pragma unroll
+      for (int b = 0; b < FM; ++b)
+        xf[b] = *reinterpret_cast<const bf16x8*>(sA + a_line[b] + (((a_hi[b] | c) ^ a_sw[b]) << 4));
+#pragma unroll
+      for (int a = 0; a < FN; ++a)
+        wf[a] = *reinterpret_cast<const bf16x8*>(sW + w_line[a] + (((w_hi[a] | c) ^ w_sw[a]) << 4));
+#pragma unroll
+      for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FM; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+    }
+  }
+
+  epilogue<FN, FM>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz);
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, int MODE>
+int launch2(const avsd_gemm_desc& d, hipStream_t s) {
+  constexpr size_t lds = (size_t)STAGES * (BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<BM, BN, WM, WN, STAGES, MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      avsd_set_error("gemm2: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+      return AVSD_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
+  dim3 grid((unsigned)(ntm * ntn), 1, (unsigned)d.batch);
+  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM, WN, STAGES, MODE>), grid, dim3(64 * WM * WN), lds, s, d);
+  AVSD_CHECK_LAUNCH("gemm2 launch");
+  return AVSD_OK;
+}
+
 template <int MODE>
 int dispatch_tile(const avsd_gemm_desc& d, int tile, hipStream_t s) {
   switch (tile) {
     case 1: return launch<128, 128, MODE>(d, s);
     case 2: return launch<128, 64, MODE>(d, s);
+    case 3: return launch<64, 64, MODE>(d, s);
+    // v2 (LDS-direct ring): BM, BN, waves M x N, stages
+    case 4: return launch2<128, 64, 2, 2, 3, MODE>(d, s);
+    case 5: return launch2<128, 128, 2, 2, 3, MODE>(d, s);
+    case 6: return launch2<128, 128, 2, 4, 3, MODE>(d, s);
+    case 7: return launch2<64, 64, 2, 2, 4, MODE>(d, s);
+    case 8: return launch2<256, 64, 4, 2, 3, MODE>(d, s);
+    case 9: return launch2<256, 128, 4, 2, 3, MODE>(d, s);
+    case 10: return launch2<128, 64, 2, 2, 4, MODE>(d, s);
     default: return launch<64, 64, MODE>(d, s);
   }
 }
@@ -362,7 +700,14 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
     AVSD_REQUIRE(false, "gemm: unknown mode %d", d.mode);
   }
   int tile = d.tile;
-  if (tile < 1 || tile > 3) tile = pick_tile(d.M, (d.flags & AVSD_GEMM_GEGLU) ? d.N : d.N, d.batch);
+  // v2 tiles (>= 4) address A/W with 32-bit byte offsets: fall back to v1 for tensors >= 2 GiB
+  {
+    const double a_rows = d.mode == AVSD_GEMM_CONV3 ? (double)(d.M / (d.ho * d.wo)) * d.hs * d.ws : (double)d.M;
+    const bool big = a_rows * d.lda * 2.0 >= 2147483648.0 || (double)d.N * d.ldw * 2.0 >= 2147483648.0 ||
+                     (d.A2 && (double)d.M * d.lda2 * 2.0 >= 2147483648.0);
+    if (big && (tile < 1 || tile > 3)) tile = (d.N > 64 && d.M > 2048) ? 1 : 3;
+  }
+  if (tile < 1 || tile > 10) tile = pick_tile(d.M, (d.flags & AVSD_GEMM_GEGLU) ? d.N : d.N, d.batch);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (d.mode) {
     case AVSD_GEMM_PLAIN: return dispatch_tile<AVSD_GEMM_PLAIN>(d, tile, s);

@@ -65,6 +65,48 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---- per-shape tile autotuning -------------------------------------------------------------------------
+# The GEMM kernel exists in several tile/wave/stage configurations (gemm.hip: dispatch_tile).  Which one is
+# fastest depends on (mode, M, N, K): the first time a shape is seen OUTSIDE a graph capture, every candidate is
+# timed with HIP events on the caller's real buffers and the winner is cached for the life of the process
+# (measure, don't guess).  During capture, or with autotuning off, an uncached shape falls back to the
+# library's static heuristic (tile 0).
+TILE_CANDIDATES = (4, 6, 7, 8, 9, 3)
+_TILE_CACHE: dict = {}
+_AUTOTUNE = True
+
+
+def set_autotune(on: bool) -> None:
+    global _AUTOTUNE
+    _AUTOTUNE = bool(on)
+
+
+def tile_cache() -> dict:
+    return _TILE_CACHE
+
+
+def _pick_tile(key, launch) -> int:
+    t = _TILE_CACHE.get(key)
+    if t is not None:
+        return t
+    if not _AUTOTUNE or _TIMER is not None or torch.cuda.is_current_stream_capturing():
+        return 0
+    best, best_ms = 0, float("inf")
+    for cand in TILE_CANDIDATES:
+        launch(cand)                       # warm (also sets the kernel's LDS attribute)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            launch(cand)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        if ms < best_ms:
+            best, best_ms = cand, ms
+    _TILE_CACHE[key] = best
+    return best
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -161,6 +203,12 @@ def gemm(
     d.mode = mode
     d.flags = (GEGLU if geglu else 0) | (OUT_F32 if out_f32 else 0)
     d.batch = 1
+    if tile == 0:
+        def _launch(t):
+            d.tile = t
+            check(_lib.lib().avsd_gemm_bf16(C.byref(d), _stream()), "avsd_gemm_bf16")
+
+        tile = _pick_tile((mode, M, N, K, d.flags, d.stride, d.ups), _launch)
     d.tile = tile
     ev = _TIMER.start() if _TIMER is not None else None
     check(_lib.lib().avsd_gemm_bf16(C.byref(d), _stream()), "avsd_gemm_bf16")
@@ -185,6 +233,12 @@ def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, alpha: float = 1.0, out_f3
     d.lda, d.ldw, d.ldc = a.stride(1), w.stride(1), out.stride(1)
     d.alpha, d.mode, d.flags, d.batch, d.tile = alpha, PLAIN, (OUT_F32 if out_f32 else 0), B, tile
     d.batch_stride_a, d.batch_stride_w, d.batch_stride_out = a.stride(0), w.stride(0), out.stride(0)
+    if tile == 0:
+        def _launch(t):
+            d.tile = t
+            check(_lib.lib().avsd_gemm_bf16(C.byref(d), _stream()), "avsd_gemm_bf16(batched)")
+
+        d.tile = _pick_tile(("batched", B, M, N, K, d.flags), _launch)
     ev = _TIMER.start() if _TIMER is not None else None
     check(_lib.lib().avsd_gemm_bf16(C.byref(d), _stream()), "avsd_gemm_bf16(batched)")
     if ev is not None:

@@ -77,7 +77,21 @@ def cpu_baseline(unet, clip):
     from asva_amd.conditioning import audio_segment_mask
     from oracle.unet_ref import unet_forward
 
-    cores = os.cpu_count() or 1
+    # pick the thread count that is fastest on this host for a representative conv (many-core boxes are
+    # slower with every hardware thread); `cores` reports the threads actually used
+    import torch.nn.functional as F
+
+    best, cores = None, 1
+    xc, wc = torch.randn(24, 320, 32, 32), torch.randn(320, 320, 3, 3)
+    for n in sorted({min(c, os.cpu_count() or 1) for c in (8, 16, 32, 64, 128)}):
+        torch.set_num_threads(n)
+        F.conv2d(xc, wc, padding=1)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            F.conv2d(xc, wc, padding=1)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best:
+            best, cores = dt, n
     torch.set_num_threads(cores)
     sd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
     lat, text, audio, null_audio = [t.float().cpu() for t in clip]

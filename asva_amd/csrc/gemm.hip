@@ -428,6 +428,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_kernel(const avsd_gemm_des
   const int tn = wg % ntn;
   const int tm = wg / ntn;
   const int64_t bz = blockIdx.z;
+  // split-K: this workgroup owns K tiles [kt0, kt1)
+  const int nk_all = (p.K + BK - 1) / BK;
+  const int nsplit = p.split_k > 1 ? p.split_k : 1;
+  const int per_split = (nk_all + nsplit - 1) / nsplit;
+  const int kt0 = blockIdx.y * per_split;
+  const int kt1 = min(nk_all, kt0 + per_split);
 
   const bf16_t* Ab = reinterpret_cast<const bf16_t*>(p.A) + bz * p.batch_stride_a;
   const bf16_t* A2b = p.A2 ? reinterpret_cast<const bf16_t*>(p.A2) + bz * p.batch_stride_a : Ab;
@@ -467,10 +473,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_kernel(const avsd_gemm_des
   // Fast path needs every K tile inside one tap / segment (cin % 64 == 0, cseg % 64 == 0).
   const bool fast = (MODE == AVSD_GEMM_PLAIN) || (MODE == AVSD_GEMM_TMIX && p.cseg % BK == 0) ||
                     (MODE == AVSD_GEMM_CONV3 && p.cin % BK == 0);
-  int i_kbase = 0;      // first k of the tile
-  int i_c0 = 0;         // PLAIN: = kbase; CONV3: channel offset inside the tap; TMIX: offset inside the segment
+  int i_kbase = kt0 * BK;   // first k of the tile
+  int i_c0 = 0;             // PLAIN: = kbase; CONV3: channel offset inside the tap; TMIX: offset inside the segment
   int i_kh = 0, i_kw = 0, i_seg = 0;
   bool i_second = false;
+  if (MODE == AVSD_GEMM_PLAIN) {
+    i_c0 = i_kbase;
+    i_second = p.A2 != nullptr && i_kbase >= p.k_split;
+  } else if (MODE == AVSD_GEMM_TMIX) {
+    i_seg = i_kbase / p.cseg;
+    i_c0 = i_kbase - i_seg * p.cseg;
+  } else {
+    const int tap = i_kbase / p.cin;
+    i_c0 = i_kbase - tap * p.cin;
+    i_kh = tap / 3;
+    i_kw = tap - i_kh * 3;
+  }
   const int hin = p.hs << p.ups, win = p.ws << p.ups;
   int abase[PA];
   bool aok[PA];
@@ -564,7 +582,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_kernel(const avsd_gemm_des
   }
   const int chalf = lane >> 5;
 
-  const int nk = (p.K + BK - 1) / BK;
+  const int nk = max(kt1 - kt0, 0);
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < nk) issue(s);
@@ -601,7 +619,72 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_kernel(const avsd_gemm_des
     }
   }
 
+  if (p.split_k > 1) {
+    // raw f32 partial tile -> ws[split][m][n]; the reduce kernel applies the epilogue
+    float* ws = p.splitk_ws + (int64_t)blockIdx.y * p.M * p.N;
+    const int hsel = (lane >> 5) * 4;
+#pragma unroll
+    for (int b = 0; b < FM; ++b) {
+      const int m = tm * BM + wm * (BM / WM) + b * 32 + (lane & 31);
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = tn * BN + wn * (BN / WN) + a * 32 + 8 * q + hsel;
+          if (n < p.N)
+            *reinterpret_cast<float4*>(ws + (int64_t)m * p.N + n) =
+                make_float4(acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]);
+        }
+    }
+    return;
+  }
   epilogue<FN, FM>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz);
+}
+
+// out = epilogue(sum_s ws[s]) for split-K launches: one thread per 4 consecutive columns
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const avsd_gemm_desc p) {
+  const int nq = p.N / 4;
+  const int64_t total = (int64_t)p.M * nq;
+  const bf16_t* R1 = reinterpret_cast<const bf16_t*>(p.res1);
+  const bf16_t* R2 = reinterpret_cast<const bf16_t*>(p.res2);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / nq);
+    const int n = (int)(i - (int64_t)m * nq) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < p.split_k; ++s) {
+      const float4 v = *reinterpret_cast<const float4*>(p.splitk_ws + ((int64_t)s * p.M + m) * p.N + n);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float v[4] = {p.alpha * acc.x, p.alpha * acc.y, p.alpha * acc.z, p.alpha * acc.w};
+    if (p.bias) {
+      const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+      v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+    }
+    if (p.rowvec) {
+      const float4 bb = *reinterpret_cast<const float4*>(p.rowvec + (int64_t)(m / p.rows_per_vec) * p.ldv + n);
+      v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+    }
+    if (R1) {
+      const uint2 rr = *reinterpret_cast<const uint2*>(R1 + (int64_t)m * p.ldr1 + n);
+      v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+      v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+    }
+    if (R2) {
+      const uint2 rr = *reinterpret_cast<const uint2*>(R2 + (int64_t)m * p.ldr2 + n);
+      v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+      v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+    }
+    const int64_t o = (int64_t)m * p.ldc + n;
+    if (p.flags & AVSD_GEMM_OUT_F32) {
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      uint2 st;
+      st.x = pack2bf(v[0], v[1]);
+      st.y = pack2bf(v[2], v[3]);
+      *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + o) = st;
+    }
+  }
 }
 
 template <int BM, int BN, int WM, int WN, int STAGES, int MODE>
@@ -618,9 +701,17 @@ int launch2(const avsd_gemm_desc& d, hipStream_t s) {
     attr_set = true;
   }
   const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
-  dim3 grid((unsigned)(ntm * ntn), 1, (unsigned)d.batch);
+  const int nsplit = d.split_k > 1 ? d.split_k : 1;
+  dim3 grid((unsigned)(ntm * ntn), (unsigned)nsplit, (unsigned)d.batch);
   hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM, WN, STAGES, MODE>), grid, dim3(64 * WM * WN), lds, s, d);
   AVSD_CHECK_LAUNCH("gemm2 launch");
+  if (nsplit > 1) {
+    const int64_t total = (int64_t)d.M * (d.N / 4);
+    int64_t g = (total + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, d);
+    AVSD_CHECK_LAUNCH("gemm split-K reduce launch");
+  }
   return AVSD_OK;
 }
 
@@ -698,6 +789,12 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
     AVSD_REQUIRE(d.ho == (hin + 2 - 3) / d.stride + 1 && d.wo == (win + 2 - 3) / d.stride + 1, "gemm/conv3: (ho,wo)=(%d,%d) inconsistent with input (%d,%d) stride %d", d.ho, d.wo, hin, win, d.stride);
   } else {
     AVSD_REQUIRE(false, "gemm: unknown mode %d", d.mode);
+  }
+  if (d.split_k > 1) {
+    AVSD_REQUIRE(d.splitk_ws != nullptr, "gemm: split_k needs a workspace");
+    AVSD_REQUIRE(!(d.flags & AVSD_GEMM_GEGLU) && d.batch == 1, "gemm: split_k cannot be combined with GEGLU or batching");
+    AVSD_REQUIRE(d.tile >= 4 && d.tile <= 10, "gemm: split_k needs an LDS-direct tile (4..10), got %d", d.tile);
+    AVSD_REQUIRE(d.split_k <= (d.K + 63) / 64, "gemm: split_k (%d) exceeds the number of K tiles", d.split_k);
   }
   int tile = d.tile;
   // v2 tiles (>= 4) address A/W with 32-bit byte offsets: fall back to v1 for tensors >= 2 GiB

@@ -9,21 +9,19 @@
 
 namespace {
 
-// ---- GroupNorm statistics ---------------------------------------------------------------------
-// grid (nchunks, nb); block = nvec * ppb threads: thread -> (channel vector t % nvec, position
-// t / nvec), striding ppb positions.  Per-channel sums are combined through LDS atomics, then the
-// first `groups` threads fold channels into groups and write this chunk's (sum, sumsq).
+// ---- GroupNorm statistics -----------------------------------------------------------------------
+// Three launches, all deterministic (no atomics):
+//   gn_stats_kernel    grid (nchunks, nb): thread -> (channel vector t % nvec, position t / nvec), striding ppb
+//                      positions over its chunk of rows; per-thread sums are laid out in LDS [ppb][2C] and the
+//                      first `groups` threads fold (positions x channels-of-group) -> partial[nb][nchunks][g][2]
+//   gn_finalize_kernel grid nb: 8 lanes per group tree-reduce the chunks in double -> stat[nb][g] = (mean, rstd)
+//   gn_apply_kernel    streams rows: y = act(x * scale[c] + shift[c]) with scale/shift built once per block in LDS
 __global__ void gn_stats_kernel(const bf16_t* x1, int ld1, int c1, const bf16_t* x2, int ld2, int c2,
                                 int rows_per_batch, int groups, float* partial, int nchunks, int nvec,
                                 int ppb) {
-  extern __shared__ float sgn[];  // [C] sum | [C] sumsq
+  extern __shared__ float sgn[];  // [ppb][2*C]: sums | sums of squares
   const int C = c1 + c2;
-  float* ssum = sgn;
-  float* ssq = sgn + C;
   const int tid = threadIdx.x;
-  for (int c = tid; c < 2 * C; c += blockDim.x) sgn[c] = 0.f;
-  __syncthreads();
-
   const int chunk = blockIdx.x;
   const int b = blockIdx.y;
   const int chunk_rows = (rows_per_batch + nchunks - 1) / nchunks;
@@ -33,10 +31,10 @@ __global__ void gn_stats_kernel(const bf16_t* x1, int ld1, int c1, const bf16_t*
   const int pos0 = tid / nvec;
   const int c0 = vec * 8;
 
-  float s[8], ss[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
   if (pos0 < ppb) {
+    float s[8], ss[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
     const bf16_t* base;
     int ld;
     if (c0 < c1) { base = x1 + c0; ld = ld1; } else { base = x2 + (c0 - c1); ld = ld2; }
@@ -47,59 +45,71 @@ __global__ void gn_stats_kernel(const bf16_t* x1, int ld1, int c1, const bf16_t*
 #pragma unroll
       for (int e = 0; e < 8; ++e) { s[e] += f[e]; ss[e] = fmaf(f[e], f[e], ss[e]); }
     }
+    float* dst = sgn + (size_t)pos0 * 2 * C + c0;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      atomicAdd(&ssum[c0 + e], s[e]);
-      atomicAdd(&ssq[c0 + e], ss[e]);
-    }
+    for (int e = 0; e < 8; ++e) { dst[e] = s[e]; dst[C + e] = ss[e]; }
   }
   __syncthreads();
   if (tid < groups) {
     const int cg = C / groups;
     float a = 0.f, q = 0.f;
-    for (int c = tid * cg; c < (tid + 1) * cg; ++c) { a += ssum[c]; q += ssq[c]; }
+    for (int pp = 0; pp < ppb; ++pp) {
+      const float* row = sgn + (size_t)pp * 2 * C + tid * cg;
+      for (int c = 0; c < cg; ++c) { a += row[c]; q += row[C + c]; }
+    }
     float* o = partial + (((int64_t)b * nchunks + chunk) * groups + tid) * 2;
     o[0] = a;
     o[1] = q;
   }
 }
 
-// ---- GroupNorm apply (+ optional SiLU, + channel concat) ----------------------------------------
-// grid (row blocks, nb); every block re-reduces the per-chunk partials of its batch (double) into
-// per-channel scale/shift in LDS, then streams its rows.
-__global__ void gn_apply_kernel(const bf16_t* x1, int ld1, int c1, const bf16_t* x2, int ld2, int c2,
-                                int rows_per_batch, int groups, const float* partial, int nchunks,
-                                const float* gamma, const float* beta, float eps, int act, bf16_t* y,
-                                int ldy, int rows_per_block) {
-  extern __shared__ float sap[];  // [C] scale | [C] shift | [groups] mean | [groups] rstd
-  const int C = c1 + c2;
-  float* sscale = sap;
-  float* sshift = sap + C;
-  float* smean = sap + 2 * C;
-  float* srstd = smean + groups;
-  const int tid = threadIdx.x;
-  const int b = blockIdx.y;
-  const int cg = C / groups;
-  if (tid < groups) {
-    double a = 0.0, q = 0.0;
-    for (int k = 0; k < nchunks; ++k) {
-      const float* o = partial + (((int64_t)b * nchunks + k) * groups + tid) * 2;
+__global__ __launch_bounds__(512) void gn_finalize_kernel(const float* partial, int nchunks, int groups, int rows_per_batch,
+                                                          int cg, float eps, float* stat) {
+  const int b = blockIdx.x;
+  const int g = threadIdx.x >> 3;     // 8 lanes per group
+  const int sub = threadIdx.x & 7;
+  double a = 0.0, q = 0.0;
+  if (g < groups) {
+    for (int k = sub; k < nchunks; k += 8) {
+      const float* o = partial + (((int64_t)b * nchunks + k) * groups + g) * 2;
       a += (double)o[0];
       q += (double)o[1];
     }
+  }
+#pragma unroll
+  for (int off = 4; off > 0; off >>= 1) {
+    a += __shfl_xor(a, off, 64);
+    q += __shfl_xor(q, off, 64);
+  }
+  if (g < groups && sub == 0) {
     const double n = (double)rows_per_batch * cg;
     const double mean = a / n;
     double var = q / n - mean * mean;
     if (var < 0.0) var = 0.0;
-    smean[tid] = (float)mean;
-    srstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+    stat[((int64_t)b * groups + g) * 2 + 0] = (float)mean;
+    stat[((int64_t)b * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
   }
-  __syncthreads();
+}
+
+// ---- GroupNorm apply (+ optional SiLU, + channel concat) ----------------------------------------
+__global__ void gn_apply_kernel(const bf16_t* x1, int ld1, int c1, const bf16_t* x2, int ld2, int c2,
+                                int rows_per_batch, int groups, const float* stat,
+                                const float* gamma, const float* beta, int act, bf16_t* y,
+                                int ldy, int rows_per_block) {
+  extern __shared__ float sap[];  // [C] scale | [C] shift
+  const int C = c1 + c2;
+  float* sscale = sap;
+  float* sshift = sap + C;
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int cg = C / groups;
   for (int c = tid; c < C; c += blockDim.x) {
     const int g = c / cg;
-    const float sc = srstd[g] * gamma[c];
+    const float mean = stat[((int64_t)b * groups + g) * 2 + 0];
+    const float rstd = stat[((int64_t)b * groups + g) * 2 + 1];
+    const float sc = rstd * gamma[c];
     sscale[c] = sc;
-    sshift[c] = beta[c] - smean[g] * sc;
+    sshift[c] = beta[c] - mean * sc;
   }
   __syncthreads();
 
@@ -221,12 +231,17 @@ void gn_geometry(int C, int* nvec, int* ppb, int* threads) {
 extern "C" int avsd_groupnorm_nchunks(int nb, int rows_per_batch, int channels) {
   (void)channels;
   if (nb <= 0 || rows_per_batch <= 0) return 1;
-  int n = 512 / nb;
-  int cap = rows_per_batch / 16;
+  int n = 2048 / nb;                 // ~2048 blocks in flight
+  int cap = rows_per_batch / 8;      // >= 8 rows per chunk
   if (n > cap) n = cap;
-  if (n > 64) n = 64;
+  if (n > 1024) n = 1024;
   if (n < 1) n = 1;
   return n;
+}
+
+// floats of scratch the stats + apply pair needs: partial[nb][nchunks][groups][2] then stat[nb][groups][2]
+extern "C" int avsd_groupnorm_scratch_floats(int nb, int nchunks, int groups) {
+  return nb * nchunks * groups * 2 + nb * groups * 2;
 }
 
 static int gn_check(const void* x1, int ld1, int c1, const void* x2, int ld2, int c2, int nb,
@@ -241,36 +256,43 @@ static int gn_check(const void* x1, int ld1, int c1, const void* x2, int ld2, in
 }
 
 extern "C" int avsd_groupnorm_stats(const void* x1, int ld1, int c1, const void* x2, int ld2, int c2, int nb,
-                                    int rows_per_batch, int groups, float* partial, int nchunks, void* stream) {
+                                    int rows_per_batch, int groups, float eps, float* scratch, int nchunks,
+                                    void* stream) {
   int rc = gn_check(x1, ld1, c1, x2, ld2, c2, nb, rows_per_batch, groups, nchunks);
   if (rc) return rc;
-  AVSD_REQUIRE(partial, "groupnorm_stats: null partial buffer");
+  AVSD_REQUIRE(scratch, "groupnorm_stats: null scratch buffer");
   const int C = c1 + c2;
   int nvec, ppb, threads;
   gn_geometry(C, &nvec, &ppb, &threads);
-  const size_t lds = (size_t)2 * C * sizeof(float);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)nchunks, (unsigned)nb), dim3((unsigned)threads), lds,
-                     reinterpret_cast<hipStream_t>(stream), (const bf16_t*)x1, ld1, c1, (const bf16_t*)x2, ld2, c2,
-                     rows_per_batch, groups, partial, nchunks, nvec, ppb);
+  const size_t lds = (size_t)ppb * 2 * C * sizeof(float);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)nchunks, (unsigned)nb), dim3((unsigned)threads), lds, s,
+                     (const bf16_t*)x1, ld1, c1, (const bf16_t*)x2, ld2, c2, rows_per_batch, groups, scratch, nchunks, nvec, ppb);
   AVSD_CHECK_LAUNCH("groupnorm_stats launch");
+  float* stat = scratch + (size_t)nb * nchunks * groups * 2;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)nb), dim3(512), 0, s, scratch, nchunks, groups, rows_per_batch,
+                     C / groups, eps, stat);
+  AVSD_CHECK_LAUNCH("groupnorm_finalize launch");
   return AVSD_OK;
 }
 
 extern "C" int avsd_groupnorm_apply(const void* x1, int ld1, int c1, const void* x2, int ld2, int c2, int nb,
-                                    int rows_per_batch, int groups, const float* partial, int nchunks,
-                                    const float* gamma, const float* beta, float eps, int act, void* y, int ldy,
+                                    int rows_per_batch, int groups, const float* scratch, int nchunks,
+                                    const float* gamma, const float* beta, int act, void* y, int ldy,
                                     void* stream) {
   int rc = gn_check(x1, ld1, c1, x2, ld2, c2, nb, rows_per_batch, groups, nchunks);
   if (rc) return rc;
-  AVSD_REQUIRE(partial && gamma && beta && y, "groupnorm_apply: null pointer");
+  AVSD_REQUIRE(scratch && gamma && beta && y, "groupnorm_apply: null pointer");
   const int C = c1 + c2;
   AVSD_REQUIRE(ldy % 8 == 0 && ldy >= C, "groupnorm_apply: bad ldy %d", ldy);
-  const int rows_per_block = 32;
+  int rows_per_block = 16;
+  while ((int64_t)nb * ((rows_per_batch + rows_per_block - 1) / rows_per_block) > 4096) rows_per_block *= 2;
   const int nblk = (rows_per_batch + rows_per_block - 1) / rows_per_block;
-  const size_t lds = (size_t)(2 * C + 2 * groups) * sizeof(float);
+  const size_t lds = (size_t)2 * C * sizeof(float);
+  const float* stat = scratch + (size_t)nb * nchunks * groups * 2;
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)nblk, (unsigned)nb), dim3(256), lds,
                      reinterpret_cast<hipStream_t>(stream), (const bf16_t*)x1, ld1, c1, (const bf16_t*)x2, ld2, c2,
-                     rows_per_batch, groups, partial, nchunks, gamma, beta, eps, act, (bf16_t*)y, ldy, rows_per_block);
+                     rows_per_batch, groups, stat, gamma, beta, act, (bf16_t*)y, ldy, rows_per_block);
   AVSD_CHECK_LAUNCH("groupnorm_apply launch");
   return AVSD_OK;
 }

@@ -71,7 +71,9 @@ def _stream() -> int:
 # timed with HIP events on the caller's real buffers and the winner is cached for the life of the process
 # (measure, don't guess).  During capture, or with autotuning off, an uncached shape falls back to the
 # library's static heuristic (tile 0).
-TILE_CANDIDATES = (4, 6, 7, 8, 9, 3)
+TILE_CANDIDATES = ((4, 1), (6, 1), (7, 1), (8, 1), (9, 1), (3, 1))
+# extra (tile, split_k) candidates for GEMMs whose output is too small to fill 256 CUs with big tiles
+SPLITK_CANDIDATES = ((6, 2), (6, 4), (6, 8), (9, 2), (9, 4), (4, 2), (4, 4), (4, 8), (7, 2), (7, 4))
 _TILE_CACHE: dict = {}
 _AUTOTUNE = True
 
@@ -85,19 +87,20 @@ def tile_cache() -> dict:
     return _TILE_CACHE
 
 
-def _pick_tile(key, launch) -> int:
+def _pick_tile(key, launch, candidates=TILE_CANDIDATES):
+    """-> (tile, split_k)"""
     t = _TILE_CACHE.get(key)
     if t is not None:
         return t
     if not _AUTOTUNE or _TIMER is not None or torch.cuda.is_current_stream_capturing():
-        return 0
-    best, best_ms = 0, float("inf")
-    for cand in TILE_CANDIDATES:
-        launch(cand)                       # warm (also sets the kernel's LDS attribute)
+        return (0, 1)
+    best, best_ms = (0, 1), float("inf")
+    for cand in candidates:
+        launch(*cand)                      # warm (also sets the kernel's LDS attribute)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(3):
-            launch(cand)
+            launch(*cand)
         e1.record()
         e1.synchronize()
         ms = e0.elapsed_time(e1)
@@ -145,6 +148,7 @@ def gemm(
     conv: Optional[tuple] = None,      # (n_img, hs, ws, stride, ups)
     m: Optional[int] = None,
     tile: int = 0,
+    split_k: int = 1,
 ) -> torch.Tensor:
     """out = epilogue(alpha * A' . W^T); see avsd_gemm_bf16 in include/avsd.h."""
     _req(a, BF16, "a")
@@ -203,13 +207,27 @@ def gemm(
     d.mode = mode
     d.flags = (GEGLU if geglu else 0) | (OUT_F32 if out_f32 else 0)
     d.batch = 1
+    ws = None
+
+    def _set(t, sk):
+        nonlocal ws
+        d.tile, d.split_k = t, sk
+        if sk > 1:
+            if ws is None or ws.numel() < sk * M * N:
+                ws = torch.empty((sk * M * N,), dtype=F32, device=a.device)
+            d.splitk_ws = _p(ws)
+
     if tile == 0:
-        def _launch(t):
-            d.tile = t
+        def _launch(t, sk):
+            _set(t, sk)
             check(_lib.lib().avsd_gemm_bf16(C.byref(d), _stream()), "avsd_gemm_bf16")
 
-        tile = _pick_tile((mode, M, N, K, d.flags, d.stride, d.ups), _launch)
-    d.tile = tile
+        cands = TILE_CANDIDATES
+        nk = (K + 63) // 64
+        if not geglu and ((M + 127) // 128) * ((N + 127) // 128) < 256 and nk >= 16:
+            cands = cands + tuple(c for c in SPLITK_CANDIDATES if nk // c[1] >= 4)
+        tile, split_k = _pick_tile((mode, M, N, K, d.flags, d.stride, d.ups), _launch, cands)
+    _set(tile, split_k)
     ev = _TIMER.start() if _TIMER is not None else None
     check(_lib.lib().avsd_gemm_bf16(C.byref(d), _stream()), "avsd_gemm_bf16")
     if ev is not None:
@@ -238,7 +256,7 @@ def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, alpha: float = 1.0, out_f3
             d.tile = t
             check(_lib.lib().avsd_gemm_bf16(C.byref(d), _stream()), "avsd_gemm_bf16(batched)")
 
-        d.tile = _pick_tile(("batched", B, M, N, K, d.flags), _launch)
+        d.tile = _pick_tile(("batched", B, M, N, K, d.flags), lambda t, sk: _launch(t))[0]
     ev = _TIMER.start() if _TIMER is not None else None
     check(_lib.lib().avsd_gemm_bf16(C.byref(d), _stream()), "avsd_gemm_bf16(batched)")
     if ev is not None:
@@ -277,15 +295,15 @@ def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], nb: int, rows_per_ba
     L = _lib.lib()
     rows = nb * rows_per_batch
     nchunks = L.avsd_groupnorm_nchunks(nb, rows_per_batch, c1 + c2)
-    partial = torch.empty((nb, nchunks, groups, 2), dtype=F32, device=x1.device)
+    partial = torch.empty((L.avsd_groupnorm_scratch_floats(nb, nchunks, groups),), dtype=F32, device=x1.device)
     if out is None:
         out = torch.empty((rows, c1 + c2), dtype=BF16, device=x1.device)
     s = _stream()
     ev = _TIMER.start() if _TIMER is not None else None
     check(L.avsd_groupnorm_stats(_p(x1), _ld(x1), c1, _p(x2), _ld(x2) if x2 is not None else 0, c2, nb, rows_per_batch,
-                                 groups, _p(partial), nchunks, s), "avsd_groupnorm_stats")
+                                 groups, float(eps), _p(partial), nchunks, s), "avsd_groupnorm_stats")
     check(L.avsd_groupnorm_apply(_p(x1), _ld(x1), c1, _p(x2), _ld(x2) if x2 is not None else 0, c2, nb, rows_per_batch,
-                                 groups, _p(partial), nchunks, _p(gamma), _p(beta), float(eps), int(act), _p(out),
+                                 groups, _p(partial), nchunks, _p(gamma), _p(beta), int(act), _p(out),
                                  _ld(out), s), "avsd_groupnorm_apply")
     if ev is not None:
         _TIMER.stop(ev, "groupnorm", 0.0, 2.0 * _nbytes(x1, x2) + _nbytes(out))

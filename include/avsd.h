@@ -91,7 +91,13 @@ typedef struct avsd_gemm_desc {
   int32_t hw, frames, cseg;
   /* CONV3: source image (hs, ws) with cin channels at row stride lda; output (ho, wo) */
   int32_t hs, ws, ho, wo, cin, stride, ups;
-  int32_t tile;                         /* 0 = auto; 1 = 128x128, 2 = 128x64, 3 = 64x64 */
+  int32_t tile;                         /* 0 = library heuristic; 1..3 register-staged tiles, 4..10 LDS-direct
+                                           tiles (see gemm.hip dispatch_tile) */
+  /* split-K (LDS-direct tiles only): K is cut into split_k slices computed by separate workgroups that
+   * store f32 partial tiles to splitk_ws[split_k][M][N]; a second launch reduces them and applies the epilogue.
+   * Deterministic (no atomics).  split_k <= 1 disables it.  Not combinable with GEGLU or batch > 1. */
+  int32_t split_k;
+  float* splitk_ws;
 } avsd_gemm_desc;
 
 int avsd_gemm_bf16(const avsd_gemm_desc* desc_host, void* stream);
@@ -106,24 +112,27 @@ int avsd_linear_small_m(const float* x, const void* W_bf16, const float* bias, f
                         int M, int N, int K, int ldw, int act_in, int act_out, void* stream);
 
 /* ---- normalisation -------------------------------------------------------------------
- * GroupNorm over channels-last data, two kernels.
+ * GroupNorm over channels-last data: stats (partials + finalize) then apply.
  * stats: for each of `nb` normalisation batches (a batch = `rows_per_batch` consecutive
  *   rows: F*H*W for the 5-D GroupNorm of ff_spatio_temp_resnet_3d.py:130,146 /
  *   audio_cond_unet_3d_condition.py:445, H*W for the per-frame GroupNorm of
- *   ff_spatio_audio_temp_transformer_3d.py:62) writes per-chunk partial (sum, sumsq) for
- *   each of `groups` channel groups to partial[nb][nchunks][groups][2].
- *   The input is the channel concat [x1 (c1 channels) | x2 (c2 channels)] (c2 may be 0).
- * apply: finishes the reduction and writes
- *   y[m, c] = act( (x - mean) * rstd * gamma[c] + beta[c] ), act 0 none / 1 SiLU, as bf16. */
+ *   ff_spatio_audio_temp_transformer_3d.py:62) reduces (sum, sumsq) of each of `groups`
+ *   channel groups over `nchunks` row chunks (deterministic, no atomics) and finalises
+ *   (mean, rstd) with biased variance and eps inside the sqrt, all inside `scratch`
+ *   (avsd_groupnorm_scratch_floats floats).  The input is the channel concat
+ *   [x1 (c1 channels) | x2 (c2 channels)] (c2 may be 0) — the UNet skip concat is never
+ *   materialised.
+ * apply: y[m, c] = act( (x - mean) * rstd * gamma[c] + beta[c] ), act 0 none / 1 SiLU, bf16. */
 int avsd_groupnorm_stats(const void* x1, int ld1, int c1, const void* x2, int ld2, int c2,
-                         int nb, int rows_per_batch, int groups, float* partial, int nchunks,
-                         void* stream);
+                         int nb, int rows_per_batch, int groups, float eps, float* scratch,
+                         int nchunks, void* stream);
 int avsd_groupnorm_apply(const void* x1, int ld1, int c1, const void* x2, int ld2, int c2,
-                         int nb, int rows_per_batch, int groups, const float* partial,
-                         int nchunks, const float* gamma, const float* beta, float eps,
-                         int act, void* y, int ldy, void* stream);
-/* Suggested nchunks for the two calls above (pure host arithmetic). */
+                         int nb, int rows_per_batch, int groups, const float* scratch,
+                         int nchunks, const float* gamma, const float* beta, int act, void* y,
+                         int ldy, void* stream);
+/* Suggested nchunks, and the scratch size in floats for it (pure host arithmetic). */
 int avsd_groupnorm_nchunks(int nb, int rows_per_batch, int channels);
+int avsd_groupnorm_scratch_floats(int nb, int nchunks, int groups);
 
 /* LayerNorm over the last dim (eps 1e-5 in the reference): y = LN(x + pos[f(m)]) with
  * pos == NULL for plain LN; f(m) = (m / hw) % frames.

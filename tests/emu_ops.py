@@ -17,7 +17,7 @@ BF16, F32 = torch.bfloat16, torch.float32
 
 
 def gemm(a, w, *, n=None, k=None, a2=None, bias=None, rowvec=None, rows_per_vec=0, res1=None, res2=None, alpha=1.0,
-         geglu=False, out_f32=False, out=None, mode=PLAIN, tmix=None, conv=None, m=None, tile=0):
+         geglu=False, out_f32=False, out=None, mode=PLAIN, tmix=None, conv=None, m=None, tile=0, split_k=1):
     assert a.dtype == BF16 and w.dtype == BF16
     wf = w.float()
     if mode == PLAIN:

@@ -160,6 +160,32 @@ def test_gemm_conv3x3(ops, stride, ups, n_img, hs, ws, cin, cout, tile):
     assert rel_l2(out, ref) < TOL_BF16
 
 
+@pytest.mark.parametrize("tile,split", [(4, 2), (6, 4), (7, 3), (9, 2), (8, 5)])
+def test_gemm_split_k(ops, tile, split):
+    from asva_amd.weights import pack_conv3x3
+
+    # conv at low resolution (the shapes split-K exists for), uneven K-tile split, full epilogue
+    n_img, hs, ws, cin, cout = 6, 4, 4, 320, 192
+    x = rnd(n_img * hs * ws, cin, seed=1)
+    w = rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5)
+    b = rndf(cout, seed=3)
+    res = rnd(n_img * hs * ws, cout, seed=4)
+    out = ops.gemm(x, pack_conv3x3(w), bias=b, res1=res, mode=ops.CONV3, conv=(n_img, hs, ws, 1, 0), tile=tile, split_k=split)
+    xi = x.float().reshape(n_img, hs, ws, cin).permute(0, 3, 1, 2)
+    ref = F.conv2d(xi, w.float(), b, padding=1).permute(0, 2, 3, 1).reshape(-1, cout) + res.float()
+    assert rel_l2(out, ref) < TOL_BF16
+    # temporal mix + plain two-source, f32 out
+    B, Fr, hw, Cc = 2, 4, 16, 320
+    y = rnd(B * Fr * hw, Cc, seed=5)
+    wt = rnd(Cc, 3 * Cc, seed=6, scale=(3 * Cc) ** -0.5)
+    out = ops.gemm(y, wt, res1=y, mode=ops.TMIX, tmix=(hw, Fr), tile=tile, split_k=split)
+    assert rel_l2(out, _tmix_ref(y, wt, torch.zeros(Cc, device=dev()), B, Fr, hw)) < TOL_BF16
+    a1, a2 = rnd(200, 640, seed=7), rnd(200, 320, seed=8)
+    w2 = rnd(132, 960, seed=9, scale=960 ** -0.5)
+    out = ops.gemm(a1, w2, a2=a2, out_f32=True, tile=tile, split_k=split)
+    assert rel_l2(out, torch.cat([a1, a2], 1).float() @ w2.float().T) < TOL_F32
+
+
 def test_gemm_batched_f32(ops):
     B, M, N, K = 3, 256, 192, 512
     a, w = rnd(B, M, K, seed=1), rnd(B, N, K, seed=2)

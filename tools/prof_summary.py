@@ -1,0 +1,46 @@
+"""Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel count, total/avg time, share.
+    python tools/prof_summary.py gpurun_out/prof_xxx/name_results.db [--steps N] > profiles/xxx.md
+Template arguments of the gemm kernels are decoded into readable tile names."""
+import re
+import sqlite3
+import sys
+
+
+def short(name: str) -> str:
+    m = re.search(r"gemm2_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", name)
+    if m:
+        bm, bn, wm, wn, st, mode = m.groups()
+        return f"gemm2<{bm}x{bn},{wm}x{wn}w,{st}st,{('plain','tmix','conv3')[int(mode)]}>"
+    m = re.search(r"gemm_kernel<(\d+), (\d+), (\d+)>", name)
+    if m:
+        bm, bn, mode = m.groups()
+        return f"gemm1<{bm}x{bn},{('plain','tmix','conv3')[int(mode)]}>"
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"\(.*", "", name)
+    return name[:90]
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else None
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+    rows = cur.execute(f"select {name_col}, start, end from kernels").fetchall()
+    agg = {}
+    for name, s, e in rows:
+        k = short(name)
+        a = agg.setdefault(k, [0, 0.0])
+        a[0] += 1
+        a[1] += (e - s) / 1e3
+    total = sum(v[1] for v in agg.values())
+    print(f"| kernel | launches | total us | avg us | share |")
+    print(f"|---|---:|---:|---:|---:|")
+    for k, (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+        print(f"| `{k}` | {n} | {us:.0f} | {us / n:.2f} | {100 * us / total:.1f}% |")
+    print(f"\ntotal kernel time {total / 1e3:.2f} ms over {sum(v[0] for v in agg.values())} launches" +
+          (f"; {total / 1e3 / steps:.3f} ms per step over {steps} steps (all kernels incl. warm-up/autotune)" if steps else ""))
+
+
+if __name__ == "__main__":
+    main()

@@ -238,7 +238,7 @@ def gemm(
 
 
 def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, alpha: float = 1.0, out_f32: bool = False,
-                 tile: int = 0) -> torch.Tensor:
+                 bias: Optional[torch.Tensor] = None, tile: int = 0) -> torch.Tensor:
     """out[b] = alpha * a[b] . w[b]^T for 3-D a [B, M, K], w [B, N, K] (VAE mid-block attention)."""
     _req(a, BF16, "a")
     _req(w, BF16, "w")
@@ -251,6 +251,9 @@ def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, alpha: float = 1.0, out_f3
     d.lda, d.ldw, d.ldc = a.stride(1), w.stride(1), out.stride(1)
     d.alpha, d.mode, d.flags, d.batch, d.tile = alpha, PLAIN, (OUT_F32 if out_f32 else 0), B, tile
     d.batch_stride_a, d.batch_stride_w, d.batch_stride_out = a.stride(0), w.stride(0), out.stride(0)
+    if bias is not None:
+        _req(bias, F32, "bias")
+        d.bias = _p(bias)
     if tile == 0:
         def _launch(t):
             d.tile = t

@@ -112,11 +112,18 @@ class PNDMScheduler(_Base):
 
     ring_slots = 4
 
-    def __init__(self, skip_prk_steps=True, **kw):
+    def __init__(self, skip_prk_steps=True, cur_sample_aliases_latents: bool = True, **kw):
+        """cur_sample_aliases_latents (default True = what the reference pipeline actually computes): diffusers'
+        step_plms keeps `self.cur_sample = sample` WITHOUT cloning, and the reference passes a view,
+        `video_latents[:, :, 1:]`, then writes the result back into that same storage
+        (pipeline_audio_cond_animation.py:364; `.contiguous()` on :365 is a no-op).  The sample "restored" at the
+        repeated second timestep is therefore the already-updated latents x1, not x0.  False gives textbook PLMS
+        (what diffusers does when the caller rebinds `latents = step(...).prev_sample`)."""
         super().__init__(**kw)
         if not skip_prk_steps:
             raise NotImplementedError("PRK warm-up steps (skip_prk_steps=False)")
         self.config["skip_prk_steps"] = True
+        self.cur_sample_aliases_latents = cur_sample_aliases_latents
 
     def set_timesteps(self, num_inference_steps: int, device=None):
         self.num_inference_steps = num_inference_steps
@@ -149,10 +156,11 @@ class PNDMScheduler(_Base):
         if i == 1:
             prev, t = t, t + ratio
         ca, cb = self._coeffs(t, prev)
+        textbook = not self.cur_sample_aliases_latents
         if i == 0:
-            return StepPlan(ca, cb, w_cur=1.0, store_slot=0, save_sample=True)
+            return StepPlan(ca, cb, w_cur=1.0, store_slot=0, save_sample=textbook)
         if i == 1:
-            return StepPlan(ca, cb, w_cur=0.5, store_slot=-1, hist_idx=(0,), hist_w=(0.5,), use_saved_sample=True)
+            return StepPlan(ca, cb, w_cur=0.5, store_slot=-1, hist_idx=(0,), hist_w=(0.5,), use_saved_sample=textbook)
         n_app = i            # appended epsilons after this step's append: steps 0,2,3,... -> i of them (i >= 2)
         cur = (n_app - 1) % self.ring_slots
         s = lambda back: (n_app - 1 - back) % self.ring_slots  # noqa: E731
@@ -163,7 +171,8 @@ class PNDMScheduler(_Base):
         return StepPlan(ca, cb, 0.0, cur, (s(0), s(1), s(2), s(3)), (55 / 24, -59 / 24, 37 / 24, -9 / 24))
 
     # object protocol (tensor-level, any device) — the same arithmetic, used when the scheduler is driven
-    # through `.step()` by the reference-style loop
+    # through `.step()` by the reference-style loop.  Like diffusers it keeps `sample` itself (no clone), so a
+    # caller that passes a view and writes back in place gets the aliasing described in __init__.
     def step(self, model_output, timestep, sample, return_dict=True, **_):
         ratio = self.num_train_timesteps // self.num_inference_steps
         t = int(timestep)
@@ -198,4 +207,4 @@ class PNDMScheduler(_Base):
         p = os.path.join(path, subfolder) if subfolder else path
         with open(os.path.join(p, "scheduler_config.json")) as f:
             cfg = json.load(f)
-        return cls(**{k: v for k, v in cfg.items() if not k.startswith("_")})
+        return cls(**{k: v for k, v in cfg.items() if not k.startswith("_") and k != "trained_betas"})

@@ -1,0 +1,326 @@
+"""AutoencoderKL (decode side) — MI355X-native host mirror of the diffusers class the reference pipeline calls
+at avgen/pipelines/pipeline_audio_cond_animation.py:206-213 (`vae.decode(latents / scaling_factor).sample` over
+all b*f frames at once).  Same config keys and decoder-side state_dict names as diffusers 0.29.2's SD1.5
+`vae/` checkpoint; `.decode(z).sample`, `.config.scaling_factor`, `.config.block_out_channels`, `.dtype` are the
+members the pipeline touches.  The encoder half (image -> latent, once per clip, before the hot
+path) is out of scope for this round and raises.
+
+As in asva_amd.unet the modules are parameter holders; decode() drives the gfx950 kernels: implicit-GEMM 3x3
+convs (nearest-2x upsample folded into the conv's gather), GroupNorm+SiLU, and the single-head mid-block
+attention as two batched GEMMs around a row softmax (d = 512 is one big contraction, not a flash-tile case).
+Frames are processed in chunks sized so every activation stays below the 2 GiB / 32-bit-offset limit of the
+LDS-direct GEMM tiles.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from .unet import FrozenConfig, _Affine, _Conv, _Linear, _Pk, _Ref
+from .weights import pack_conv1x1, pack_conv3x3, pack_linear
+
+
+class DecoderOutput:
+    def __init__(self, sample):
+        self.sample = sample
+
+    def __getitem__(self, i):
+        return (self.sample,)[i]
+
+
+class _VaeRes(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.norm1 = _Affine(cin)
+        self.conv1 = _Conv(cin, cout, 3)
+        self.norm2 = _Affine(cout)
+        self.conv2 = _Conv(cout, cout, 3)
+        if cin != cout:
+            self.conv_shortcut = _Conv(cin, cout, 1)
+
+
+class _VaeAttn(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.group_norm = _Affine(c)
+        self.to_q = _Linear(c, c)
+        self.to_k = _Linear(c, c)
+        self.to_v = _Linear(c, c)
+        self.to_out = nn.ModuleList([_Linear(c, c)])
+
+
+class _VaeMid(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.attentions = nn.ModuleList([_VaeAttn(c)])
+        self.resnets = nn.ModuleList([_VaeRes(c, c), _VaeRes(c, c)])
+
+
+class _VaeUpsampler(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = _Conv(c, c, 3)
+
+
+class _VaeUp(nn.Module):
+    def __init__(self, cin, cout, n, up):
+        super().__init__()
+        self.resnets = nn.ModuleList([_VaeRes(cin if j == 0 else cout, cout) for j in range(n)])
+        if up:
+            self.upsamplers = nn.ModuleList([_VaeUpsampler(cout)])
+
+
+class _Decoder(nn.Module):
+    def __init__(self, latent, out, ch, layers):
+        super().__init__()
+        rch = list(ch)[::-1]
+        self.conv_in = _Conv(latent, rch[0], 3)
+        self.mid_block = _VaeMid(rch[0])
+        self.up_blocks = nn.ModuleList()
+        prev = rch[0]
+        for i, c in enumerate(rch):
+            self.up_blocks.append(_VaeUp(prev, c, layers + 1, i < len(rch) - 1))
+            prev = c
+        self.conv_norm_out = _Affine(rch[-1])
+        self.conv_out = _Conv(rch[-1], out, 3)
+
+
+# older diffusers checkpoints name the mid-block attention projections differently
+_LEGACY_ATTN = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+
+
+class AutoencoderKL(nn.Module):
+    def __init__(self, in_channels=3, out_channels=3, down_block_types=("DownEncoderBlock2D",) * 4,
+                 up_block_types=("UpDecoderBlock2D",) * 4, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
+                 act_fn="silu", latent_channels=4, norm_num_groups=32, sample_size=512, scaling_factor=0.18215,
+                 force_upcast=True, **_):
+        super().__init__()
+        if act_fn != "silu" or any(t != "UpDecoderBlock2D" for t in up_block_types):
+            raise NotImplementedError("AutoencoderKL (MI355X path): SD1.5 decoder architecture only")
+        self._config = FrozenConfig(in_channels=in_channels, out_channels=out_channels, down_block_types=tuple(down_block_types),
+                                    up_block_types=tuple(up_block_types), block_out_channels=tuple(block_out_channels),
+                                    layers_per_block=layers_per_block, act_fn=act_fn, latent_channels=latent_channels,
+                                    norm_num_groups=norm_num_groups, sample_size=sample_size, scaling_factor=scaling_factor,
+                                    force_upcast=force_upcast)
+        self.post_quant_conv = _Conv(latent_channels, latent_channels, 1)
+        self.decoder = _Decoder(latent_channels, out_channels, block_out_channels, layers_per_block)
+        self._packed = None
+
+    @property
+    def config(self):
+        return self._config
+
+    @property
+    def dtype(self):
+        return next(self.parameters()).dtype
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @classmethod
+    def from_config(cls, config, **kw):
+        args = {k: v for k, v in dict(config).items() if not k.startswith("_")}
+        args.update(kw)
+        return cls(**args)
+
+    @classmethod
+    def from_pretrained(cls, path: str, subfolder: Optional[str] = None, **_):
+        p = os.path.join(path, subfolder) if subfolder else path
+        with open(os.path.join(p, "config.json")) as f:
+            model = cls.from_config(json.load(f))
+        st = os.path.join(p, "diffusion_pytorch_model.safetensors")
+        if os.path.isfile(st):
+            from safetensors.torch import load_file
+
+            sd = load_file(st)
+        else:
+            sd = torch.load(os.path.join(p, "diffusion_pytorch_model.bin"), map_location="cpu", weights_only=True)
+        model.load_state_dict(sd)
+        return model.eval()
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        """Accepts a full AutoencoderKL checkpoint: encoder.* / quant_conv.* are ignored (decode-only), legacy
+        attention names are mapped, legacy [C, C, 1, 1] attention weights are squeezed."""
+        sd = {}
+        for k, v in state_dict.items():
+            if k.startswith("encoder.") or k.startswith("quant_conv."):
+                continue
+            parts = k.split(".")
+            if "attentions" in parts:
+                for old, new in _LEGACY_ATTN.items():
+                    if parts[-2] == old:
+                        k = ".".join(parts[:-2] + [new, parts[-1]])
+                if k.endswith("weight") and v.dim() == 4 and "group_norm" not in k:
+                    v = v.reshape(v.shape[0], v.shape[1])
+            sd[k] = v
+        r = super().load_state_dict(sd, strict=strict, **kw)
+        self._packed = None
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._packed = None
+        return r
+
+    def encode(self, *a, **k):
+        raise NotImplementedError("VAE encode (image -> latent, once per clip before the denoising path) is the "
+                                  "'next' row of SURVEY.md §8f; feed image latents directly")
+
+    # ---- packing -----------------------------------------------------------------------------------------------
+    def pack(self, device=None):
+        if device is not None:
+            device = torch.device(device)
+            if device.type == "cuda" and device.index is None:
+                device = torch.device("cuda", torch.cuda.current_device())
+        if self._packed is not None and (device is None or self._packed.blob.device == device):
+            return self._packed
+        device = device if device is not None else self.device
+        if device.type != "cuda" and not getattr(ops, "EMULATED", False):
+            raise RuntimeError("AutoencoderKL.pack: the MI355X path needs a cuda (HIP) device — there is no CPU compute path")
+        items = []
+
+        def reg(t):
+            items.append(t.contiguous())
+            return _Ref(len(items) - 1)
+
+        def aff(m):
+            return _Pk(g=reg(m.weight.detach().float()), b=reg(m.bias.detach().float()))
+
+        def conv3(m):
+            cout, cin = m.weight.shape[:2]
+            cop, cip = (cout + 3) // 4 * 4, (cin + 7) // 8 * 8
+            b = torch.zeros(cop, device=m.weight.device)
+            b[:cout] = m.bias.detach().float()
+            return _Pk(w=reg(pack_conv3x3(m.weight.detach().float(), cip, cop)), b=reg(b), cout=cop)
+
+        def conv1(m):
+            cout, cin = m.weight.shape[:2]
+            cop, cip = (cout + 7) // 8 * 8, (cin + 7) // 8 * 8
+            w = torch.zeros(cop, cip, dtype=torch.bfloat16, device=m.weight.device)
+            w[:cout, :cin] = pack_conv1x1(m.weight.detach().float())
+            b = torch.zeros(cop, device=m.weight.device)
+            b[:cout] = m.bias.detach().float()
+            return _Pk(w=reg(w), b=reg(b))
+
+        def res(m):
+            return _Pk(norm1=aff(m.norm1), conv1=conv3(m.conv1), norm2=aff(m.norm2), conv2=conv3(m.conv2),
+                       shortcut=conv1(m.conv_shortcut) if hasattr(m, "conv_shortcut") else None)
+
+        d = self.decoder
+        at = d.mid_block.attentions[0]
+        pk = _Pk(pq=conv1(self.post_quant_conv), conv_in=conv3(d.conv_in),
+                 mid=[res(d.mid_block.resnets[0]), res(d.mid_block.resnets[1])],
+                 attn=_Pk(norm=aff(at.group_norm),
+                          wqk=reg(pack_linear(torch.cat([at.to_q.weight, at.to_k.weight], 0).float())),
+                          bqk=reg(torch.cat([at.to_q.bias, at.to_k.bias], 0).detach().float()),
+                          wv=reg(pack_linear(at.to_v.weight.float())), bv=reg(at.to_v.bias.detach().float()),
+                          wo=reg(pack_linear(at.to_out[0].weight.float())), bo=reg(at.to_out[0].bias.detach().float()),
+                          dim=at.to_q.weight.shape[0]),
+                 up=[_Pk(resnets=[res(r) for r in u.resnets],
+                         up=conv3(u.upsamplers[0].conv) if hasattr(u, "upsamplers") else None) for u in d.up_blocks],
+                 norm_out=aff(d.conv_norm_out), conv_out=conv3(d.conv_out))
+        offs, total = [], 0
+        for t in items:
+            offs.append(total)
+            total += (t.numel() * t.element_size() + 255) // 256 * 256
+        blob = torch.zeros(total, dtype=torch.uint8, device=device)
+        views = []
+        for t, o in zip(items, offs):
+            nb = t.numel() * t.element_size()
+            if not t.is_meta:
+                blob[o:o + nb].copy_(t.reshape(-1).view(torch.uint8))
+            views.append(blob[o:o + nb].view(t.dtype).view(t.shape))
+
+        def resolve(obj):
+            if isinstance(obj, _Pk):
+                for k, v in list(obj.__dict__.items()):
+                    if isinstance(v, _Ref):
+                        obj.__dict__[k] = views[v.idx]
+                    else:
+                        resolve(v)
+            elif isinstance(obj, list):
+                for v in obj:
+                    resolve(v)
+
+        resolve(pk)
+        pk.blob = blob
+        self._packed = pk
+        return pk
+
+    # ---- decode ----------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor, return_dict: bool = True, frames_per_chunk: Optional[int] = None,
+               postprocess: bool = False):
+        """z: (N, 4, h, w) latents already divided by scaling_factor -> DecoderOutput(sample (N, 3, 8h, 8w) f32).
+        postprocess=True additionally applies the pipeline's (x / 2 + 0.5).clamp(0, 1) in the output kernel."""
+        pk = self.pack()
+        dev = pk.blob.device
+        N, _, h, w = z.shape
+        up = 2 ** (len(self.config.block_out_channels) - 1)
+        if frames_per_chunk is None:
+            # largest activation: rows x 256 ch bf16 at full resolution (+ the mid attention scores, f32 HW x HW)
+            per_frame = max((h * up) * (w * up) * 256 * 2, (h * w) ** 2 * 4)
+            frames_per_chunk = max(1, min(N, int((2 ** 31 - 1) // per_frame)))
+        outs = []
+        z32 = z.to(device=dev, dtype=torch.float32).contiguous()
+        for i in range(0, N, frames_per_chunk):
+            outs.append(self._decode_rows(pk, z32[i:i + frames_per_chunk], postprocess))
+        img = torch.cat(outs, 0) if len(outs) > 1 else outs[0]
+        if not return_dict:
+            return (img,)
+        return DecoderOutput(img)
+
+    def decode_to_video(self, latents: torch.Tensor) -> torch.Tensor:
+        """(b, 4, f, h, w) denoised latents -> (b, f, 3, H, W) f32 in [0, 1]: the whole post-processing of
+        pipeline_audio_cond_animation.py:368-370 + :207-212 (1/scaling_factor, decode, x/2+0.5, clamp)."""
+        b, c, f, h, w = latents.shape
+        z = latents.to(torch.float32).permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w) / self.config.scaling_factor
+        img = self.decode(z, postprocess=True).sample
+        return img.reshape(b, f, *img.shape[1:])
+
+    def _res(self, x, p, n, hw, groups):
+        L = hw[0] * hw[1]
+        a = ops.groupnorm(x, None, n, L, groups, p.norm1.g, p.norm1.b, 1e-6, True)
+        h = ops.gemm(a, p.conv1.w, bias=p.conv1.b, mode=ops.CONV3, conv=(n, hw[0], hw[1], 1, 0))
+        a = ops.groupnorm(h, None, n, L, groups, p.norm2.g, p.norm2.b, 1e-6, True)
+        s = x if p.shortcut is None else ops.gemm(x, p.shortcut.w, bias=p.shortcut.b)
+        return ops.gemm(a, p.conv2.w, bias=p.conv2.b, res1=s, mode=ops.CONV3, conv=(n, hw[0], hw[1], 1, 0))
+
+    def _decode_rows(self, pk, z32, postprocess=False):
+        n, c, h, w = z32.shape
+        groups = self.config.norm_num_groups
+        x = ops.ncfhw_to_rows(z32.reshape(n, c, 1, h, w), cpad=8)
+        x = ops.gemm(x, pk.pq.w, bias=pk.pq.b)                                            # post_quant_conv 1x1
+        hw = (h, w)
+        x = ops.gemm(x, pk.conv_in.w, bias=pk.conv_in.b, mode=ops.CONV3, conv=(n, h, w, 1, 0))
+        x = self._res(x, pk.mid[0], n, hw, groups)
+        # mid-block attention, one head of width C: S = QK^T/sqrt(C) (f32) -> softmax -> P V ; V^T comes straight
+        # out of a GEMM with the roles swapped, and V's bias is added after P.V (softmax rows sum to 1)
+        a = pk.attn
+        C, L = a.dim, h * w
+        xn = ops.groupnorm(x, None, n, L, groups, a.norm.g, a.norm.b, 1e-6, False)
+        qk = ops.gemm(xn, a.wqk, bias=a.bqk).view(n, L, 2 * C)
+        s = ops.gemm_batched(qk[:, :, :C], qk[:, :, C:], alpha=float(C) ** -0.5, out_f32=True)      # [n, L, L]
+        p = ops.softmax_rows(s.view(n * L, L)).view(n, L, L)
+        vt = ops.gemm_batched(a.wv.unsqueeze(0).expand(n, C, C), xn.view(n, L, C))                  # [n, C, L] = V^T
+        o = ops.gemm_batched(p, vt, bias=a.bv).view(n * L, C)
+        x = ops.gemm(o, a.wo, bias=a.bo, res1=x)
+        x = self._res(x, pk.mid[1], n, hw, groups)
+        for u in pk.up:
+            for r in u.resnets:
+                x = self._res(x, r, n, hw, groups)
+            if u.up is not None:
+                x = ops.gemm(x, u.up.w, bias=u.up.b, mode=ops.CONV3, conv=(n, hw[0], hw[1], 1, 1))
+                hw = (hw[0] * 2, hw[1] * 2)
+        a = ops.groupnorm(x, None, n, hw[0] * hw[1], groups, pk.norm_out.g, pk.norm_out.b, 1e-6, True)
+        if postprocess:
+            y = ops.gemm(a, pk.conv_out.w, bias=pk.conv_out.b, mode=ops.CONV3, conv=(n, hw[0], hw[1], 1, 0))
+            return ops.vae_postprocess(y, n, hw[0], hw[1])
+        y = ops.gemm(a, pk.conv_out.w, bias=pk.conv_out.b, out_f32=True, mode=ops.CONV3, conv=(n, hw[0], hw[1], 1, 0))
+        return ops.rows_to_ncfhw(y, n, self.config.out_channels, 1, hw[0], hw[1]).reshape(n, self.config.out_channels, hw[0], hw[1])

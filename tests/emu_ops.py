@@ -57,8 +57,10 @@ def gemm(a, w, *, n=None, k=None, a2=None, bias=None, rowvec=None, rows_per_vec=
     return v if out_f32 else v.to(BF16)
 
 
-def gemm_batched(a, w, *, alpha=1.0, out_f32=False, tile=0):
+def gemm_batched(a, w, *, alpha=1.0, out_f32=False, bias=None, tile=0):
     v = alpha * torch.einsum("bmk,bnk->bmn", a.float(), w.float())
+    if bias is not None:
+        v = v + bias
     return v if out_f32 else v.to(BF16)
 
 

@@ -1,0 +1,261 @@
+"""Pins the oracle (-m "not gpu").
+
+1. oracle/unet_ref.py == the REFERENCE's own UNet code: golden vectors in tests/golden were produced by importing
+   /root/reference/avgen/models/unets (oracle/gen_golden.py) with the closed-form filler weights; the restatement
+   must reproduce them to fp32 round-off.
+2. The third-party (diffusers) arithmetic has no reference-side vectors ("parity unpinned"): it is pinned against
+   torch built-ins and closed-form known answers.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import sched_ref, unet_ref, vae_ref
+from oracle.filler import fill_state_dict, fill_tensor
+from tests.helpers import load_golden, load_shapes, rel_l2
+
+TOL = 2e-5
+
+
+def _sd(prefix, shapes):
+    return {k: fill_tensor(prefix + k, v) for k, v in shapes.items()}
+
+
+# ---- 1. against the reference's golden vectors ------------------------------------------------------------------
+def test_unet_forward_matches_reference_golden():
+    g = load_golden("unet_tiny_e2e.pt")
+    sd = fill_state_dict(load_shapes("unet_tiny_state_dict_shapes.json"))
+    B, Fr = g["sample"].shape[0], g["sample"].shape[2]
+    text = g["text"][:, None].expand(B, Fr, *g["text"].shape[1:])
+    audio = g["audio"][:, None].expand(B, Fr, *g["audio"].shape[1:])
+    mask = g["mask"][None].expand(B, -1, -1)
+    for t, ref in zip(g["timesteps"], g["out"]):
+        out = unet_ref.unet_forward(sd, g["config"], g["sample"], t, text, audio, mask)
+        assert rel_l2(out, ref) < TOL
+
+
+def test_ops_match_reference_goldens():
+    g = load_golden("unet_ops.pt")
+    for name in ("conv3_s1", "conv3_s2", "conv1"):
+        cin, cout, k, s, p = g[name]["args"]
+        sd = _sd(name + ".", {"weight": (cout, cin, k, k), "bias": (cout,), "conv_temp.weight": (cout, 3 * cout), "conv_temp.bias": (cout,)})
+        sd = {name + "." + kk: v for kk, v in sd.items()}
+        y = unet_ref.ff_inflated_conv3d(g[name]["x"], sd, name, stride=s, padding=p)
+        assert rel_l2(y, g[name]["y"]) < TOL, name
+    for name, (cin, cout) in {"res_same": (32, 32), "res_short": (48, 32)}.items():
+        shapes = {"norm1.weight": (cin,), "norm1.bias": (cin,), "conv1.weight": (cout, cin, 3, 3), "conv1.bias": (cout,),
+                  "conv1.conv_temp.weight": (cout, 3 * cout), "conv1.conv_temp.bias": (cout,),
+                  "time_emb_proj.weight": (cout, 64), "time_emb_proj.bias": (cout,),
+                  "norm2.weight": (cout,), "norm2.bias": (cout,), "conv2.weight": (cout, cout, 3, 3), "conv2.bias": (cout,),
+                  "conv2.conv_temp.weight": (cout, 3 * cout), "conv2.conv_temp.bias": (cout,)}
+        if cin != cout:
+            shapes.update({"conv_shortcut.weight": (cout, cin, 1, 1), "conv_shortcut.bias": (cout,),
+                           "conv_shortcut.conv_temp.weight": (cout, 3 * cout), "conv_shortcut.conv_temp.bias": (cout,)})
+        sd = {name + "." + kk: v for kk, v in _sd(name + ".", shapes).items()}
+        y = unet_ref.resnet_block(g[name]["x"], g[name]["temb"], sd, name, g[name]["groups"], g[name]["eps"])
+        assert rel_l2(y, g[name]["y"]) < TOL, name
+    # samplers: stride-2 conv; nearest x(1,2,2) then conv
+    for name in ("down", "up"):
+        sd = {f"{name}.conv." + kk: v for kk, v in _sd(f"{name}.conv.", {"weight": (16, 16, 3, 3), "bias": (16,), "conv_temp.weight": (16, 48),
+                                                                        "conv_temp.bias": (16,)}).items()}
+        x = g[name]["x"]
+        if name == "up":
+            x = F.interpolate(x, scale_factor=(1.0, 2.0, 2.0), mode="nearest")
+        y = unet_ref.ff_inflated_conv3d(x, sd, f"{name}.conv", stride=2 if name == "down" else 1)
+        assert rel_l2(y, g[name]["y"]) < TOL, name
+    # first-frame attention (FFAttnProcessor)
+    a = g["ffattn"]
+    sd = {"ffattn." + kk: v for kk, v in _sd("ffattn.", {"to_q.weight": (32, 32), "to_k.weight": (32, 32), "to_v.weight": (32, 32),
+                                                       "to_out.0.weight": (32, 32), "to_out.0.bias": (32,)}).items()}
+    x = a["x"]
+    Fr = a["frames"]
+    ctx = x.reshape(-1, Fr, *x.shape[1:])[:, :1].expand(-1, Fr, -1, -1).reshape(x.shape)
+    assert rel_l2(unet_ref.attention(x, ctx, sd, "ffattn", a["heads"]), a["y"]) < TOL
+    # whole transformer wrapper + block
+    t = g["transformer3d"]
+    C, Dt, Da = 32, 24, 40
+    p = "tr.transformer_blocks.0."
+    shapes = {"norm.weight": (C,), "norm.bias": (C,), "proj_in.weight": (C, C, 1, 1), "proj_in.bias": (C,),
+              "proj_out.weight": (C, C, 1, 1), "proj_out.bias": (C,)}
+    blk = {}
+    for n in ("norm1", "norm_audio", "norm2", "norm_temp", "norm3"):
+        blk[n + ".weight"] = (C,)
+        blk[n + ".bias"] = (C,)
+    for n, ctxd in (("attn1", C), ("attn_audio", Da), ("attn2", Dt), ("attn_temp", C)):
+        blk.update({f"{n}.to_q.weight": (C, C), f"{n}.to_k.weight": (C, ctxd), f"{n}.to_v.weight": (C, ctxd),
+                    f"{n}.to_out.0.weight": (C, C), f"{n}.to_out.0.bias": (C,)})
+    blk.update({"pos_embedding_temp.linear_1.weight": (C, C), "pos_embedding_temp.linear_1.bias": (C,),
+                "pos_embedding_temp.linear_2.weight": (C, C), "pos_embedding_temp.linear_2.bias": (C,),
+                "ff.net.0.proj.weight": (8 * C, C), "ff.net.0.proj.bias": (8 * C,), "ff.net.2.weight": (C, 4 * C), "ff.net.2.bias": (C,)})
+    shapes.update({"transformer_blocks.0." + k: v for k, v in blk.items()})
+    sd = {"tr." + kk: fill_tensor("tr." + kk, v) for kk, v in shapes.items()}
+    y = unet_ref.transformer_3d(t["x"], t["text"], t["audio"], t["mask"], sd, "tr", t["heads"], t["groups"])
+    assert rel_l2(y, t["y"]) < TOL
+
+
+# ---- 2. third-party primitives: torch built-ins and known answers ------------------------------------------------
+def test_timestep_embedding_known_answers():
+    e = unet_ref.sinusoidal_embedding(torch.tensor([0, 1, 981]), 320)
+    assert torch.equal(e[0], torch.cat([torch.ones(160), torch.zeros(160)]))          # cos 0 | sin 0 (flip_sin_to_cos)
+    assert math.isclose(e[1, 0].item(), math.cos(1.0), rel_tol=1e-6) and math.isclose(e[1, 160].item(), math.sin(1.0), rel_tol=1e-6)
+    w159 = math.exp(-math.log(10000.0) * 159 / 160)
+    assert math.isclose(e[2, 159].item(), math.cos(981 * w159), rel_tol=1e-4)
+
+
+def test_attention_is_softmax_qk_v_with_bool_mask():
+    g = torch.Generator().manual_seed(0)
+    C, heads = 16, 2
+    sd = {"a.to_q.weight": torch.randn(C, C, generator=g), "a.to_k.weight": torch.randn(C, 12, generator=g),
+          "a.to_v.weight": torch.randn(C, 12, generator=g), "a.to_out.0.weight": torch.randn(C, C, generator=g),
+          "a.to_out.0.bias": torch.randn(C, generator=g)}
+    x, ctx = torch.randn(3, 5, C, generator=g), torch.randn(3, 7, 12, generator=g)
+    mask = torch.tensor([1, 0, 1, 1, 0, 0, 1], dtype=torch.bool)
+    out = unet_ref.attention(x, ctx, sd, "a", heads, mask[None, None, None, :])
+    q = (x @ sd["a.to_q.weight"].T).reshape(3, 5, heads, 8).transpose(1, 2)
+    k = (ctx @ sd["a.to_k.weight"].T).reshape(3, 7, heads, 8).transpose(1, 2)
+    v = (ctx @ sd["a.to_v.weight"].T).reshape(3, 7, heads, 8).transpose(1, 2)
+    s = q @ k.transpose(-1, -2) / math.sqrt(8)
+    s = s.masked_fill(~mask, float("-inf"))
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(3, 5, C) @ sd["a.to_out.0.weight"].T + sd["a.to_out.0.bias"]
+    assert rel_l2(out, ref) < 1e-5
+    # masked keys carry exactly zero weight == gathering the visible keys
+    out_g = unet_ref.attention(x, ctx[:, mask], sd, "a", heads)
+    assert rel_l2(out_g, out) < 1e-6
+
+
+def test_pndm_known_answers():
+    s = sched_ref.RefPNDM()
+    s.set_timesteps(50)
+    ts = s.timesteps.tolist()
+    assert len(ts) == 51 and ts[:4] == [981, 961, 961, 941] and ts[-1] == 1
+    acp = s.acp
+    assert math.isclose(acp[0].item(), 1 - 0.00085, rel_tol=1e-6)
+    assert math.isclose(acp[999].item(), 0.0046604, rel_tol=2e-3)                     # SD1.5 alpha-bar_T
+    # first step from x, eps: x' = sqrt(a'/a) x - (a'-a) eps / (a sqrt(1-a') + sqrt(a(1-a)a'))
+    x, e = torch.tensor([0.7]), torch.tensor([-0.3])
+    a, ap = acp[981].item(), acp[961].item()
+    want = math.sqrt(ap / a) * 0.7 - (ap - a) * (-0.3) / (a * math.sqrt(1 - ap) + math.sqrt(a * (1 - a) * ap))
+    assert math.isclose(s.step(e, 981, x).item(), want, rel_tol=1e-6)
+
+
+def test_ddim_known_answers():
+    s = sched_ref.RefDDIM()
+    s.set_timesteps(25)
+    ts = s.timesteps.tolist()
+    assert len(ts) == 25 and ts[0] == 961 and ts[1] == 921 and ts[-1] == 1
+    x, e = torch.tensor([0.2]), torch.tensor([1.1])
+    a, ap = s.acp[961].item(), s.acp[921].item()
+    x0 = (0.2 - math.sqrt(1 - a) * 1.1) / math.sqrt(a)
+    assert math.isclose(s.step(e, 961, x).item(), math.sqrt(ap) * x0 + math.sqrt(1 - ap) * 1.1, rel_tol=1e-4, abs_tol=1e-5)
+    # exact eps => exact recovery of a clean sample in one jump to t_prev < 0 (final alpha-bar = alpha-bar_0)
+    s2 = sched_ref.RefDDIM()
+    s2.set_timesteps(1000)
+    clean, noise = torch.tensor([0.5]), torch.tensor([0.8])
+    a1 = s2.acp[1].item()
+    noisy = math.sqrt(a1) * clean + math.sqrt(1 - a1) * noise
+    out = s2.step(noise, 1, noisy)
+    a0 = s2.acp[0].item()
+    assert math.isclose(out.item(), math.sqrt(a0) * 0.5 + math.sqrt(1 - a0) * 0.8, rel_tol=1e-5)
+
+
+@pytest.mark.parametrize("kind,steps,aliased", [("pndm", 50, True), ("pndm", 25, True), ("pndm", 7, True), ("pndm", 50, False),
+                                                ("ddim", 50, True), ("ddim", 25, True)])
+def test_product_scheduler_matches_oracle(kind, steps, aliased):
+    """asva_amd.schedulers: (a) the object protocol (.step) and (b) the planned-coefficient form that feeds
+    avsd_guided_step (emulated here) both reproduce the oracle scheduler on a random eps sequence.
+
+    aliased=True drives the oracle exactly as the reference pipeline does (:364): a VIEW of the latents goes in and
+    the result is written back into the same storage, so PNDM's un-cloned `cur_sample` follows the update.
+    aliased=False rebinds fresh tensors (textbook PLMS)."""
+    from asva_amd.schedulers import DDIMScheduler, PNDMScheduler
+    from tests import emu_ops
+
+    ref = sched_ref.RefPNDM() if kind == "pndm" else sched_ref.RefDDIM()
+    mk = (lambda: PNDMScheduler(cur_sample_aliases_latents=aliased)) if kind == "pndm" else DDIMScheduler
+    prod, obj = mk(), mk()
+    ref.set_timesteps(steps)
+    prod.set_timesteps(steps)
+    obj.set_timesteps(steps)
+    assert prod.timesteps.tolist() == ref.timesteps.tolist()
+    g = torch.Generator().manual_seed(1)
+    shape = (1, 4, 3, 4, 4)
+    x_ref = torch.randn(shape, generator=g)
+    x_obj = x_ref.clone()
+    x_prod = x_ref.clone()
+    hist = torch.zeros((4,) + shape)
+    saved = torch.zeros(shape)
+    frame0 = x_ref[:, :, 0].clone()
+    for i, t in enumerate(ref.timesteps):
+        eps = torch.randn(shape, generator=g)
+        # the pipeline steps frames 1.. only; frame 0 is the pinned image latent (pipeline :364)
+        if aliased:
+            x_ref[:, :, 1:] = ref.step(eps[:, :, 1:], t, x_ref[:, :, 1:])
+            x_obj[:, :, 1:] = obj.step(eps[:, :, 1:], t, x_obj[:, :, 1:]).prev_sample
+        else:
+            x_ref = torch.cat([x_ref[:, :, :1], ref.step(eps[:, :, 1:], t, x_ref[:, :, 1:].clone())], 2)
+            x_obj = torch.cat([x_obj[:, :, :1], obj.step(eps[:, :, 1:], t, x_obj[:, :, 1:].clone()).prev_sample], 2)
+        p = prod.plan_step(i)
+        if p.save_sample:
+            saved.copy_(x_prod)
+        emu_ops.guided_step(eps, 1, 1.0, saved if p.use_saved_sample else x_prod, x_prod, p.ca, p.cb, eps_hist=hist,
+                            store_slot=p.store_slot, w_cur=p.w_cur, hist_idx=p.hist_idx, w=p.hist_w)
+        assert rel_l2(x_obj, x_ref) < 1e-5, (i, int(t))
+        assert rel_l2(x_prod, x_ref) < 1e-5, (i, int(t))
+        assert torch.equal(x_prod[:, :, 0], frame0)
+
+
+def test_reference_pipeline_aliases_plms_cur_sample():
+    """Documents the quirk: driven the reference's way, the sample PLMS restores at the repeated timestep is the
+    already-updated latents, and that is NOT textbook PLMS."""
+    outs = {}
+    for aliased in (True, False):
+        s = sched_ref.RefPNDM()
+        s.set_timesteps(10)
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(1, 4, 3, 2, 2, generator=g)
+        for t in s.timesteps[:2]:
+            e = torch.randn(1, 4, 2, 2, 2, generator=g)
+            if aliased:
+                x[:, :, 1:] = s.step(e, t, x[:, :, 1:])
+            else:
+                x = torch.cat([x[:, :, :1], s.step(e, t, x[:, :, 1:].clone())], 2)
+        outs[aliased] = x
+    assert rel_l2(outs[True], outs[False]) > 1e-2
+
+
+def test_audio_segment_mask_contract():
+    """segmask_imagebind.py:62-78,104-114: CLS + 12 frequency rows x ceil(19/f) time columns."""
+    from asva_amd.conditioning import audio_segment_mask, mask_to_key_index
+
+    m = audio_segment_mask(12)
+    assert m.shape == (12, 229) and m[:, 0].all() and (m.sum(1) == 25).all()
+    grid = m[:, 1:].reshape(12, 12, 19)
+    assert (grid == grid[:, :1]).all()                                     # same time window for every frequency row
+    starts = [int(torch.nonzero(grid[s, 0])[0]) for s in range(12)]
+    assert starts == [0, 2, 3, 5, 6, 8, 9, 11, 12, 14, 15, 17]              # round(linspace(0, 17, 12)), half-to-even
+    assert (audio_segment_mask(24).sum(1) == 13).all()
+    idx = mask_to_key_index(m)
+    assert idx.shape == (12, 25) and idx.dtype == torch.int32 and (idx[:, 0] == 0).all()
+    with pytest.raises(ValueError):
+        mask_to_key_index(torch.tensor([[True, False], [True, True]]))
+
+
+def test_vae_decoder_primitives():
+    cfg = dict(vae_ref.SD15_VAE_CONFIG, block_out_channels=(32, 64, 64, 64))
+    sd = fill_state_dict(vae_ref.decoder_shapes(cfg))
+    z = torch.randn(2, 4, 4, 4, generator=torch.Generator().manual_seed(0))
+    y = vae_ref.vae_decode(sd, cfg, z)
+    assert y.shape == (2, 3, 32, 32) and torch.isfinite(y).all()
+    # frames are independent (the pipeline decodes b*f frames in one call)
+    assert rel_l2(vae_ref.vae_decode(sd, cfg, z[1:]), y[1:]) < 1e-5
+    # mid attention == explicit single-head softmax attention over the h*w tokens
+    p = "decoder.mid_block.attentions.0"
+    x = torch.randn(1, 64, 4, 4, generator=torch.Generator().manual_seed(1))
+    h = F.group_norm(x, 32, sd[p + ".group_norm.weight"], sd[p + ".group_norm.bias"], 1e-6).reshape(1, 64, 16).transpose(1, 2)
+    q, k, v = (h @ sd[p + f".to_{n}.weight"].T + sd[p + f".to_{n}.bias"] for n in "qkv")
+    o = torch.softmax(q @ k.transpose(1, 2) / 8.0, -1) @ v
+    o = o @ sd[p + ".to_out.0.weight"].T + sd[p + ".to_out.0.bias"]
+    ref = x + o.transpose(1, 2).reshape(1, 64, 4, 4)
+    assert rel_l2(vae_ref.mid_attention(x, sd, p, 32), ref) < 1e-5

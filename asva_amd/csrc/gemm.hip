@@ -803,6 +803,12 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
     const bool big = a_rows * d.lda * 2.0 >= 2147483648.0 || (double)d.N * d.ldw * 2.0 >= 2147483648.0 ||
                      (d.A2 && (double)d.M * d.lda2 * 2.0 >= 2147483648.0);
     if (big && (tile < 1 || tile > 3)) tile = (d.N > 64 && d.M > 2048) ? 1 : 3;
+    // the LDS-direct loader picks the source buffer (A or A2) per 64-wide K tile: a split point inside a tile
+    // needs the per-vector select of the register-staged kernel
+    if (d.mode == AVSD_GEMM_PLAIN && d.A2 && d.k_split % 64 != 0 && (tile < 1 || tile > 3)) {
+      AVSD_REQUIRE(d.split_k <= 1, "gemm: split_k with a two-source A needs k_split %% 64 == 0 (got %d)", d.k_split);
+      tile = (d.N > 64 && d.M > 2048) ? 2 : 3;
+    }
   }
   if (tile < 1 || tile > 10) tile = pick_tile(d.M, (d.flags & AVSD_GEMM_GEGLU) ? d.N : d.N, d.batch);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

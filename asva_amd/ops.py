@@ -224,7 +224,8 @@ def gemm(
 
         cands = TILE_CANDIDATES
         nk = (K + 63) // 64
-        if not geglu and ((M + 127) // 128) * ((N + 127) // 128) < 256 and nk >= 16:
+        two_src_unaligned = a2 is not None and (a.shape[1] % 64 != 0)     # C falls back to register-staged tiles
+        if not geglu and not two_src_unaligned and ((M + 127) // 128) * ((N + 127) // 128) < 256 and nk >= 16:
             cands = cands + tuple(c for c in SPLITK_CANDIDATES if nk // c[1] >= 4)
         tile, split_k = _pick_tile((mode, M, N, K, d.flags, d.stride, d.ups), _launch, cands)
     _set(tile, split_k)

@@ -94,8 +94,8 @@ def test_gemm_strided_views_two_residuals_rowvec_alpha(ops):
 
 
 @pytest.mark.parametrize("tile", [0, 2, 4, 5, 7, 9])
-def test_gemm_two_source_concat(ops, tile):
-    M, N, K1, K2 = 512, 320, 640, 320
+@pytest.mark.parametrize("M,N,K1,K2", [(512, 320, 640, 320), (8, 160, 160, 160), (200, 80, 160, 80), (1000, 1280, 1280, 640)])
+def test_gemm_two_source_concat(ops, tile, M, N, K1, K2):
     a1, a2 = rnd(M, K1, seed=1), rnd(M, K2, seed=2)
     w = rnd(N, K1 + K2, seed=3, scale=(K1 + K2) ** -0.5)
     out = ops.gemm(a1, w, a2=a2, out_f32=True, tile=tile)

@@ -35,7 +35,7 @@ def test_vae_decode_full_clip_shape_is_finite_and_chunking_is_consistent():
     out = vae.decode(z).sample                                   # 12 x 256 x 256: the cfg-2 clip
     assert out.shape == (12, 3, 256, 256) and bool(torch.isfinite(out).all())
     part = vae.decode(z, frames_per_chunk=5).sample
-    assert rel_l2(part, out) < 1e-2
+    assert rel_l2(part, out) < 2e-2   # other chunk size -> other autotuned tiles -> other f32 summation order -> bf16 flips
     torch.cuda.synchronize()
     import time
 
@@ -56,11 +56,12 @@ def test_pipeline_matches_oracle_pipeline(kind):
     gen = torch.Generator().manual_seed(0)
     il, noise = torch.randn(1, 4, h, w, generator=gen) * 0.18215, torch.randn(1, 4, f - 1, h, w, generator=gen)
     unet, vae = filled_unet(g["config"]), _filled_vae(TINY_VAE)
+    unet_sd = {k: v.clone() for k, v in unet.state_dict().items()}        # CPU copies for the oracle (pipe.to moves the modules)
     steps = 4
     x0 = pipeline_ref.prepare_video_latents(il, noise)
-    ref_lat = pipeline_ref.denoise(unet.state_dict(), dict(unet.config), x0, g["text"][:1], g["audio"][1:2], g["audio"][:1], g["mask"],
+    ref_lat = pipeline_ref.denoise(unet_sd, dict(unet.config), x0, g["text"][:1], g["audio"][1:2], g["audio"][:1], g["mask"],
                                    steps, 4.0, kind)
-    ref_vid = pipeline_ref.decode(vae.state_dict(), TINY_VAE, ref_lat)
+    ref_vid = pipeline_ref.decode({k: v.clone() for k, v in vae.state_dict().items()}, TINY_VAE, ref_lat)
     pipe = AudioCondAnimationPipeline(unet=unet, scheduler=PNDMScheduler() if kind == "pndm" else DDIMScheduler(), vae=vae)
     pipe.to("cuda")
     pipe.set_progress_bar_config(disable=True)
@@ -83,6 +84,6 @@ def test_pipeline_matches_oracle_pipeline(kind):
     pipe.use_engine = True
     kw2 = dict(kw, audio_encodings=g["audio"][:1], null_audio_encodings=g["audio"][1:2])
     lat3 = pipe(**kw2, output_latents=True)
-    ref3 = pipeline_ref.denoise(unet.state_dict(), dict(unet.config), x0, g["text"][:1], g["audio"][:1], g["audio"][1:2], g["mask"],
+    ref3 = pipeline_ref.denoise(unet_sd, dict(unet.config), x0, g["text"][:1], g["audio"][:1], g["audio"][1:2], g["mask"],
                                 steps, 4.0, kind)
     assert rel_l2(lat3, ref3) < 5e-2

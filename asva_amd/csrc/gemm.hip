@@ -593,7 +593,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_kernel(const avsd_gemm_des
       if (kt + 1 < nk) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
     } else if constexpr (STAGES == 4) {
       if (kt + 2 < nk) wait_vmcnt<2 * LPT>(); else if (kt + 1 < nk) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
-    } else {
+    } else {   // STAGES == 2: the tile issued during the previous iteration must have landed
       wait_vmcnt<0>();
     }
     __builtin_amdgcn_s_barrier();
@@ -611,11 +611,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_kernel(const avsd_gemm_des
 #pragma unroll
       for (int a = 0; a < FN; ++a)
         wf[a] = *reinterpret_cast<const bf16x8*>(sW + w_line[a] + (((w_hi[a] | c) ^ w_sw[a]) << 4));
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int a = 0; a < FN; ++a)
 #pragma unroll
         for (int b = 0; b < FM; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
     }
   }
 
@@ -729,6 +731,10 @@ int dispatch_tile(const avsd_gemm_desc& d, int tile, hipStream_t s) {
     case 8: return launch2<256, 64, 4, 2, 3, MODE>(d, s);
     case 9: return launch2<256, 128, 4, 2, 3, MODE>(d, s);
     case 10: return launch2<128, 64, 2, 2, 4, MODE>(d, s);
+    case 11: return launch2<128, 128, 2, 2, 2, MODE>(d, s);   // 64 KB: two 4-wave blocks per CU, 64x64 wave tiles
+    case 12: return launch2<128, 64, 2, 2, 2, MODE>(d, s);    // 48 KB: three blocks per CU
+    case 13: return launch2<64, 64, 2, 2, 2, MODE>(d, s);     // 32 KB: five blocks per CU (short-K GEMMs)
+    case 14: return launch2<256, 128, 4, 2, 2, MODE>(d, s);   // 96 KB
     default: return launch<64, 64, MODE>(d, s);
   }
 }
@@ -793,7 +799,7 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
   if (d.split_k > 1) {
     AVSD_REQUIRE(d.splitk_ws != nullptr, "gemm: split_k needs a workspace");
     AVSD_REQUIRE(!(d.flags & AVSD_GEMM_GEGLU) && d.batch == 1, "gemm: split_k cannot be combined with GEGLU or batching");
-    AVSD_REQUIRE(d.tile >= 4 && d.tile <= 10, "gemm: split_k needs an LDS-direct tile (4..10), got %d", d.tile);
+    AVSD_REQUIRE(d.tile >= 4 && d.tile <= 14, "gemm: split_k needs an LDS-direct tile (4..14), got %d", d.tile);
     AVSD_REQUIRE(d.split_k <= (d.K + 63) / 64, "gemm: split_k (%d) exceeds the number of K tiles", d.split_k);
   }
   int tile = d.tile;
@@ -810,7 +816,7 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
       tile = (d.N > 64 && d.M > 2048) ? 2 : 3;
     }
   }
-  if (tile < 1 || tile > 10) tile = pick_tile(d.M, (d.flags & AVSD_GEMM_GEGLU) ? d.N : d.N, d.batch);
+  if (tile < 1 || tile > 14) tile = pick_tile(d.M, (d.flags & AVSD_GEMM_GEGLU) ? d.N : d.N, d.batch);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (d.mode) {
     case AVSD_GEMM_PLAIN: return dispatch_tile<AVSD_GEMM_PLAIN>(d, tile, s);

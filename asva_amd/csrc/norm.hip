@@ -39,7 +39,20 @@ __global__ void gn_stats_kernel(const bf16_t* x1, int ld1, int c1, const bf16_t*
     int ld;
     if (c0 < c1) { base = x1 + c0; ld = ld1; } else { base = x2 + (c0 - c1); ld = ld2; }
     base += (int64_t)b * rows_per_batch * ld;
-    for (int r = r0 + pos0; r < r1; r += ppb) {
+    int r = r0 + pos0;
+    for (; r + 3 * ppb < r1; r += 4 * ppb) {          // 4 independent loads in flight
+      uint4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4*>(base + (int64_t)(r + u * ppb) * ld);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float f[8];
+        unpack8(v[u], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] += f[e]; ss[e] = fmaf(f[e], f[e], ss[e]); }
+      }
+    }
+    for (; r < r1; r += ppb) {
       float f[8];
       unpack8(*reinterpret_cast<const uint4*>(base + (int64_t)r * ld), f);
 #pragma unroll
@@ -63,21 +76,30 @@ __global__ void gn_stats_kernel(const bf16_t* x1, int ld1, int c1, const bf16_t*
   }
 }
 
-__global__ __launch_bounds__(512) void gn_finalize_kernel(const float* partial, int nchunks, int groups, int rows_per_batch,
-                                                          int cg, float eps, float* stat) {
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* partial, int nchunks, int groups, int rows_per_batch,
+                                                           int cg, float eps, float* stat) {
+  // 16 lanes per group, 4 independent accumulator pairs per lane so the loads overlap
   const int b = blockIdx.x;
-  const int g = threadIdx.x >> 3;     // 8 lanes per group
-  const int sub = threadIdx.x & 7;
-  double a = 0.0, q = 0.0;
+  const int g = threadIdx.x >> 4;
+  const int sub = threadIdx.x & 15;
+  double a0 = 0.0, q0 = 0.0, a1 = 0.0, q1 = 0.0;
   if (g < groups) {
-    for (int k = sub; k < nchunks; k += 8) {
-      const float* o = partial + (((int64_t)b * nchunks + k) * groups + g) * 2;
-      a += (double)o[0];
-      q += (double)o[1];
+    const float2* base = reinterpret_cast<const float2*>(partial) + (int64_t)b * nchunks * groups + g;
+    int k = sub;
+    for (; k + 16 < nchunks; k += 32) {
+      const float2 u = base[(int64_t)k * groups];
+      const float2 v = base[(int64_t)(k + 16) * groups];
+      a0 += (double)u.x; q0 += (double)u.y;
+      a1 += (double)v.x; q1 += (double)v.y;
+    }
+    if (k < nchunks) {
+      const float2 u = base[(int64_t)k * groups];
+      a0 += (double)u.x; q0 += (double)u.y;
     }
   }
+  double a = a0 + a1, q = q0 + q1;
 #pragma unroll
-  for (int off = 4; off > 0; off >>= 1) {
+  for (int off = 8; off > 0; off >>= 1) {
     a += __shfl_xor(a, off, 64);
     q += __shfl_xor(q, off, 64);
   }
@@ -117,19 +139,33 @@ __global__ void gn_apply_kernel(const bf16_t* x1, int ld1, int c1, const bf16_t*
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(rows_per_batch, r0 + rows_per_block);
   const int total = (r1 - r0) * nvec;
-  for (int idx = tid; idx < total; idx += blockDim.x) {
-    const int r = r0 + idx / nvec;
-    const int c0 = (idx % nvec) * 8;
-    const int64_t grow = (int64_t)b * rows_per_batch + r;
-    const bf16_t* src = (c0 < c1) ? x1 + grow * ld1 + c0 : x2 + grow * ld2 + (c0 - c1);
-    float f[8];
-    unpack8(*reinterpret_cast<const uint4*>(src), f);
+  for (int idx0 = tid; idx0 < total; idx0 += 2 * blockDim.x) {
+    uint4 v[2];
+    int cc[2];
+    int64_t gr[2];
+    bool ok[2];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float v = fmaf(f[e], sscale[c0 + e], sshift[c0 + e]);
-      f[e] = act ? silu_f(v) : v;
+    for (int u = 0; u < 2; ++u) {
+      const int idx = idx0 + u * blockDim.x;
+      ok[u] = idx < total;
+      const int r = r0 + (ok[u] ? idx / nvec : 0);
+      cc[u] = ok[u] ? (idx % nvec) * 8 : 0;
+      gr[u] = (int64_t)b * rows_per_batch + r;
+      const bf16_t* src = (cc[u] < c1) ? x1 + gr[u] * ld1 + cc[u] : x2 + gr[u] * ld2 + (cc[u] - c1);
+      v[u] = ok[u] ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
     }
-    *reinterpret_cast<uint4*>(y + grow * ldy + c0) = pack8(f);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (!ok[u]) continue;
+      float f[8];
+      unpack8(v[u], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float t = fmaf(f[e], sscale[cc[u] + e], sshift[cc[u] + e]);
+        f[e] = act ? silu_f(t) : t;
+      }
+      *reinterpret_cast<uint4*>(y + gr[u] * ldy + cc[u]) = pack8(f);
+    }
   }
 }
 
@@ -231,10 +267,10 @@ void gn_geometry(int C, int* nvec, int* ppb, int* threads) {
 extern "C" int avsd_groupnorm_nchunks(int nb, int rows_per_batch, int channels) {
   (void)channels;
   if (nb <= 0 || rows_per_batch <= 0) return 1;
-  int n = 2048 / nb;                 // ~2048 blocks in flight
-  int cap = rows_per_batch / 8;      // >= 8 rows per chunk
+  int n = 1024 / nb;                 // ~1024 blocks in flight
+  int cap = rows_per_batch / 16;     // >= 16 rows per chunk
   if (n > cap) n = cap;
-  if (n > 1024) n = 1024;
+  if (n > 512) n = 512;
   if (n < 1) n = 1;
   return n;
 }
@@ -270,7 +306,7 @@ extern "C" int avsd_groupnorm_stats(const void* x1, int ld1, int c1, const void*
                      (const bf16_t*)x1, ld1, c1, (const bf16_t*)x2, ld2, c2, rows_per_batch, groups, scratch, nchunks, nvec, ppb);
   AVSD_CHECK_LAUNCH("groupnorm_stats launch");
   float* stat = scratch + (size_t)nb * nchunks * groups * 2;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)nb), dim3(512), 0, s, scratch, nchunks, groups, rows_per_batch,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)nb), dim3(1024), 0, s, scratch, nchunks, groups, rows_per_batch,
                      C / groups, eps, stat);
   AVSD_CHECK_LAUNCH("groupnorm_finalize launch");
   return AVSD_OK;

@@ -735,6 +735,10 @@ int dispatch_tile(const avsd_gemm_desc& d, int tile, hipStream_t s) {
     case 12: return launch2<128, 64, 2, 2, 2, MODE>(d, s);    // 48 KB: three blocks per CU
     case 13: return launch2<64, 64, 2, 2, 2, MODE>(d, s);     // 32 KB: five blocks per CU (short-K GEMMs)
     case 14: return launch2<256, 128, 4, 2, 2, MODE>(d, s);   // 96 KB
+    // full-row tiles for N = 320 / 640 / 1280 layers: the activation tile is fetched from L2 once per block
+    case 15: return launch2<128, 320, 2, 2, 2, MODE>(d, s);   // 112 KB, 4 waves, 64x160 wave tiles
+    case 16: return launch2<64, 320, 2, 2, 3, MODE>(d, s);    // 144 KB, 4 waves, 32x160 wave tiles
+    case 17: return launch2<128, 320, 4, 2, 2, MODE>(d, s);   // 112 KB, 8 waves, 32x160 wave tiles
     default: return launch<64, 64, MODE>(d, s);
   }
 }
@@ -799,7 +803,7 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
   if (d.split_k > 1) {
     AVSD_REQUIRE(d.splitk_ws != nullptr, "gemm: split_k needs a workspace");
     AVSD_REQUIRE(!(d.flags & AVSD_GEMM_GEGLU) && d.batch == 1, "gemm: split_k cannot be combined with GEGLU or batching");
-    AVSD_REQUIRE(d.tile >= 4 && d.tile <= 14, "gemm: split_k needs an LDS-direct tile (4..14), got %d", d.tile);
+    AVSD_REQUIRE(d.tile >= 4 && d.tile <= 17, "gemm: split_k needs an LDS-direct tile (4..17), got %d", d.tile);
     AVSD_REQUIRE(d.split_k <= (d.K + 63) / 64, "gemm: split_k (%d) exceeds the number of K tiles", d.split_k);
   }
   int tile = d.tile;
@@ -816,7 +820,7 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
       tile = (d.N > 64 && d.M > 2048) ? 2 : 3;
     }
   }
-  if (tile < 1 || tile > 14) tile = pick_tile(d.M, (d.flags & AVSD_GEMM_GEGLU) ? d.N : d.N, d.batch);
+  if (tile < 1 || tile > 17) tile = pick_tile(d.M, (d.flags & AVSD_GEMM_GEGLU) ? d.N : d.N, d.batch);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (d.mode) {
     case AVSD_GEMM_PLAIN: return dispatch_tile<AVSD_GEMM_PLAIN>(d, tile, s);

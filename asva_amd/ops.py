@@ -71,7 +71,7 @@ def _stream() -> int:
 # timed with HIP events on the caller's real buffers and the winner is cached for the life of the process
 # (measure, don't guess).  During capture, or with autotuning off, an uncached shape falls back to the
 # library's static heuristic (tile 0).
-TILE_CANDIDATES = ((4, 1), (6, 1), (7, 1), (8, 1), (9, 1), (3, 1), (11, 1), (12, 1), (13, 1), (14, 1))
+TILE_CANDIDATES = ((4, 1), (6, 1), (7, 1), (8, 1), (9, 1), (3, 1), (11, 1), (12, 1), (13, 1), (14, 1), (15, 1), (16, 1), (17, 1))
 # extra (tile, split_k) candidates for GEMMs whose output is too small to fill 256 CUs with big tiles
 SPLITK_CANDIDATES = ((6, 2), (6, 4), (6, 8), (9, 2), (9, 4), (4, 2), (4, 4), (4, 8), (7, 2), (7, 4))
 _TILE_CACHE: dict = {}

@@ -209,8 +209,13 @@ struct TAttnArgs {
   float scale;
 };
 
+// One thread per (head, query frame, d-slice): the head dimension is cut into DS slices of SL channels held by DS
+// adjacent lanes (partial dot products are summed with 1-2 shuffles), so d = 160 runs 4x the threads of d = 40.
 template <int D, int FMAX>
-__global__ __launch_bounds__(256) void tattn_kernel(const TAttnArgs p) {
+__global__ __launch_bounds__(1024) void tattn_kernel(const TAttnArgs p) {
+  constexpr int SL = (D % 40 == 0) ? 40 : 32;   // slice length
+  constexpr int DS = D / SL;                    // 1, 2 or 4 lanes per (head, frame)
+  constexpr int NV = SL / 8;                    // 16-byte vectors per slice
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_t[];
   bf16_t* sKV = reinterpret_cast<bf16_t*>(smem_t);  // [frames][2*C] : k | v
   const int C = p.heads * D;
@@ -220,7 +225,6 @@ __global__ __launch_bounds__(256) void tattn_kernel(const TAttnArgs p) {
   const int64_t row0 = ((int64_t)b * F) * p.hw + pix;  // row of frame f = row0 + f*hw
   const int tid = threadIdx.x;
 
-  // stage K|V (columns C .. 3C of each of the F rows)
   const int vec_per_row = 2 * C / 8;
   for (int v = tid; v < F * vec_per_row; v += blockDim.x) {
     const int f = v / vec_per_row;
@@ -230,32 +234,36 @@ __global__ __launch_bounds__(256) void tattn_kernel(const TAttnArgs p) {
   }
   __syncthreads();
 
-  if (tid >= p.heads * F) return;
-  const int head = tid / F;
-  const int i = tid - head * F;
+  const int s = tid % DS;
+  const int hi = tid / DS;            // head * F + i
+  const bool active = hi < p.heads * F;
+  const int head = active ? hi / F : 0;
+  const int i = active ? hi - head * F : 0;
+  const int coff = head * D + s * SL; // this lane's channel slice
 
-  uint4 qv[D / 8];
+  uint4 qv[NV];
   {
-    const bf16_t* qrow = p.QKV + (row0 + (int64_t)i * p.hw) * p.ldqkv + head * D;
+    const bf16_t* qrow = p.QKV + (row0 + (int64_t)i * p.hw) * p.ldqkv + coff;
 #pragma unroll
-    for (int d = 0; d < D / 8; ++d) qv[d] = *reinterpret_cast<const uint4*>(qrow + d * 8);
+    for (int d = 0; d < NV; ++d) qv[d] = *reinterpret_cast<const uint4*>(qrow + d * 8);
   }
-
   float sc[FMAX];
   float mx = -1e30f;
 #pragma unroll
   for (int j = 0; j < FMAX; ++j) {
     float dot = 0.f;
     if (j < F) {
-      const bf16_t* krow = sKV + j * 2 * C + head * D;
+      const bf16_t* krow = sKV + j * 2 * C + coff;
 #pragma unroll
-      for (int d = 0; d < D / 8; ++d) {
+      for (int d = 0; d < NV; ++d) {
         float a[8], k[8];
         unpack8(qv[d], a);
         unpack8(*reinterpret_cast<const uint4*>(krow + d * 8), k);
 #pragma unroll
         for (int e = 0; e < 8; ++e) dot = fmaf(a[e], k[e], dot);
       }
+#pragma unroll
+      for (int o = DS / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
       dot *= p.scale;
       mx = fmaxf(mx, dot);
     }
@@ -269,10 +277,11 @@ __global__ __launch_bounds__(256) void tattn_kernel(const TAttnArgs p) {
     sum += e;
   }
   const float inv = 1.0f / sum;
+  if (!active) return;
 
-  bf16_t* orow = p.O + (row0 + (int64_t)i * p.hw) * p.ldo + head * D;
+  bf16_t* orow = p.O + (row0 + (int64_t)i * p.hw) * p.ldo + coff;
 #pragma unroll
-  for (int d = 0; d < D / 8; ++d) {
+  for (int d = 0; d < NV; ++d) {
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
@@ -280,7 +289,7 @@ __global__ __launch_bounds__(256) void tattn_kernel(const TAttnArgs p) {
     for (int j = 0; j < FMAX; ++j) {
       if (j < F) {
         float vv[8];
-        unpack8(*reinterpret_cast<const uint4*>(sKV + j * 2 * C + C + head * D + d * 8), vv);
+        unpack8(*reinterpret_cast<const uint4*>(sKV + j * 2 * C + C + coff + d * 8), vv);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = fmaf(sc[j], vv[e], o[e]);
       }
@@ -293,6 +302,7 @@ __global__ __launch_bounds__(256) void tattn_kernel(const TAttnArgs p) {
 
 template <int D, int FMAX>
 int launch_tattn(const TAttnArgs& a, int B, hipStream_t s) {
+  constexpr int DS = D / ((D % 40 == 0) ? 40 : 32);
   const size_t lds = (size_t)a.frames * 2 * a.heads * D * sizeof(bf16_t);
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
@@ -304,8 +314,11 @@ int launch_tattn(const TAttnArgs& a, int B, hipStream_t s) {
     }
     attr_lds = lds;
   }
-  int threads = (a.heads * a.frames + 63) / 64 * 64;
-  if (threads < 64) threads = 64;
+  int threads = (a.heads * a.frames * DS + 63) / 64 * 64;
+  if (threads > 1024) {
+    avsd_set_error("temporal attention: heads*frames*%d = %d threads exceeds 1024", DS, a.heads * a.frames * DS);
+    return AVSD_EINVAL;
+  }
   hipLaunchKernelGGL((tattn_kernel<D, FMAX>), dim3((unsigned)(B * a.hw)), dim3(threads), lds, s, a);
   AVSD_CHECK_LAUNCH("temporal attention launch");
   return AVSD_OK;

@@ -77,8 +77,11 @@ __global__ void gn_stats_kernel(const bf16_t* x1, int ld1, int c1, const bf16_t*
 }
 
 __global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* partial, int nchunks, int groups, int rows_per_batch,
-                                                           int cg, float eps, float* stat) {
-  // 16 lanes per group, 4 independent accumulator pairs per lane so the loads overlap
+                                                           int cg, float eps, const float* gamma, const float* beta,
+                                                           float* scale_shift) {
+  // 16 lanes per group, 2 independent accumulator pairs per lane so the loads overlap; then every thread turns
+  // (mean, rstd) into per-channel (scale, shift) so the apply kernel is a pure stream
+  __shared__ float smean[64], srstd[64];
   const int b = blockIdx.x;
   const int g = threadIdx.x >> 4;
   const int sub = threadIdx.x & 15;
@@ -108,60 +111,55 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* partial,
     const double mean = a / n;
     double var = q / n - mean * mean;
     if (var < 0.0) var = 0.0;
-    stat[((int64_t)b * groups + g) * 2 + 0] = (float)mean;
-    stat[((int64_t)b * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    smean[g] = (float)mean;
+    srstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const int C = groups * cg;
+  float* out = scale_shift + (int64_t)b * 2 * C;        // [C] scale | [C] shift
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const int gg = c / cg;
+    const float sc = srstd[gg] * gamma[c];
+    out[c] = sc;
+    out[C + c] = beta[c] - smean[gg] * sc;
   }
 }
 
-// ---- GroupNorm apply (+ optional SiLU, + channel concat) ----------------------------------------
-__global__ void gn_apply_kernel(const bf16_t* x1, int ld1, int c1, const bf16_t* x2, int ld2, int c2,
-                                int rows_per_batch, int groups, const float* stat,
-                                const float* gamma, const float* beta, int act, bf16_t* y,
-                                int ldy, int rows_per_block) {
-  extern __shared__ float sap[];  // [C] scale | [C] shift
+// ---- GroupNorm apply (+ optional SiLU, + channel concat): flat grid-stride stream, 2 vectors in flight per thread
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x1, int ld1, int c1, const bf16_t* x2, int ld2, int c2,
+                                                       int rows_per_batch, int nb, const float* scale_shift, int act,
+                                                       bf16_t* y, int ldy) {
   const int C = c1 + c2;
-  float* sscale = sap;
-  float* sshift = sap + C;
-  const int tid = threadIdx.x;
-  const int b = blockIdx.y;
-  const int cg = C / groups;
-  for (int c = tid; c < C; c += blockDim.x) {
-    const int g = c / cg;
-    const float mean = stat[((int64_t)b * groups + g) * 2 + 0];
-    const float rstd = stat[((int64_t)b * groups + g) * 2 + 1];
-    const float sc = rstd * gamma[c];
-    sscale[c] = sc;
-    sshift[c] = beta[c] - mean * sc;
-  }
-  __syncthreads();
-
   const int nvec = C / 8;
-  const int r0 = blockIdx.x * rows_per_block;
-  const int r1 = min(rows_per_batch, r0 + rows_per_block);
-  const int total = (r1 - r0) * nvec;
-  for (int idx0 = tid; idx0 < total; idx0 += 2 * blockDim.x) {
+  const int64_t total = (int64_t)nb * rows_per_batch * nvec;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i0 < total; i0 += 2 * stride) {
     uint4 v[2];
     int cc[2];
     int64_t gr[2];
     bool ok[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int idx = idx0 + u * blockDim.x;
-      ok[u] = idx < total;
-      const int r = r0 + (ok[u] ? idx / nvec : 0);
-      cc[u] = ok[u] ? (idx % nvec) * 8 : 0;
-      gr[u] = (int64_t)b * rows_per_batch + r;
+      const int64_t i = i0 + u * stride;
+      ok[u] = i < total;
+      gr[u] = ok[u] ? i / nvec : 0;
+      cc[u] = ok[u] ? (int)(i - gr[u] * nvec) * 8 : 0;
       const bf16_t* src = (cc[u] < c1) ? x1 + gr[u] * ld1 + cc[u] : x2 + gr[u] * ld2 + (cc[u] - c1);
       v[u] = ok[u] ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       if (!ok[u]) continue;
+      const float* ss = scale_shift + (gr[u] / rows_per_batch) * 2 * C + cc[u];
+      const float4 s0 = *reinterpret_cast<const float4*>(ss), s1 = *reinterpret_cast<const float4*>(ss + 4);
+      const float4 h0 = *reinterpret_cast<const float4*>(ss + C), h1 = *reinterpret_cast<const float4*>(ss + C + 4);
+      const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+      const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
       float f[8];
       unpack8(v[u], f);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float t = fmaf(f[e], sscale[cc[u] + e], sshift[cc[u] + e]);
+        const float t = fmaf(f[e], sc[e], sh[e]);
         f[e] = act ? silu_f(t) : t;
       }
       *reinterpret_cast<uint4*>(y + gr[u] * ldy + cc[u]) = pack8(f);
@@ -169,21 +167,25 @@ __global__ void gn_apply_kernel(const bf16_t* x1, int ld1, int c1, const bf16_t*
   }
 }
 
-// ---- LayerNorm: one wave per row, up to 4 vectors (C <= 2048) per lane in registers -------------
+// ---- LayerNorm: LPR lanes per row (power of two), 64/LPR rows per wave, up to 8 vectors per lane in registers.
+// C = 320/640/1280 -> LPR = 8/16/32 with exactly 5 vectors per lane: every lane busy, 5 loads in flight per lane.
+template <int LPR>
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* x, int ldx, bf16_t* y, int ldy, int M,
                                                         int C, const float* gamma, const float* beta,
                                                         float eps, const float* pos, int hw, int frames) {
+  constexpr int RPW = 64 / LPR;                 // rows per wave
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+  const int sub = lane % LPR;
+  const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+  const bool rvalid = row < M;
   const int nvec = C / 8;
-  const float* prow = pos ? pos + (int64_t)((row / hw) % frames) * C : nullptr;
-  float f[4][8];
+  const float* prow = (pos && rvalid) ? pos + (int64_t)((row / hw) % frames) * C : nullptr;
+  float f[8][8];
   float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int v = lane + 64 * i;
-    if (v < nvec) {
+  for (int i = 0; i < 8; ++i) {
+    const int v = sub + LPR * i;
+    if (rvalid && v < nvec) {
       unpack8(*reinterpret_cast<const uint4*>(x + (int64_t)row * ldx + v * 8), f[i]);
       if (prow) {
         const float4 p0 = *reinterpret_cast<const float4*>(prow + v * 8);
@@ -195,21 +197,25 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* x, int ldx
       for (int e = 0; e < 8; ++e) sum += f[i][e];
     }
   }
-  const float mean = wave_sum(sum) / (float)C;
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float mean = sum / (float)C;
   float sq = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int v = lane + 64 * i;
-    if (v < nvec) {
+  for (int i = 0; i < 8; ++i) {
+    const int v = sub + LPR * i;
+    if (rvalid && v < nvec) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) { const float d = f[i][e] - mean; sq = fmaf(d, d, sq); }
     }
   }
-  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int v = lane + 64 * i;
-    if (v < nvec) {
+  for (int o = LPR / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  const float rstd = rsqrtf(sq / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int v = sub + LPR * i;
+    if (rvalid && v < nvec) {
       const float4 g0 = *reinterpret_cast<const float4*>(gamma + v * 8);
       const float4 g1 = *reinterpret_cast<const float4*>(gamma + v * 8 + 4);
       const float4 b0 = *reinterpret_cast<const float4*>(beta + v * 8);
@@ -222,6 +228,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* x, int ldx
       *reinterpret_cast<uint4*>(y + (int64_t)row * ldy + v * 8) = pack8(o);
     }
   }
+}
+
+template <int LPR>
+void launch_layernorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, int M, int C, const float* gamma, const float* beta,
+                      float eps, const float* pos, int hw, int frames, hipStream_t s) {
+  const int rows_per_block = 4 * (64 / LPR);
+  hipLaunchKernelGGL(layernorm_kernel<LPR>, dim3((unsigned)((M + rows_per_block - 1) / rows_per_block)), dim3(256), 0, s, x, ldx,
+                     y, ldy, M, C, gamma, beta, eps, pos, hw, frames);
 }
 
 // ---- row softmax: S f32 -> P bf16, one wave per row ---------------------------------------------
@@ -275,9 +289,9 @@ extern "C" int avsd_groupnorm_nchunks(int nb, int rows_per_batch, int channels) 
   return n;
 }
 
-// floats of scratch the stats + apply pair needs: partial[nb][nchunks][groups][2] then stat[nb][groups][2]
-extern "C" int avsd_groupnorm_scratch_floats(int nb, int nchunks, int groups) {
-  return nb * nchunks * groups * 2 + nb * groups * 2;
+// floats of scratch the stats + apply pair needs: partial[nb][nchunks][groups][2] then scale_shift[nb][2][channels]
+extern "C" int avsd_groupnorm_scratch_floats(int nb, int nchunks, int groups, int channels) {
+  return nb * nchunks * groups * 2 + nb * 2 * channels;
 }
 
 static int gn_check(const void* x1, int ld1, int c1, const void* x2, int ld2, int c2, int nb,
@@ -292,11 +306,11 @@ static int gn_check(const void* x1, int ld1, int c1, const void* x2, int ld2, in
 }
 
 extern "C" int avsd_groupnorm_stats(const void* x1, int ld1, int c1, const void* x2, int ld2, int c2, int nb,
-                                    int rows_per_batch, int groups, float eps, float* scratch, int nchunks,
-                                    void* stream) {
+                                    int rows_per_batch, int groups, const float* gamma, const float* beta, float eps,
+                                    float* scratch, int nchunks, void* stream) {
   int rc = gn_check(x1, ld1, c1, x2, ld2, c2, nb, rows_per_batch, groups, nchunks);
   if (rc) return rc;
-  AVSD_REQUIRE(scratch, "groupnorm_stats: null scratch buffer");
+  AVSD_REQUIRE(scratch && gamma && beta, "groupnorm_stats: null pointer");
   const int C = c1 + c2;
   int nvec, ppb, threads;
   gn_geometry(C, &nvec, &ppb, &threads);
@@ -305,30 +319,28 @@ extern "C" int avsd_groupnorm_stats(const void* x1, int ld1, int c1, const void*
   hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)nchunks, (unsigned)nb), dim3((unsigned)threads), lds, s,
                      (const bf16_t*)x1, ld1, c1, (const bf16_t*)x2, ld2, c2, rows_per_batch, groups, scratch, nchunks, nvec, ppb);
   AVSD_CHECK_LAUNCH("groupnorm_stats launch");
-  float* stat = scratch + (size_t)nb * nchunks * groups * 2;
+  float* scale_shift = scratch + (size_t)nb * nchunks * groups * 2;
   hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)nb), dim3(1024), 0, s, scratch, nchunks, groups, rows_per_batch,
-                     C / groups, eps, stat);
+                     C / groups, eps, gamma, beta, scale_shift);
   AVSD_CHECK_LAUNCH("groupnorm_finalize launch");
   return AVSD_OK;
 }
 
 extern "C" int avsd_groupnorm_apply(const void* x1, int ld1, int c1, const void* x2, int ld2, int c2, int nb,
-                                    int rows_per_batch, int groups, const float* scratch, int nchunks,
-                                    const float* gamma, const float* beta, int act, void* y, int ldy,
-                                    void* stream) {
+                                    int rows_per_batch, int groups, const float* scratch, int nchunks, int act, void* y,
+                                    int ldy, void* stream) {
   int rc = gn_check(x1, ld1, c1, x2, ld2, c2, nb, rows_per_batch, groups, nchunks);
   if (rc) return rc;
-  AVSD_REQUIRE(scratch && gamma && beta && y, "groupnorm_apply: null pointer");
+  AVSD_REQUIRE(scratch && y, "groupnorm_apply: null pointer");
   const int C = c1 + c2;
   AVSD_REQUIRE(ldy % 8 == 0 && ldy >= C, "groupnorm_apply: bad ldy %d", ldy);
-  int rows_per_block = 16;
-  while ((int64_t)nb * ((rows_per_batch + rows_per_block - 1) / rows_per_block) > 4096) rows_per_block *= 2;
-  const int nblk = (rows_per_batch + rows_per_block - 1) / rows_per_block;
-  const size_t lds = (size_t)2 * C * sizeof(float);
-  const float* stat = scratch + (size_t)nb * nchunks * groups * 2;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)nblk, (unsigned)nb), dim3(256), lds,
-                     reinterpret_cast<hipStream_t>(stream), (const bf16_t*)x1, ld1, c1, (const bf16_t*)x2, ld2, c2,
-                     rows_per_batch, groups, stat, gamma, beta, act, (bf16_t*)y, ldy, rows_per_block);
+  const int64_t total = (int64_t)nb * rows_per_batch * (C / 8);
+  int64_t nblk = (total + 511) / 512;       // 2 vectors per thread per sweep
+  if (nblk > 4096) nblk = 4096;
+  const float* scale_shift = scratch + (size_t)nb * nchunks * groups * 2;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)nblk), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     (const bf16_t*)x1, ld1, c1, (const bf16_t*)x2, ld2, c2, rows_per_batch, nb, scale_shift, act,
+                     (bf16_t*)y, ldy);
   AVSD_CHECK_LAUNCH("groupnorm_apply launch");
   return AVSD_OK;
 }
@@ -336,12 +348,21 @@ extern "C" int avsd_groupnorm_apply(const void* x1, int ld1, int c1, const void*
 extern "C" int avsd_layernorm(const void* x, int ldx, void* y, int ldy, int M, int C, const float* gamma,
                               const float* beta, float eps, const float* pos, int hw, int frames, void* stream) {
   AVSD_REQUIRE(x && y && gamma && beta, "layernorm: null pointer");
-  AVSD_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, "layernorm: C (%d) must be a multiple of 8, <= 2048", C);
+  AVSD_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= 4096, "layernorm: C (%d) must be a multiple of 8, <= 4096", C);
   AVSD_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C, "layernorm: bad strides");
   if (pos) AVSD_REQUIRE(hw > 0 && frames > 0, "layernorm: pos needs hw and frames");
   if (!pos) { hw = 1; frames = 1; }
-  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     (const bf16_t*)x, ldx, (bf16_t*)y, ldy, M, C, gamma, beta, eps, pos, hw, frames);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int nvec = C / 8;
+  const bf16_t* xi = (const bf16_t*)x;
+  bf16_t* yo = (bf16_t*)y;
+  if (nvec <= 8) launch_layernorm<1>(xi, ldx, yo, ldy, M, C, gamma, beta, eps, pos, hw, frames, s);
+  else if (nvec <= 16) launch_layernorm<2>(xi, ldx, yo, ldy, M, C, gamma, beta, eps, pos, hw, frames, s);
+  else if (nvec <= 32) launch_layernorm<4>(xi, ldx, yo, ldy, M, C, gamma, beta, eps, pos, hw, frames, s);
+  else if (nvec <= 64) launch_layernorm<8>(xi, ldx, yo, ldy, M, C, gamma, beta, eps, pos, hw, frames, s);
+  else if (nvec <= 128) launch_layernorm<16>(xi, ldx, yo, ldy, M, C, gamma, beta, eps, pos, hw, frames, s);
+  else if (nvec <= 256) launch_layernorm<32>(xi, ldx, yo, ldy, M, C, gamma, beta, eps, pos, hw, frames, s);
+  else launch_layernorm<64>(xi, ldx, yo, ldy, M, C, gamma, beta, eps, pos, hw, frames, s);
   AVSD_CHECK_LAUNCH("layernorm launch");
   return AVSD_OK;
 }

@@ -94,18 +94,20 @@ def _pick_tile(key, launch, candidates=TILE_CANDIDATES):
         return t
     if not _AUTOTUNE or _TIMER is not None or torch.cuda.is_current_stream_capturing():
         return (0, 1)
-    best, best_ms = (0, 1), float("inf")
-    for cand in candidates:
-        launch(*cand)                      # warm (also sets the kernel's LDS attribute)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(3):
-            launch(*cand)
-        e1.record()
-        e1.synchronize()
-        ms = e0.elapsed_time(e1)
-        if ms < best_ms:
-            best, best_ms = cand, ms
+    times = {}
+    for rnd in range(2):                   # two interleaved rounds, best-of per candidate: robust to clock ramp / noise
+        for cand in candidates:
+            if rnd == 0:
+                launch(*cand)              # warm (also sets the kernel's LDS attribute)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                launch(*cand)
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1)
+            times[cand] = min(ms, times.get(cand, float("inf")))
+    best = min(times, key=times.get)
     _TILE_CACHE[key] = best
     return best
 
@@ -299,16 +301,15 @@ def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], nb: int, rows_per_ba
     L = _lib.lib()
     rows = nb * rows_per_batch
     nchunks = L.avsd_groupnorm_nchunks(nb, rows_per_batch, c1 + c2)
-    partial = torch.empty((L.avsd_groupnorm_scratch_floats(nb, nchunks, groups),), dtype=F32, device=x1.device)
+    partial = torch.empty((L.avsd_groupnorm_scratch_floats(nb, nchunks, groups, c1 + c2),), dtype=F32, device=x1.device)
     if out is None:
         out = torch.empty((rows, c1 + c2), dtype=BF16, device=x1.device)
     s = _stream()
     ev = _TIMER.start() if _TIMER is not None else None
     check(L.avsd_groupnorm_stats(_p(x1), _ld(x1), c1, _p(x2), _ld(x2) if x2 is not None else 0, c2, nb, rows_per_batch,
-                                 groups, float(eps), _p(partial), nchunks, s), "avsd_groupnorm_stats")
+                                 groups, _p(gamma), _p(beta), float(eps), _p(partial), nchunks, s), "avsd_groupnorm_stats")
     check(L.avsd_groupnorm_apply(_p(x1), _ld(x1), c1, _p(x2), _ld(x2) if x2 is not None else 0, c2, nb, rows_per_batch,
-                                 groups, _p(partial), nchunks, _p(gamma), _p(beta), int(act), _p(out),
-                                 _ld(out), s), "avsd_groupnorm_apply")
+                                 groups, _p(partial), nchunks, int(act), _p(out), _ld(out), s), "avsd_groupnorm_apply")
     if ev is not None:
         _TIMER.stop(ev, "groupnorm", 0.0, 2.0 * _nbytes(x1, x2) + _nbytes(out))
     return out

@@ -82,35 +82,68 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
   const int32_t* kidx = p.key_index ? p.key_index + (int64_t)frame * p.Lk : nullptr;
 
   const int ntiles = (p.Lk + 31) / 32;
-  for (int t = 0; t < ntiles; ++t) {
-    // ---- stage K tile [32 keys][DK] and V tile transposed [DV][32 keys] --------------------------
-    for (int v = tid; v < 32 * KVEC; v += 256) {
+  // Software pipeline: the global loads of tile t+1 are issued before the MFMA/softmax work of tile t and parked
+  // in registers; they are written to LDS after the tile's trailing barrier.  (K: [32 keys][DK] row-major;
+  // V: transposed [DV][32 keys] so the P.V operand is a contiguous 8-byte read per lane.)
+  constexpr int NKV = (32 * KVEC + 255) / 256;   // K vectors per thread per tile
+  constexpr int NVV = (32 * VVEC + 255) / 256;
+  uint4 rk[NKV], rv[NVV];
+  auto gload = [&](int t) {
+#pragma unroll
+    for (int u = 0; u < NKV; ++u) {
+      const int v = tid + u * 256;
       const int key = v / KVEC;
       const int dv = (v - key * KVEC) * 8;
       const int kk = t * 32 + key;
-      uint4 val = make_uint4(0, 0, 0, 0);
-      if (kk < p.Lk && dv < D) {
+      rk[u] = make_uint4(0, 0, 0, 0);
+      if (v < 32 * KVEC && kk < p.Lk && dv < D) {
         const int row = kidx ? kidx[kk] : kk;
-        val = *reinterpret_cast<const uint4*>(Kb + (int64_t)row * p.ldk + dv);
+        rk[u] = *reinterpret_cast<const uint4*>(Kb + (int64_t)row * p.ldk + dv);
       }
-      *reinterpret_cast<uint4*>(sK + key * KS + dv) = val;
     }
-    for (int v = tid; v < 32 * VVEC; v += 256) {
+#pragma unroll
+    for (int u = 0; u < NVV; ++u) {
+      const int v = tid + u * 256;
       const int key = v / VVEC;
       const int dv = (v - key * VVEC) * 8;
       const int kk = t * 32 + key;
-      uint4 val = make_uint4(0, 0, 0, 0);
-      if (kk < p.Lk && dv < D) {
+      rv[u] = make_uint4(0, 0, 0, 0);
+      if (v < 32 * VVEC && kk < p.Lk && dv < D) {
         const int row = kidx ? kidx[kk] : kk;
-        val = *reinterpret_cast<const uint4*>(Vb + (int64_t)row * p.ldv + dv);
+        rv[u] = *reinterpret_cast<const uint4*>(Vb + (int64_t)row * p.ldv + dv);
       }
-      bf16_t* dst = sVt + dv * VS + key;
-      dst[0 * VS] = (bf16_t)(val.x & 0xffff); dst[1 * VS] = (bf16_t)(val.x >> 16);
-      dst[2 * VS] = (bf16_t)(val.y & 0xffff); dst[3 * VS] = (bf16_t)(val.y >> 16);
-      dst[4 * VS] = (bf16_t)(val.z & 0xffff); dst[5 * VS] = (bf16_t)(val.z >> 16);
-      dst[6 * VS] = (bf16_t)(val.w & 0xffff); dst[7 * VS] = (bf16_t)(val.w >> 16);
     }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int u = 0; u < NKV; ++u) {
+      const int v = tid + u * 256;
+      if (v < 32 * KVEC) {
+        const int key = v / KVEC;
+        const int dv = (v - key * KVEC) * 8;
+        *reinterpret_cast<uint4*>(sK + key * KS + dv) = rk[u];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NVV; ++u) {
+      const int v = tid + u * 256;
+      if (v < 32 * VVEC) {
+        const int key = v / VVEC;
+        const int dv = (v - key * VVEC) * 8;
+        const uint4 val = rv[u];
+        bf16_t* dst = sVt + dv * VS + key;
+        dst[0 * VS] = (bf16_t)(val.x & 0xffff); dst[1 * VS] = (bf16_t)(val.x >> 16);
+        dst[2 * VS] = (bf16_t)(val.y & 0xffff); dst[3 * VS] = (bf16_t)(val.y >> 16);
+        dst[4 * VS] = (bf16_t)(val.z & 0xffff); dst[5 * VS] = (bf16_t)(val.z >> 16);
+        dst[6 * VS] = (bf16_t)(val.w & 0xffff); dst[7 * VS] = (bf16_t)(val.w >> 16);
+      }
+    }
+  };
+  gload(0);
+  for (int t = 0; t < ntiles; ++t) {
+    lstore();
     __syncthreads();
+    if (t + 1 < ntiles) gload(t + 1);
 
     // ---- S^T[key][query] = K . Q^T ---------------------------------------------------------------
     f32x16 s;

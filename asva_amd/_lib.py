@@ -32,7 +32,7 @@ class GemmDesc(C.Structure):
         ("batch_stride_a", C.c_int64), ("batch_stride_w", C.c_int64), ("batch_stride_out", C.c_int64),
         ("hw", C.c_int32), ("frames", C.c_int32), ("cseg", C.c_int32),
         ("hs", C.c_int32), ("ws", C.c_int32), ("ho", C.c_int32), ("wo", C.c_int32),
-        ("cin", C.c_int32), ("stride", C.c_int32), ("ups", C.c_int32),
+        ("cin", C.c_int32), ("stride", C.c_int32), ("ups", C.c_int32), ("pad", C.c_int32),
         ("tile", C.c_int32),
         ("split_k", C.c_int32), ("splitk_ws", c_void_p),
     ]

@@ -49,8 +49,8 @@ __device__ __forceinline__ RowInfo make_row(const avsd_gemm_desc& p, int m) {
     const int oh = rem / p.wo;
     const int ow = rem - oh * p.wo;
     r.o0 = n;
-    r.hb = oh * p.stride - 1;
-    r.wb = ow * p.stride - 1;
+    r.hb = oh * p.stride - p.pad;
+    r.wb = ow * p.stride - p.pad;
   }
   return r;
 }
@@ -345,8 +345,8 @@ __device__ __forceinline__ RowInfo32 make_row32(const avsd_gemm_desc& p, int m) 
     const int rem = m - n * per;
     const int oh = rem / p.wo;
     r.o0 = n;
-    r.hb = oh * p.stride - 1;
-    r.wb = (rem - oh * p.wo) * p.stride - 1;
+    r.hb = oh * p.stride - p.pad;
+    r.wb = (rem - oh * p.wo) * p.stride - p.pad;
   }
   return r;
 }
@@ -794,6 +794,7 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
     AVSD_REQUIRE(d.cin > 0 && d.cin % 8 == 0 && d.K == 9 * d.cin, "gemm/conv3: K (%d) must equal 9*cin (%d), cin %% 8 == 0", d.K, d.cin);
     AVSD_REQUIRE(d.stride == 1 || d.stride == 2, "gemm/conv3: stride must be 1 or 2");
     AVSD_REQUIRE(d.ups == 0 || d.ups == 1, "gemm/conv3: ups must be 0 or 1");
+    AVSD_REQUIRE(d.pad == 0 || d.pad == 1, "gemm/conv3: pad must be 0 or 1");
     AVSD_REQUIRE(d.hs > 0 && d.ws > 0 && d.ho > 0 && d.wo > 0 && d.M % (d.ho * d.wo) == 0, "gemm/conv3: bad image geometry");
     const int hin = d.hs << d.ups, win = d.ws << d.ups;
     AVSD_REQUIRE(d.ho == (hin + 2 - 3) / d.stride + 1 && d.wo == (win + 2 - 3) / d.stride + 1, "gemm/conv3: (ho,wo)=(%d,%d) inconsistent with input (%d,%d) stride %d", d.ho, d.wo, hin, win, d.stride);

@@ -147,7 +147,7 @@ def gemm(
     out: Optional[torch.Tensor] = None,
     mode: int = PLAIN,
     tmix: Optional[tuple] = None,      # (hw, frames)
-    conv: Optional[tuple] = None,      # (n_img, hs, ws, stride, ups)
+    conv: Optional[tuple] = None,      # (n_img, hs, ws, stride, ups[, pad])
     m: Optional[int] = None,
     tile: int = 0,
     split_k: int = 1,
@@ -176,13 +176,14 @@ def gemm(
         K = 3 * cseg
         d.hw, d.frames, d.cseg = hw, frames, cseg
     elif mode == CONV3:
-        n_img, hs, ws, stride, ups = conv
+        n_img, hs, ws, stride, ups = conv[:5]
+        pad = conv[5] if len(conv) > 5 else 1
         cin = a.shape[1]
         hin, win = hs << ups, ws << ups
         ho, wo = (hin + 2 - 3) // stride + 1, (win + 2 - 3) // stride + 1
         M = n_img * ho * wo
         K = 9 * cin
-        d.hs, d.ws, d.ho, d.wo, d.cin, d.stride, d.ups = hs, ws, ho, wo, cin, stride, ups
+        d.hs, d.ws, d.ho, d.wo, d.cin, d.stride, d.ups, d.pad = hs, ws, ho, wo, cin, stride, ups, pad
     else:
         raise ValueError(f"unknown gemm mode {mode}")
     n_out = N // 2 if geglu else N
@@ -229,7 +230,7 @@ def gemm(
         two_src_unaligned = a2 is not None and (a.shape[1] % 64 != 0)     # C falls back to register-staged tiles
         if not geglu and not two_src_unaligned and ((M + 127) // 128) * ((N + 127) // 128) < 256 and nk >= 16:
             cands = cands + tuple(c for c in SPLITK_CANDIDATES if nk // c[1] >= 4)
-        tile, split_k = _pick_tile((mode, M, N, K, d.flags, d.stride, d.ups), _launch, cands)
+        tile, split_k = _pick_tile((mode, M, N, K, d.flags, d.stride, d.ups, d.pad), _launch, cands)
     _set(tile, split_k)
     ev = _TIMER.start() if _TIMER is not None else None
     check(_lib.lib().avsd_gemm_bf16(C.byref(d), _stream()), "avsd_gemm_bf16")

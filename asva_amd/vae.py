@@ -2,8 +2,9 @@
 at avgen/pipelines/pipeline_audio_cond_animation.py:206-213 (`vae.decode(latents / scaling_factor).sample` over
 all b*f frames at once).  Same config keys and decoder-side state_dict names as diffusers 0.29.2's SD1.5
 `vae/` checkpoint; `.decode(z).sample`, `.config.scaling_factor`, `.config.block_out_channels`, `.dtype` are the
-members the pipeline touches.  The encoder half (image -> latent, once per clip, before the hot
-path) is out of scope for this round and raises.
+members the pipeline touches.  The encoder half (image -> latent, once per clip, the step right
+before the hot path: pipeline :198-203) runs on the same kernels: `.encode(x).latent_dist`
+with `.sample(generator)` / `.mode()`.
 
 As in asva_amd.unet the modules are parameter holders; decode() drives the gfx950 kernels: implicit-GEMM 3x3
 convs (nearest-2x upsample folded into the conv's gather), GroupNorm+SiLU, and the single-head mid-block
@@ -75,6 +76,60 @@ class _VaeUp(nn.Module):
             self.upsamplers = nn.ModuleList([_VaeUpsampler(cout)])
 
 
+class _VaeDownsampler(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = _Conv(c, c, 3)
+
+
+class _VaeDown(nn.Module):
+    def __init__(self, cin, cout, n, down):
+        super().__init__()
+        self.resnets = nn.ModuleList([_VaeRes(cin if j == 0 else cout, cout) for j in range(n)])
+        if down:
+            self.downsamplers = nn.ModuleList([_VaeDownsampler(cout)])
+
+
+class _Encoder(nn.Module):
+    def __init__(self, cin, latent, ch, layers):
+        super().__init__()
+        ch = list(ch)
+        self.conv_in = _Conv(cin, ch[0], 3)
+        self.down_blocks = nn.ModuleList()
+        prev = ch[0]
+        for i, c in enumerate(ch):
+            self.down_blocks.append(_VaeDown(prev, c, layers, i < len(ch) - 1))
+            prev = c
+        self.mid_block = _VaeMid(ch[-1])
+        self.conv_norm_out = _Affine(ch[-1])
+        self.conv_out = _Conv(ch[-1], 2 * latent, 3)
+
+
+class DiagonalGaussianDistribution:
+    """diffusers' posterior object: parameters (N, 2*latent, h, w) -> mean | logvar (clamped to [-30, 20])."""
+
+    def __init__(self, mean, logvar):
+        self.mean = mean
+        self.logvar = logvar.clamp(-30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+
+    def sample(self, generator=None, noise=None):
+        if noise is None:
+            noise = torch.randn(self.mean.shape, generator=generator, device=self.mean.device, dtype=self.mean.dtype)
+        return self.mean + self.std * noise
+
+    def mode(self):
+        return self.mean
+
+
+class EncoderOutput:
+    def __init__(self, latent_dist):
+        self.latent_dist = latent_dist
+
+    def __getitem__(self, i):
+        return (self.latent_dist,)[i]
+
+
 class _Decoder(nn.Module):
     def __init__(self, latent, out, ch, layers):
         super().__init__()
@@ -107,6 +162,8 @@ class AutoencoderKL(nn.Module):
                                     layers_per_block=layers_per_block, act_fn=act_fn, latent_channels=latent_channels,
                                     norm_num_groups=norm_num_groups, sample_size=sample_size, scaling_factor=scaling_factor,
                                     force_upcast=force_upcast)
+        self.encoder = _Encoder(in_channels, latent_channels, block_out_channels, layers_per_block)
+        self.quant_conv = _Conv(2 * latent_channels, 2 * latent_channels, 1)
         self.post_quant_conv = _Conv(latent_channels, latent_channels, 1)
         self.decoder = _Decoder(latent_channels, out_channels, block_out_channels, layers_per_block)
         self._packed = None
@@ -145,12 +202,10 @@ class AutoencoderKL(nn.Module):
         return model.eval()
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
-        """Accepts a full AutoencoderKL checkpoint: encoder.* / quant_conv.* are ignored (decode-only), legacy
-        attention names are mapped, legacy [C, C, 1, 1] attention weights are squeezed."""
+        """Accepts diffusers AutoencoderKL checkpoints of either vintage: legacy attention names
+        (query/key/value/proj_attn) are mapped and legacy [C, C, 1, 1] attention weights are squeezed."""
         sd = {}
         for k, v in state_dict.items():
-            if k.startswith("encoder.") or k.startswith("quant_conv."):
-                continue
             parts = k.split(".")
             if "attentions" in parts:
                 for old, new in _LEGACY_ATTN.items():
@@ -168,9 +223,34 @@ class AutoencoderKL(nn.Module):
         self._packed = None
         return r
 
-    def encode(self, *a, **k):
-        raise NotImplementedError("VAE encode (image -> latent, once per clip before the denoising path) is the "
-                                  "'next' row of SURVEY.md §8f; feed image latents directly")
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor, return_dict: bool = True):
+        """x: (N, 3, H, W) in [-1, 1] -> EncoderOutput(latent_dist) (pipeline :202 then does
+        `.latent_dist.sample() * scaling_factor`).  H, W multiples of 8."""
+        pk = self.pack()
+        dev = pk.blob.device
+        n, c, H, W = x.shape
+        groups = self.config.norm_num_groups
+        e = pk.enc
+        h = ops.ncfhw_to_rows(x.to(device=dev, dtype=torch.float32).reshape(n, c, 1, H, W).contiguous(), cpad=8)
+        hw = (H, W)
+        h = ops.gemm(h, e.conv_in.w, bias=e.conv_in.b, mode=ops.CONV3, conv=(n, H, W, 1, 0))
+        for blk in e.down:
+            for r in blk.resnets:
+                h = self._res(h, r, n, hw, groups)
+            if blk.down is not None:      # Downsample2D(padding=0): F.pad(0,1,0,1) then stride-2 conv == top/left pad 0
+                h = ops.gemm(h, blk.down.w, bias=blk.down.b, mode=ops.CONV3, conv=(n, hw[0], hw[1], 2, 0, 0))
+                hw = (hw[0] // 2, hw[1] // 2)
+        h = self._res(h, e.mid[0], n, hw, groups)
+        h = self._mid_attention(h, e.attn, n, hw, groups)
+        h = self._res(h, e.mid[1], n, hw, groups)
+        a = ops.groupnorm(h, None, n, hw[0] * hw[1], groups, e.norm_out.g, e.norm_out.b, 1e-6, True)
+        h = ops.gemm(a, e.conv_out.w, bias=e.conv_out.b, mode=ops.CONV3, conv=(n, hw[0], hw[1], 1, 0))
+        m = ops.gemm(h, e.quant.w, bias=e.quant.b, out_f32=True)                               # quant_conv 1x1 -> moments
+        lat = self.config.latent_channels
+        m = ops.rows_to_ncfhw(m, n, 2 * lat, 1, hw[0], hw[1]).reshape(n, 2 * lat, hw[0], hw[1])
+        dist = DiagonalGaussianDistribution(m[:, :lat].contiguous(), m[:, lat:].contiguous())
+        return EncoderOutput(dist) if return_dict else (dist,)
 
     # ---- packing -----------------------------------------------------------------------------------------------
     def pack(self, device=None):
@@ -212,16 +292,24 @@ class AutoencoderKL(nn.Module):
             return _Pk(norm1=aff(m.norm1), conv1=conv3(m.conv1), norm2=aff(m.norm2), conv2=conv3(m.conv2),
                        shortcut=conv1(m.conv_shortcut) if hasattr(m, "conv_shortcut") else None)
 
+        def attn(at):
+            return _Pk(norm=aff(at.group_norm),
+                       wqk=reg(pack_linear(torch.cat([at.to_q.weight, at.to_k.weight], 0).float())),
+                       bqk=reg(torch.cat([at.to_q.bias, at.to_k.bias], 0).detach().float()),
+                       wv=reg(pack_linear(at.to_v.weight.float())), bv=reg(at.to_v.bias.detach().float()),
+                       wo=reg(pack_linear(at.to_out[0].weight.float())), bo=reg(at.to_out[0].bias.detach().float()),
+                       dim=at.to_q.weight.shape[0])
+
         d = self.decoder
-        at = d.mid_block.attentions[0]
-        pk = _Pk(pq=conv1(self.post_quant_conv), conv_in=conv3(d.conv_in),
+        en = self.encoder
+        enc = _Pk(conv_in=conv3(en.conv_in),
+                  down=[_Pk(resnets=[res(r) for r in b.resnets],
+                            down=conv3(b.downsamplers[0].conv) if hasattr(b, "downsamplers") else None) for b in en.down_blocks],
+                  mid=[res(en.mid_block.resnets[0]), res(en.mid_block.resnets[1])], attn=attn(en.mid_block.attentions[0]),
+                  norm_out=aff(en.conv_norm_out), conv_out=conv3(en.conv_out), quant=conv1(self.quant_conv))
+        pk = _Pk(enc=enc, pq=conv1(self.post_quant_conv), conv_in=conv3(d.conv_in),
                  mid=[res(d.mid_block.resnets[0]), res(d.mid_block.resnets[1])],
-                 attn=_Pk(norm=aff(at.group_norm),
-                          wqk=reg(pack_linear(torch.cat([at.to_q.weight, at.to_k.weight], 0).float())),
-                          bqk=reg(torch.cat([at.to_q.bias, at.to_k.bias], 0).detach().float()),
-                          wv=reg(pack_linear(at.to_v.weight.float())), bv=reg(at.to_v.bias.detach().float()),
-                          wo=reg(pack_linear(at.to_out[0].weight.float())), bo=reg(at.to_out[0].bias.detach().float()),
-                          dim=at.to_q.weight.shape[0]),
+                 attn=attn(d.mid_block.attentions[0]),
                  up=[_Pk(resnets=[res(r) for r in u.resnets],
                          up=conv3(u.upsamplers[0].conv) if hasattr(u, "upsamplers") else None) for u in d.up_blocks],
                  norm_out=aff(d.conv_norm_out), conv_out=conv3(d.conv_out))
@@ -292,6 +380,18 @@ class AutoencoderKL(nn.Module):
         s = x if p.shortcut is None else ops.gemm(x, p.shortcut.w, bias=p.shortcut.b)
         return ops.gemm(a, p.conv2.w, bias=p.conv2.b, res1=s, mode=ops.CONV3, conv=(n, hw[0], hw[1], 1, 0))
 
+    def _mid_attention(self, x, a, n, hw, groups):
+        """mid-block attention, one head of width C: S = QK^T/sqrt(C) (f32) -> softmax -> P V ; V^T comes straight out of
+        a GEMM with the roles swapped, and V's bias is added after P.V (softmax rows sum to 1)"""
+        C, L = a.dim, hw[0] * hw[1]
+        xn = ops.groupnorm(x, None, n, L, groups, a.norm.g, a.norm.b, 1e-6, False)
+        qk = ops.gemm(xn, a.wqk, bias=a.bqk).view(n, L, 2 * C)
+        s = ops.gemm_batched(qk[:, :, :C], qk[:, :, C:], alpha=float(C) ** -0.5, out_f32=True)      # [n, L, L]
+        p = ops.softmax_rows(s.view(n * L, L)).view(n, L, L)
+        vt = ops.gemm_batched(a.wv.unsqueeze(0).expand(n, C, C), xn.view(n, L, C))                  # [n, C, L] = V^T
+        o = ops.gemm_batched(p, vt, bias=a.bv).view(n * L, C)
+        return ops.gemm(o, a.wo, bias=a.bo, res1=x)
+
     def _decode_rows(self, pk, z32, postprocess=False):
         n, c, h, w = z32.shape
         groups = self.config.norm_num_groups
@@ -300,17 +400,7 @@ class AutoencoderKL(nn.Module):
         hw = (h, w)
         x = ops.gemm(x, pk.conv_in.w, bias=pk.conv_in.b, mode=ops.CONV3, conv=(n, h, w, 1, 0))
         x = self._res(x, pk.mid[0], n, hw, groups)
-        # mid-block attention, one head of width C: S = QK^T/sqrt(C) (f32) -> softmax -> P V ; V^T comes straight
-        # out of a GEMM with the roles swapped, and V's bias is added after P.V (softmax rows sum to 1)
-        a = pk.attn
-        C, L = a.dim, h * w
-        xn = ops.groupnorm(x, None, n, L, groups, a.norm.g, a.norm.b, 1e-6, False)
-        qk = ops.gemm(xn, a.wqk, bias=a.bqk).view(n, L, 2 * C)
-        s = ops.gemm_batched(qk[:, :, :C], qk[:, :, C:], alpha=float(C) ** -0.5, out_f32=True)      # [n, L, L]
-        p = ops.softmax_rows(s.view(n * L, L)).view(n, L, L)
-        vt = ops.gemm_batched(a.wv.unsqueeze(0).expand(n, C, C), xn.view(n, L, C))                  # [n, C, L] = V^T
-        o = ops.gemm_batched(p, vt, bias=a.bv).view(n * L, C)
-        x = ops.gemm(o, a.wo, bias=a.bo, res1=x)
+        x = self._mid_attention(x, pk.attn, n, hw, groups)
         x = self._res(x, pk.mid[1], n, hw, groups)
         for u in pk.up:
             for r in u.resnets:

@@ -59,7 +59,7 @@ int avsd_device_info(char* name_host, int len, int* num_cu_host);
  *   AVSD_GEMM_CONV3  implicit-GEMM 3x3 pad-1 convolution over channels-last images
  *                    (utils.py:37-38 -> nn.Conv2d): K = 9*cin (tap-major, cin-minor),
  *                    row m = (n, ho, wo); stride 1 or 2; `ups`=1 reads the input through a
- *                    nearest x2 upsample (ff_spatio_temp_resnet_3d.py:48).
+ *                    nearest x2 upsample (ff_spatio_temp_resnet_3d.py:48); `pad` = top/left padding.
  *
  * epilogue, in f32:  v = alpha*acc + bias[n] + rowvec[(m / rows_per_vec)*ldv + n]
  *                                   + res1[m*ldr1 + n] + res2[m*ldr2 + n]
@@ -91,6 +91,8 @@ typedef struct avsd_gemm_desc {
   int32_t hw, frames, cseg;
   /* CONV3: source image (hs, ws) with cin channels at row stride lda; output (ho, wo) */
   int32_t hs, ws, ho, wo, cin, stride, ups;
+  int32_t pad;                          /* CONV3 top/left zero padding: 1 (symmetric "padding=1") or 0 (the VAE encoder's
+                                           F.pad(0,1,0,1) + stride-2 conv); bottom/right reads beyond the image are zero */
   int32_t tile;                         /* 0 = library heuristic; 1..3 register-staged tiles, 4..10 LDS-direct
                                            tiles (see gemm.hip dispatch_tile) */
   /* split-K (LDS-direct tiles only): K is cut into split_k slices computed by separate workgroups that

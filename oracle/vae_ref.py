@@ -64,6 +64,73 @@ def vae_decode(sd, cfg, z):
     return _conv(h, sd, "decoder.conv_out", 1)
 
 
+def vae_encode_moments(sd, cfg, x):
+    """AutoencoderKL.encode up to the posterior parameters (pipeline :198-203 calls `.latent_dist.sample()` on it):
+    Encoder = conv_in -> 4 DownEncoderBlock2D (2 resnets each; Downsample2D = F.pad(0,1,0,1) + 3x3 stride-2 conv,
+    padding 0, after the first three) -> mid block (resnet, attention, resnet) -> GroupNorm(eps 1e-6) -> SiLU ->
+    conv_out (2*latent channels) -> quant_conv 1x1.  x: (N, 3, H, W) in [-1, 1] -> (mean, logvar) each (N, 4, H/8, W/8);
+    logvar clamped to [-30, 20] (DiagonalGaussianDistribution)."""
+    sd = {k: v.float() for k, v in sd.items()}
+    groups = cfg["norm_num_groups"]
+    nblk = len(cfg["block_out_channels"])
+    h = _conv(x.float(), sd, "encoder.conv_in", 1)
+    for i in range(nblk):
+        for j in range(cfg["layers_per_block"]):
+            h = resnet(h, sd, f"encoder.down_blocks.{i}.resnets.{j}", groups)
+        if i < nblk - 1:
+            p = f"encoder.down_blocks.{i}.downsamplers.0.conv"
+            h = F.conv2d(F.pad(h, (0, 1, 0, 1)), sd[p + ".weight"], sd[p + ".bias"], stride=2)
+    h = resnet(h, sd, "encoder.mid_block.resnets.0", groups)
+    h = mid_attention(h, sd, "encoder.mid_block.attentions.0", groups)
+    h = resnet(h, sd, "encoder.mid_block.resnets.1", groups)
+    h = F.silu(F.group_norm(h, groups, sd["encoder.conv_norm_out.weight"], sd["encoder.conv_norm_out.bias"], 1e-6))
+    h = _conv(h, sd, "encoder.conv_out", 1)
+    m = _conv(h, sd, "quant_conv")
+    mean, logvar = m.chunk(2, dim=1)
+    return mean, logvar.clamp(-30.0, 20.0)
+
+
+def encoder_shapes(cfg) -> dict:
+    """name -> shape of the encoder-side state_dict (encoder.* + quant_conv)."""
+    ch = list(cfg["block_out_channels"])
+    lat = cfg["latent_channels"]
+    s = {}
+
+    def conv(p, ci, co, k):
+        s[p + ".weight"] = (co, ci, k, k)
+        s[p + ".bias"] = (co,)
+
+    def norm(p, c):
+        s[p + ".weight"] = (c,)
+        s[p + ".bias"] = (c,)
+
+    def res(p, ci, co):
+        norm(p + ".norm1", ci); conv(p + ".conv1", ci, co, 3); norm(p + ".norm2", co); conv(p + ".conv2", co, co, 3)
+        if ci != co:
+            conv(p + ".conv_shortcut", ci, co, 1)
+
+    conv("encoder.conv_in", cfg["in_channels"], ch[0], 3)
+    prev = ch[0]
+    for i, co in enumerate(ch):
+        for j in range(cfg["layers_per_block"]):
+            res(f"encoder.down_blocks.{i}.resnets.{j}", prev if j == 0 else co, co)
+        if i < len(ch) - 1:
+            conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", co, co, 3)
+        prev = co
+    top = ch[-1]
+    res("encoder.mid_block.resnets.0", top, top)
+    a = "encoder.mid_block.attentions.0"
+    norm(a + ".group_norm", top)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        s[f"{a}.{n}.weight"] = (top, top)
+        s[f"{a}.{n}.bias"] = (top,)
+    res("encoder.mid_block.resnets.1", top, top)
+    norm("encoder.conv_norm_out", top)
+    conv("encoder.conv_out", top, 2 * lat, 3)
+    conv("quant_conv", 2 * lat, 2 * lat, 1)
+    return s
+
+
 def decoder_shapes(cfg) -> dict:
     """name -> shape of the decoder-side state_dict (post_quant_conv + decoder.*), from the architecture."""
     ch = list(cfg["block_out_channels"])

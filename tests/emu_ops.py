@@ -29,12 +29,18 @@ def gemm(a, w, *, n=None, k=None, a2=None, bias=None, rowvec=None, rows_per_vec=
         prev = torch.cat([y[:, :1], y[:, :-1]], 1)
         x = torch.cat([y[:, :1].expand_as(y), prev, y], -1).reshape(-1, 3 * C)
     else:
-        n_img, hs, ws, stride, ups = conv
+        n_img, hs, ws, stride, ups = conv[:5]
+        pad = conv[5] if len(conv) > 5 else 1
         cin = a.shape[1]
         xi = a.float().reshape(n_img, hs, ws, cin).permute(0, 3, 1, 2)
         if ups:
             xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
-        cols = F.unfold(xi, 3, padding=1, stride=stride)                      # [n, cin*9, L] (c-major, tap-minor)
+        xi = F.pad(xi, (pad, 1, pad, 1))                  # top/left = pad, bottom/right: reads past the image are zero
+        cols = F.unfold(xi, 3, padding=0, stride=stride)
+        ho = ((hs << ups) - 1) // stride + 1
+        wo = ((ws << ups) - 1) // stride + 1
+        full_w = (xi.shape[-1] - 3) // stride + 1
+        cols = cols.reshape(n_img, cin * 9, -1, full_w)[:, :, :ho, :wo].reshape(n_img, cin * 9, ho * wo)                      # [n, cin*9, L] (c-major, tap-minor)
         L = cols.shape[-1]
         x = cols.reshape(n_img, cin, 9, L).permute(0, 3, 2, 1).reshape(n_img * L, 9 * cin)   # tap-major, c-minor
     assert x.shape[1] == wf.shape[1], (x.shape, wf.shape)

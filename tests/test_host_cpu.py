@@ -141,15 +141,36 @@ def _filled_vae(cfg):
     return m
 
 
-def test_vae_state_dict_surface_matches_sd15_decoder():
+def test_vae_state_dict_surface_matches_sd15():
     from asva_amd.vae import AutoencoderKL
-    from oracle.vae_ref import SD15_VAE_CONFIG, decoder_shapes
+    from oracle.vae_ref import SD15_VAE_CONFIG, decoder_shapes, encoder_shapes
 
     with torch.device("meta"):
         m = AutoencoderKL.from_config(SD15_VAE_CONFIG)
-    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == decoder_shapes(SD15_VAE_CONFIG)
-    assert sum(v.numel() for v in m.state_dict().values()) == 49490199
+    want = dict(decoder_shapes(SD15_VAE_CONFIG))
+    want.update(encoder_shapes(SD15_VAE_CONFIG))
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == want
+    assert sum(v.numel() for k, v in m.state_dict().items() if k.startswith(("decoder.", "post_quant"))) == 49490199
+    assert sum(v.numel() for v in m.state_dict().values()) == 83653863          # the SD1.5 AutoencoderKL
     assert m.config.scaling_factor == 0.18215 and len(m.config.block_out_channels) == 4
+
+
+def test_vae_encode_orchestration_vs_oracle(monkeypatch):
+    import asva_amd.vae as vae_mod
+    from oracle.vae_ref import vae_encode_moments
+
+    monkeypatch.setattr(vae_mod, "ops", emu_ops)
+    m = _filled_vae(TINY_VAE)
+    x = torch.rand(2, 3, 32, 48, generator=torch.Generator().manual_seed(0)) * 2 - 1
+    mean, logvar = vae_encode_moments(m.state_dict(), TINY_VAE, x)
+    dist = m.encode(x).latent_dist
+    assert dist.mean.shape == (2, 4, 4, 6)
+    assert rel_l2(dist.mean, mean) < 3e-2 and rel_l2(dist.logvar, logvar) < 3e-2
+    noise = torch.randn(2, 4, 4, 6, generator=torch.Generator().manual_seed(1))
+    assert rel_l2(dist.sample(noise=noise), mean + torch.exp(0.5 * logvar) * noise) < 3e-2
+    assert torch.equal(dist.mode(), dist.mean)
+    g1, g2 = torch.Generator().manual_seed(5), torch.Generator().manual_seed(5)
+    assert torch.equal(dist.sample(generator=g1), dist.sample(generator=g2))
 
 
 def test_vae_decode_orchestration_vs_oracle(monkeypatch):
@@ -172,22 +193,59 @@ def test_vae_decode_orchestration_vs_oracle(monkeypatch):
     assert rel_l2(chunked, out) < 2e-2   # (different GEMM batch sizes: last-bit f32 differences flip bf16 roundings)
 
 
-def test_vae_accepts_full_and_legacy_checkpoints():
+def test_vae_accepts_legacy_checkpoint_names():
     m = _filled_vae(TINY_VAE)
-    sd = dict(m.state_dict())
-    sd["encoder.conv_in.weight"] = torch.zeros(1)
-    sd["quant_conv.weight"] = torch.zeros(1)
     legacy = {}
-    for k, v in sd.items():
+    for k, v in m.state_dict().items():
         for new, old in (("to_q", "query"), ("to_k", "key"), ("to_v", "value"), ("to_out.0", "proj_attn")):
             if f"attentions.0.{new}." in k:
                 k = k.replace(f"attentions.0.{new}.", f"attentions.0.{old}.")
                 if k.endswith("weight"):
                     v = v[:, :, None, None]
         legacy[k] = v
+    assert any(".query." in k for k in legacy)
     m2 = _filled_vae(TINY_VAE)
+    with torch.no_grad():
+        for p in m2.parameters():
+            p.zero_()
     m2.load_state_dict(legacy)
     for (k1, v1), (k2, v2) in zip(sorted(m.state_dict().items()), sorted(m2.state_dict().items())):
         assert k1 == k2 and torch.equal(v1, v2)
-    with pytest.raises(NotImplementedError):
-        m.encode(torch.zeros(1, 3, 8, 8))
+
+
+def test_from_pretrained_2d_inflation(tmp_path):
+    """2-D -> 3-D inflation (audio_cond_unet_3d_condition.py:800-838): every key containing '_temp', every key missing
+    from the 2-D checkpoint (audio attention) and every shape mismatch keeps the fresh 3-D init; the rest is loaded."""
+    import json
+
+    from safetensors.torch import save_file
+
+    from asva_amd.unet import AudioUNet3DConditionModel
+
+    g = load_golden("unet_tiny_e2e.pt")
+    src = filled_unet(g["config"])
+    sd2d = {k: v.clone() for k, v in src.state_dict().items() if "_temp" not in k and "audio" not in k}
+    sd2d["conv_in.weight"] = torch.zeros(80, 9, 3, 3)                      # a shape mismatch must be ignored
+    cfg2d = {k: (list(v) if isinstance(v, tuple) else v) for k, v in g["config"].items()}
+    cfg2d.update(_class_name="UNet2DConditionModel", _diffusers_version="0.29.2",
+                 down_block_types=["CrossAttnDownBlock2D"] * 3 + ["DownBlock2D"], mid_block_type="UNetMidBlock2DCrossAttn",
+                 up_block_types=["UpBlock2D"] + ["CrossAttnUpBlock2D"] * 3)
+    cfg2d.pop("audio_cross_attention_dim")
+    d = tmp_path / "sd" / "unet"
+    d.mkdir(parents=True)
+    json.dump(cfg2d, open(d / "config.json", "w"))
+    save_file({k: v.contiguous() for k, v in sd2d.items()}, str(d / "diffusion_pytorch_model.safetensors"))
+    cfg3d = dict(down_block_types=g["config"]["down_block_types"], up_block_types=g["config"]["up_block_types"],
+                 mid_block_type=g["config"]["mid_block_type"], audio_cross_attention_dim=64)
+    m = AudioUNet3DConditionModel.from_pretrained_2d(cfg3d, str(tmp_path / "sd"), subfolder="unet")
+    assert m.config.down_block_types == tuple(g["config"]["down_block_types"]) and m.config.audio_cross_attention_dim == 64
+    got = m.state_dict()
+    for k, v in src.state_dict().items():
+        if k == "conv_in.weight":
+            assert not torch.equal(got[k], torch.zeros_like(got[k])) and got[k].shape == v.shape      # fresh init kept
+        elif "conv_temp" in k or k.endswith("attn_temp.to_out.0.weight"):
+            assert float(got[k].abs().sum()) == 0                                                     # zero-initialised temporal path
+        elif "_temp" in k or "audio" in k:
+            assert not torch.equal(got[k], v)                                                         # fresh, not the source's filler
+        else:
+            assert torch.equal(got[k], v), k

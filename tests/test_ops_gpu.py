@@ -186,6 +186,21 @@ def test_gemm_split_k(ops, tile, split):
     assert rel_l2(out, torch.cat([a1, a2], 1).float() @ w2.float().T) < TOL_F32
 
 
+@pytest.mark.parametrize("tile", [0, 3, 4, 6, 13, 17])
+def test_gemm_conv3x3_stride2_asymmetric_pad(ops, tile):
+    """VAE encoder Downsample2D: F.pad(x, (0, 1, 0, 1)) then 3x3 stride-2 conv with padding 0."""
+    from asva_amd.weights import pack_conv3x3
+
+    n_img, hs, ws, cin, cout = 2, 16, 24, 128, 128
+    x = rnd(n_img * hs * ws, cin, seed=1)
+    w = rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5)
+    b = rndf(cout, seed=3)
+    out = ops.gemm(x, pack_conv3x3(w), bias=b, mode=ops.CONV3, conv=(n_img, hs, ws, 2, 0, 0), tile=tile)
+    xi = F.pad(x.float().reshape(n_img, hs, ws, cin).permute(0, 3, 1, 2), (0, 1, 0, 1))
+    ref = F.conv2d(xi, w.float(), b, stride=2).permute(0, 2, 3, 1).reshape(-1, cout)
+    assert out.shape == ref.shape and rel_l2(out, ref) < TOL_BF16
+
+
 def test_gemm_batched_f32(ops):
     B, M, N, K = 3, 256, 192, 512
     a, w = rnd(B, M, K, seed=1), rnd(B, N, K, seed=2)

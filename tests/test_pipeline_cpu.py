@@ -65,6 +65,26 @@ def test_pipeline_matches_oracle_pipeline(emu, kind):
     assert torch.is_tensor(bare) and bare.shape == vid.shape
 
 
+def test_pipeline_encodes_the_conditioning_image(emu):
+    """images= path (pipeline :309-310): preprocess to [-1, 1], vae.encode(...).latent_dist.sample() * 0.18215."""
+    from asva_amd.schedulers import DDIMScheduler
+    from oracle.vae_ref import vae_encode_moments
+
+    g = load_golden("unet_tiny_e2e.pt")
+    c = _clip(g)
+    pipe, unet, vae = _pipe(g, DDIMScheduler())
+    img = torch.rand(3, *c["hw"], generator=torch.Generator().manual_seed(2))          # (3, H, W) in [0, 1]
+    kw = dict(images=[img], texts=[""], text_encodings=[c["text"]], video_length=c["f"], height=c["hw"][0], width=c["hw"][1],
+              num_inference_steps=1, audio_guidance_scale=4.0, audio_encodings=c["audio"], null_audio_encodings=c["null_audio"],
+              audio_masks=c["mask"], noise=c["noise"], output_latents=True)
+    torch.manual_seed(11)                     # the reference samples the image latent from the GLOBAL generator (:202)
+    lat = pipe(**kw)
+    mean, logvar = vae_encode_moments(vae.state_dict(), TINY_VAE, img[None] * 2 - 1)
+    torch.manual_seed(11)
+    want = (mean + torch.exp(0.5 * logvar) * torch.randn(mean.shape)) * 0.18215
+    assert rel_l2(lat[:, :, 0], want) < 3e-2
+
+
 def test_engine_loop_equals_reference_style_loop(emu):
     from asva_amd.schedulers import PNDMScheduler
 

@@ -27,6 +27,22 @@ def test_sd15_vae_decoder_matches_oracle():
     assert rel_l2(vid[0], (ref / 2 + 0.5).clamp(0, 1)) < 3e-2 and float(vid.min()) >= 0 and float(vid.max()) <= 1
 
 
+def test_sd15_vae_encoder_matches_oracle():
+    from oracle.vae_ref import SD15_VAE_CONFIG, vae_encode_moments
+
+    vae = _filled_vae(SD15_VAE_CONFIG)
+    x = torch.rand(2, 3, 128, 96, generator=torch.Generator().manual_seed(0)) * 2 - 1
+    mean, logvar = vae_encode_moments(vae.state_dict(), SD15_VAE_CONFIG, x)
+    vae = vae.to("cuda")
+    dist = vae.encode(x.cuda()).latent_dist
+    e1, e2 = rel_l2(dist.mean, mean), rel_l2(dist.logvar, logvar)
+    print(f"SD1.5 VAE encode (2 x 128x96): mean rel-L2 {e1:.3e}, logvar rel-L2 {e2:.3e}")
+    assert dist.mean.shape == (2, 4, 16, 12) and e1 < 3e-2 and e2 < 3e-2
+    # encode -> decode round trip stays finite and image-shaped
+    out = vae.decode(dist.mode()).sample
+    assert out.shape == (2, 3, 128, 96) and bool(torch.isfinite(out).all())
+
+
 def test_vae_decode_full_clip_shape_is_finite_and_chunking_is_consistent():
     from oracle.vae_ref import SD15_VAE_CONFIG
 

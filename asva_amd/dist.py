@@ -21,7 +21,8 @@ def env_rank_world():
 
 def init_process_group(backend: str | None = None) -> None:
     rank, local_rank, world = env_rank_world()
-    if world <= 1 or dist.is_initialized():
+    force = os.environ.get("AVSD_FORCE_DIST") == "1"      # lets a 1-GPU box exercise the RCCL calls (world size 1)
+    if (world <= 1 and not force) or dist.is_initialized():
         return
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
@@ -41,7 +42,7 @@ def broadcast_blob(blob: torch.Tensor, src: int = 0) -> torch.Tensor:
     """One collective for all weights: the packed uint8 blob (UNet ~2.4 GB bf16) from `src` to every rank.
     xGMI is point-to-point, so RCCL runs this as a ring/tree at per-link rate; it happens once, outside the
     denoising loop."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.broadcast(blob, src=src)
     return blob
 
@@ -49,7 +50,7 @@ def broadcast_blob(blob: torch.Tensor, src: int = 0) -> torch.Tensor:
 def gather_metrics(values: Sequence[float], device=None) -> List[List[float]]:
     """all-gather of a few floats per rank (clips, steps, seconds, ...)."""
     t = torch.tensor(list(values), dtype=torch.float64, device=device)
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not dist.is_initialized():
         return [t.tolist()]
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
@@ -57,5 +58,5 @@ def gather_metrics(values: Sequence[float], device=None) -> List[List[float]]:
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.barrier()

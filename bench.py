@@ -216,4 +216,10 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:
+        import torch.distributed as _d
+
+        if _d.is_available() and _d.is_initialized():
+            _d.destroy_process_group()

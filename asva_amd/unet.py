@@ -328,6 +328,7 @@ class AudioUNet3DConditionModel(nn.Module):
         self._packed = None
         self._cond = None
         self._cond_key = None
+        self._cond_refs = None
 
     # ---- config / (de)serialisation surface ---------------------------------------------------------
     @property
@@ -453,6 +454,7 @@ class AudioUNet3DConditionModel(nn.Module):
         self._packed = None
         self._cond = None
         self._cond_key = None
+        self._cond_refs = None
 
     # attention-processor plug-in protocol of the reference (:469-527).  The fused gfx950 kernels ARE the
     # processor on this path; the hooks exist so callers that enumerate / reset processors keep working.
@@ -724,8 +726,12 @@ class AudioUNet3DConditionModel(nn.Module):
             key = tuple((t.data_ptr(), tuple(t.shape), t._version) if t is not None else None
                         for t in (encoder_hidden_states, audio_encoder_hidden_states, audio_attention_mask)) + (Fr,)
             if self._cond is None or self._cond_key != key:
+                self._cond_key = None
                 self.set_conditioning(encoder_hidden_states, audio_encoder_hidden_states, audio_attention_mask, Fr)
                 self._cond_key = key
+                # keep the keyed tensors alive: their addresses cannot be recycled for different data while the
+                # (data_ptr, shape, version) key is in use
+                self._cond_refs = (encoder_hidden_states, audio_encoder_hidden_states, audio_attention_mask)
         if self._cond is None:
             raise RuntimeError("no conditioning: pass encoder_hidden_states or call set_conditioning first")
         dev = pk.blob.device

@@ -249,3 +249,49 @@ def test_from_pretrained_2d_inflation(tmp_path):
             assert not torch.equal(got[k], v)                                                         # fresh, not the source's filler
         else:
             assert torch.equal(got[k], v), k
+
+
+def test_non_audio_block_types_and_input_validation(emulated):
+    """The reference also ships block types without the audio cross-attention (unet_3d_blocks.py:372-702,
+    ff_spatio_temp_transformer_3d.py); they are constructible and run through the same kernels.  Also: the error
+    behaviour of forward() on inputs the path does not take."""
+    from asva_amd.unet import AudioUNet3DConditionModel
+    from oracle.filler import fill_module_
+    from oracle.unet_ref import unet_forward
+
+    cfg = dict(load_golden("unet_tiny_e2e.pt")["config"])
+    cfg["down_block_types"] = ["FFSpatioTempCrossAttnDownBlock3D"] * 3 + ["FFSpatioTempResDownBlock3D"]
+    cfg["up_block_types"] = ["FFSpatioTempResUpBlock3D"] + ["FFSpatioTempCrossAttnUpBlock3D"] * 3
+    cfg["mid_block_type"] = "FFSpatioTempCrossAttnUNetMidBlock3D"
+    m = AudioUNet3DConditionModel.from_config(cfg).eval()
+    fill_module_(m)
+    assert not any("audio" in k for k in m.state_dict())
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 4, 3, 8, 8, generator=gen)
+    text = torch.randn(1, 7, 64, generator=gen)
+    out = m(x, 77, text).sample                                        # 3-D text, no audio, no mask
+    ref = unet_forward(m.state_dict(), cfg, x, 77, text[:, None].expand(1, 3, 7, 64), torch.zeros(1, 3, 229, 64), None)
+    assert rel_l2(out, ref) < 3e-2
+    # input validation
+    g = load_golden("unet_tiny_e2e.pt")
+    full = filled_unet(g["config"])
+    with pytest.raises(ValueError, match="audio_encoder_hidden_states is required"):
+        full(g["sample"], 1, g["text"])
+    with pytest.raises(NotImplementedError, match="multiples of"):
+        full(torch.zeros(2, 4, 4, 6, 8), 1, g["text"], g["audio"], audio_attention_mask=g["mask"])
+    with pytest.raises(NotImplementedError, match="class_labels"):
+        full(g["sample"], 1, g["text"], g["audio"], class_labels=torch.zeros(2))
+    with pytest.raises(AssertionError):
+        full(g["sample"][:, :, 0], 1, g["text"], g["audio"])
+    full(g["sample"], 1, g["text"], g["audio"], audio_attention_mask=g["mask"])
+    with pytest.raises(ValueError, match="conditioning was prepared for batch"):
+        full(g["sample"][:1], 1)                                       # cached conditioning is for batch 2
+    # an all-visible mask (or None) attends to all 229 keys
+    a = full(g["sample"], 1, g["text"], g["audio"], audio_attention_mask=None).sample
+    b = full(g["sample"], 1, g["text"], g["audio"], audio_attention_mask=torch.ones(4, 229, dtype=torch.bool)).sample
+    assert torch.equal(a, b)
+    # ragged masks (different number of visible keys per frame) cannot be a gather list
+    ragged = g["mask"].clone()
+    ragged[0, 5] = True
+    with pytest.raises(ValueError, match="different numbers of keys"):
+        full(g["sample"], 1, g["text"], g["audio"], audio_attention_mask=ragged)

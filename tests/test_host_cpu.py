@@ -292,6 +292,7 @@ def test_non_audio_block_types_and_input_validation(emulated):
     assert torch.equal(a, b)
     # ragged masks (different number of visible keys per frame) cannot be a gather list
     ragged = g["mask"].clone()
-    ragged[0, 5] = True
+    assert not bool(ragged[0, 6])
+    ragged[0, 6] = True
     with pytest.raises(ValueError, match="different numbers of keys"):
         full(g["sample"], 1, g["text"], g["audio"], audio_attention_mask=ragged)

@@ -132,6 +132,19 @@ __global__ void vae_postprocess_kernel(const bf16_t* src, int ld, float* dst, in
   }
 }
 
+// channels-last bf16 rows [N*HW][ld] -> uint8 frames (N, H, W, 3): (clamp(x/2+0.5, 0, 1) * 255) truncated, i.e. the
+// pipeline's post-processing (:212) followed by generate_videos' `(video.permute(0,2,3,1) * 255).byte()` (:448)
+__global__ void vae_postprocess_u8_kernel(const bf16_t* src, int ld, uint8_t* dst, int64_t npix) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+    const bf16_t* s = src + i * ld;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = fminf(fmaxf(bf2f(s[c]) * 0.5f + 0.5f, 0.f), 1.f);
+      dst[i * 3 + c] = (uint8_t)(v * 255.0f);
+    }
+  }
+}
+
 inline unsigned grid_for(int64_t n, int block) {
   int64_t g = (n + block - 1) / block;
   if (g > 4096) g = 4096;
@@ -207,5 +220,14 @@ extern "C" int avsd_vae_postprocess(const void* src, int ld, float* dst, int N, 
   hipLaunchKernelGGL(vae_postprocess_kernel, dim3(grid_for(n, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      (const bf16_t*)src, ld, dst, N, HW);
   AVSD_CHECK_LAUNCH("vae_postprocess launch");
+  return AVSD_OK;
+}
+
+extern "C" int avsd_vae_postprocess_u8(const void* src, int ld, void* dst, int N, int HW, void* stream) {
+  AVSD_REQUIRE(src && dst && N > 0 && HW > 0 && ld >= 3, "vae_postprocess_u8: bad arguments");
+  const int64_t n = (int64_t)N * HW;
+  hipLaunchKernelGGL(vae_postprocess_u8_kernel, dim3(grid_for(n, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     (const bf16_t*)src, ld, (uint8_t*)dst, n);
+  AVSD_CHECK_LAUNCH("vae_postprocess_u8 launch");
   return AVSD_OK;
 }

@@ -433,3 +433,10 @@ def vae_postprocess(rows: torch.Tensor, n_img: int, H: int, W: int) -> torch.Ten
     out = torch.empty((n_img, 3, H, W), dtype=F32, device=rows.device)
     check(_lib.lib().avsd_vae_postprocess(_p(rows), _ld(rows), _p(out), n_img, H * W, _stream()), "avsd_vae_postprocess")
     return out
+
+
+def vae_postprocess_u8(rows: torch.Tensor, n_img: int, H: int, W: int) -> torch.Tensor:
+    _req(rows, BF16, "rows")
+    out = torch.empty((n_img, H, W, 3), dtype=torch.uint8, device=rows.device)
+    check(_lib.lib().avsd_vae_postprocess_u8(_p(rows), _ld(rows), _p(out), n_img, H * W, _stream()), "avsd_vae_postprocess_u8")
+    return out

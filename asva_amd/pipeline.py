@@ -175,7 +175,8 @@ class AudioCondAnimationPipeline:
     def __call__(self, images=None, audios=None, texts=None, text_encodings=None, video_length: int = 12, height: int = 256,
                  width: int = 256, num_inference_steps: int = 20, audio_guidance_scale: float = 4.0,
                  text_guidance_scale: float = 1.0, generator=None, return_dict: bool = True, *, image_latents=None,
-                 audio_encodings=None, null_audio_encodings=None, audio_masks=None, noise=None, output_latents: bool = False):
+                 audio_encodings=None, null_audio_encodings=None, audio_masks=None, noise=None, output_latents: bool = False,
+                 output_type: str = "float"):
         device = self.device
         f32 = torch.float32
         do_text = text_guidance_scale > 1.0
@@ -209,6 +210,9 @@ class AudioCondAnimationPipeline:
                                                  do_audio, audio_guidance_scale, text_guidance_scale)
         if output_latents:
             return latents
+        if output_type == "uint8":          # (b, f, H, W, 3) uint8 CPU frames, converted on the device
+            frames = self.vae.decode_to_uint8_frames(latents).cpu()
+            return {"videos": frames} if return_dict else frames
         b, c, f, h, w = latents.shape
         videos = self.decode_latents(latents.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w))
         videos = videos.reshape(b, f, *videos.shape[1:])
@@ -314,12 +318,12 @@ def generate_videos(pipeline, image_path: str = "", audio_path: str = "", video_
         if "audio_encodings" in clip:
             kw["audio_encodings"] = clip["audio_encodings"][None]
             kw["null_audio_encodings"] = clip["null_audio_encodings"][None]
+        # uint8 (f, H, W, 3) frames = (video.permute(0, 2, 3, 1) * 255).byte() of the reference (:448), made on the device
         video = pipeline(images=[clip["image"]] if "image" in clip else None, audios=[clip.get("audio")], texts=[category],
                          text_encodings=[category_text_encoding] if category_text_encoding is not None else None,
                          video_length=video_num_frame, height=image_size[0], width=image_size[1], num_inference_steps=50,
                          audio_guidance_scale=audio_guidance_scale, text_guidance_scale=text_guidance_scale,
-                         generator=generator, return_dict=False, **kw)[0]
-        video = (video.permute(0, 2, 3, 1).contiguous() * 255).byte()          # (f, H, W, 3) uint8
+                         generator=generator, return_dict=False, output_type="uint8", **kw)[0]
         if save_template:
             path = f"{save_template}_clip-{k:02d}.mp4"
             os.makedirs(os.path.dirname(path) or ".", exist_ok=True)

@@ -344,9 +344,10 @@ class AutoencoderKL(nn.Module):
     # ---- decode ----------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = True, frames_per_chunk: Optional[int] = None,
-               postprocess: bool = False):
+               postprocess=False):
         """z: (N, 4, h, w) latents already divided by scaling_factor -> DecoderOutput(sample (N, 3, 8h, 8w) f32).
-        postprocess=True additionally applies the pipeline's (x / 2 + 0.5).clamp(0, 1) in the output kernel."""
+        postprocess=True additionally applies the pipeline's (x / 2 + 0.5).clamp(0, 1) in the output kernel;
+        postprocess="uint8" returns uint8 frames (N, H, W, 3) = trunc(that * 255), ready for the video writer."""
         pk = self.pack()
         dev = pk.blob.device
         N, _, h, w = z.shape
@@ -370,6 +371,14 @@ class AutoencoderKL(nn.Module):
         b, c, f, h, w = latents.shape
         z = latents.to(torch.float32).permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w) / self.config.scaling_factor
         img = self.decode(z, postprocess=True).sample
+        return img.reshape(b, f, *img.shape[1:])
+
+    def decode_to_uint8_frames(self, latents: torch.Tensor) -> torch.Tensor:
+        """(b, 4, f, h, w) denoised latents -> (b, f, H, W, 3) uint8 on the device (what generate_videos hands to
+        the video writer, pipeline :448), without the f32 round trip."""
+        b, c, f, h, w = latents.shape
+        z = latents.to(torch.float32).permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w) / self.config.scaling_factor
+        img = self.decode(z, postprocess="uint8").sample
         return img.reshape(b, f, *img.shape[1:])
 
     def _res(self, x, p, n, hw, groups):
@@ -411,6 +420,8 @@ class AutoencoderKL(nn.Module):
         a = ops.groupnorm(x, None, n, hw[0] * hw[1], groups, pk.norm_out.g, pk.norm_out.b, 1e-6, True)
         if postprocess:
             y = ops.gemm(a, pk.conv_out.w, bias=pk.conv_out.b, mode=ops.CONV3, conv=(n, hw[0], hw[1], 1, 0))
+            if postprocess == "uint8":
+                return ops.vae_postprocess_u8(y, n, hw[0], hw[1])
             return ops.vae_postprocess(y, n, hw[0], hw[1])
         y = ops.gemm(a, pk.conv_out.w, bias=pk.conv_out.b, out_f32=True, mode=ops.CONV3, conv=(n, hw[0], hw[1], 1, 0))
         return ops.rows_to_ncfhw(y, n, self.config.out_channels, 1, hw[0], hw[1]).reshape(n, self.config.out_channels, hw[0], hw[1])

@@ -196,6 +196,10 @@ int avsd_guided_step(const float* noise_pred, int n_branch, float g, float* eps_
 /* VAE post-processing (pipeline_audio_cond_animation.py:212): channels-last bf16
  * [N*H*W][ld] (3 channels) -> (N, 3, H, W) f32 = clamp(x / 2 + 0.5, 0, 1). */
 int avsd_vae_postprocess(const void* src, int ld, float* dst, int N, int HW, void* stream);
+/* Same input -> uint8 frames (N, H, W, 3) = trunc(clamp(x / 2 + 0.5, 0, 1) * 255): the post-processing above followed
+ * by generate_videos' `(video.permute(0, 2, 3, 1) * 255).byte()` (pipeline_audio_cond_animation.py:448), on device —
+ * 4x fewer bytes cross PCIe per clip. */
+int avsd_vae_postprocess_u8(const void* src, int ld, void* dst_u8, int N, int HW, void* stream);
 
 #ifdef __cplusplus
 }

@@ -164,3 +164,8 @@ def guided_step(noise_pred, n_branch, g, x_in, x_out, ca, cb, *, eps_hist=None, 
 
 def vae_postprocess(rows, n_img, H, W):
     return (rows[:, :3].float().reshape(n_img, H, W, 3).permute(0, 3, 1, 2) / 2 + 0.5).clamp(0, 1).contiguous()
+
+
+def vae_postprocess_u8(rows, n_img, H, W):
+    v = (rows[:, :3].float().reshape(n_img, H, W, 3) / 2 + 0.5).clamp(0, 1)
+    return (v * 255).to(torch.uint8)

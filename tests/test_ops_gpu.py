@@ -400,6 +400,9 @@ def test_guided_step(ops):
 def test_vae_postprocess(ops):
     n, H, W = 3, 16, 8
     rows = rnd(n * H * W, 4, seed=1)
+    u8 = ops.vae_postprocess_u8(rows, n, H, W)
+    want = ((rows[:, :3].float().reshape(n, H, W, 3) / 2 + 0.5).clamp(0, 1) * 255).to(torch.uint8)
+    assert u8.dtype == torch.uint8 and torch.equal(u8, want)
     out = ops.vae_postprocess(rows, n, H, W)
     ref = (rows[:, :3].float().reshape(n, H, W, 3).permute(0, 3, 1, 2) / 2 + 0.5).clamp(0, 1)
     assert torch.allclose(out, ref, atol=1e-6)

@@ -63,6 +63,9 @@ def test_pipeline_matches_oracle_pipeline(emu, kind):
     assert rel_l2(vid, ref_vid) < 5e-2
     bare = pipe(**kw, return_dict=False)
     assert torch.is_tensor(bare) and bare.shape == vid.shape
+    u8 = pipe(**kw, return_dict=False, output_type="uint8")            # device-side (x * 255).byte() in NHWC
+    assert u8.dtype == torch.uint8 and u8.shape == (1, c["f"], *c["hw"], 3)
+    assert (u8.int() - (vid.permute(0, 1, 3, 4, 2) * 255).byte().int()).abs().max() <= 1
 
 
 def test_pipeline_encodes_the_conditioning_image(emu):

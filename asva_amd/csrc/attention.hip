@@ -18,6 +18,7 @@
 // gather list), :352-358 (temporal attention).  diffusers 0.29.2 AttnProcessor2_0 semantics:
 // softmax(q k^T * d^-1/2 + mask) v, masked keys = -inf.
 #include "avsd_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -29,19 +30,31 @@ struct AttnArgs {
   float scale;
 };
 
-template <int D>
-__global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
+// QB = 32-query blocks per wave (the workgroup covers 128*QB queries); QB = 2 halves the LDS traffic per query.
+// (min 2 workgroups per CU caps the kernel at 256 registers, which also makes the compiler keep the MFMA
+// accumulators in VGPRs where the softmax reads them, instead of shuttling them through AGPRs.)
+template <int D, int QB, bool IDX>
+__global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
+  static_assert(D % 8 == 0, "head dim must be a multiple of 8");
   constexpr int DK = (D + 15) / 16 * 16;   // contraction length of Q.K^T, padded to MFMA K
   constexpr int NCK = DK / 16;
   constexpr int DV = (D + 31) / 32 * 32;   // output channels, padded to MFMA M
   constexpr int NDB = DV / 32;
   constexpr int KS = DK + 8;               // sK row stride (elements)
   constexpr int VS = 32 + 4;               // sVt row stride (elements): 72 B -> conflict-free b64 reads
-  constexpr int KVEC = DK / 8;             // 16-byte vectors per key row (K staging)
-  constexpr int VVEC = DV / 8;
+  constexpr int KVEC = D / 8;              // 16-byte vectors per key row
+  constexpr int KITEMS = 32 * KVEC;        // K staging: one vector per item
+  constexpr int VITEMS = 16 * KVEC;        // V staging: one vector of two adjacent keys per item
+  constexpr int NKV = (KITEMS + 255) / 256;
+  constexpr int NVV = (VITEMS + 255) / 256;
+  constexpr int VROT = (256 - (KITEMS & 255)) & 255;  // V items start on the threads the K items left idle
+  // With a spare padded output row, row D of V^T is all ones: the P.V MFMA then also accumulates the softmax
+  // denominator (of the bf16-rounded probabilities the numerator uses) and no VALU row sum is needed.
+  constexpr bool ONES = DV > D;
+  constexpr int LB = D / 32, LR = ((D % 32) & 3) + 4 * ((D % 32) >> 3), LH = ((D % 32) >> 2) & 1;
 
-  __shared__ __attribute__((aligned(16))) bf16_t sK[32 * KS];
-  __shared__ __attribute__((aligned(16))) bf16_t sVt[DV * VS];
+  __shared__ __attribute__((aligned(16))) bf16_t sK[2][32 * KS];
+  __shared__ __attribute__((aligned(16))) bf16_t sVt[2][DV * VS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -53,186 +66,270 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
   const int qb = blockIdx.z;
   const int kb = qb / p.q_per_kv;
   const int frame = qb % p.frames;
-  const int q = blockIdx.x * 128 + wave * 32 + l31;
-  const bool qvalid = q < p.Lq;
+  const int q0 = blockIdx.x * (128 * QB) + wave * (32 * QB) + l31;
+
+  // zero both stages once: the padding (K columns D..DK, V^T rows D..DV) is never written again
+  for (int i = tid; i < (int)(sizeof(sK) / 16); i += 256) reinterpret_cast<uint4*>(&sK[0][0])[i] = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < (int)(sizeof(sVt) / 16); i += 256) reinterpret_cast<uint4*>(&sVt[0][0])[i] = make_uint4(0, 0, 0, 0);
 
   // ---- Q fragments (MFMA B operand: lane holds Q[q][16c + 8*half + 0..7]) ----------------------
-  bf16x8 qf[NCK];
-  {
+  bf16x8 qf[QB][NCK];
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    const int q = q0 + 32 * j;
     const bf16_t* qrow = p.Q + ((int64_t)qb * p.Lq + q) * p.ldq + head * D;
 #pragma unroll
     for (int c = 0; c < NCK; ++c) {
       const int dd = c * 16 + half * 8;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (qvalid && dd < D) v = *reinterpret_cast<const uint4*>(qrow + dd);
-      qf[c] = __builtin_bit_cast(bf16x8, v);
+      if (q < p.Lq && dd < D) v = *reinterpret_cast<const uint4*>(qrow + dd);
+      qf[j][c] = __builtin_bit_cast(bf16x8, v);
     }
   }
 
-  f32x16 acc_o[NDB];
+  f32x16 acc_o[QB][NDB];
+  float m_run[QB], l_run[QB];
 #pragma unroll
-  for (int b = 0; b < NDB; ++b)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc_o[b][r] = 0.f;
-  float m_run = -1e30f;
-  float l_run = 0.f;
-
-  const bf16_t* Kb = p.K + (int64_t)kb * p.kv_rows * p.ldk + head * D;
-  const bf16_t* Vb = p.V + (int64_t)kb * p.kv_rows * p.ldv + head * D;
-  const int32_t* kidx = p.key_index ? p.key_index + (int64_t)frame * p.Lk : nullptr;
-
-  const int ntiles = (p.Lk + 31) / 32;
-  // Software pipeline: the global loads of tile t+1 are issued before the MFMA/softmax work of tile t and parked
-  // in registers; they are written to LDS after the tile's trailing barrier.  (K: [32 keys][DK] row-major;
-  // V: transposed [DV][32 keys] so the P.V operand is a contiguous 8-byte read per lane.)
-  constexpr int NKV = (32 * KVEC + 255) / 256;   // K vectors per thread per tile
-  constexpr int NVV = (32 * VVEC + 255) / 256;
-  uint4 rk[NKV], rv[NVV];
-  auto gload = [&](int t) {
-#pragma unroll
-    for (int u = 0; u < NKV; ++u) {
-      const int v = tid + u * 256;
-      const int key = v / KVEC;
-      const int dv = (v - key * KVEC) * 8;
-      const int kk = t * 32 + key;
-      rk[u] = make_uint4(0, 0, 0, 0);
-      if (v < 32 * KVEC && kk < p.Lk && dv < D) {
-        const int row = kidx ? kidx[kk] : kk;
-        rk[u] = *reinterpret_cast<const uint4*>(Kb + (int64_t)row * p.ldk + dv);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < NVV; ++u) {
-      const int v = tid + u * 256;
-      const int key = v / VVEC;
-      const int dv = (v - key * VVEC) * 8;
-      const int kk = t * 32 + key;
-      rv[u] = make_uint4(0, 0, 0, 0);
-      if (v < 32 * VVEC && kk < p.Lk && dv < D) {
-        const int row = kidx ? kidx[kk] : kk;
-        rv[u] = *reinterpret_cast<const uint4*>(Vb + (int64_t)row * p.ldv + dv);
-      }
-    }
-  };
-  auto lstore = [&]() {
-#pragma unroll
-    for (int u = 0; u < NKV; ++u) {
-      const int v = tid + u * 256;
-      if (v < 32 * KVEC) {
-        const int key = v / KVEC;
-        const int dv = (v - key * KVEC) * 8;
-        *reinterpret_cast<uint4*>(sK + key * KS + dv) = rk[u];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < NVV; ++u) {
-      const int v = tid + u * 256;
-      if (v < 32 * VVEC) {
-        const int key = v / VVEC;
-        const int dv = (v - key * VVEC) * 8;
-        const uint4 val = rv[u];
-        bf16_t* dst = sVt + dv * VS + key;
-        dst[0 * VS] = (bf16_t)(val.x & 0xffff); dst[1 * VS] = (bf16_t)(val.x >> 16);
-        dst[2 * VS] = (bf16_t)(val.y & 0xffff); dst[3 * VS] = (bf16_t)(val.y >> 16);
-        dst[4 * VS] = (bf16_t)(val.z & 0xffff); dst[5 * VS] = (bf16_t)(val.z >> 16);
-        dst[6 * VS] = (bf16_t)(val.w & 0xffff); dst[7 * VS] = (bf16_t)(val.w >> 16);
-      }
-    }
-  };
-  gload(0);
-  for (int t = 0; t < ntiles; ++t) {
-    lstore();
-    __syncthreads();
-    if (t + 1 < ntiles) gload(t + 1);
-
-    // ---- S^T[key][query] = K . Q^T ---------------------------------------------------------------
-    f32x16 s;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-    for (int c = 0; c < NCK; ++c) {
-      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + l31 * KS + c * 16 + half * 8);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[c], s, 0, 0, 0);
-    }
-
-    // ---- online softmax: lane owns query l31, keys (r&3) + 8*(r>>2) + 4*half ---------------------
-    float pmax = -1e30f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const float sv = (t * 32 + key < p.Lk) ? s[r] * p.scale : -1e30f;
-      s[r] = sv;
-      pmax = fmaxf(pmax, sv);
-    }
-    pmax = fmaxf(pmax, __shfl_xor(pmax, 32, 64));
-    const float m_new = fmaxf(m_run, pmax);
-    const float alpha = __expf(m_run - m_new);
-    float psum = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float pv = __expf(s[r] - m_new);
-      s[r] = pv;
-      psum += pv;
-    }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
+  for (int j = 0; j < QB; ++j) {
 #pragma unroll
     for (int b = 0; b < NDB; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc_o[b][r] *= alpha;
+      for (int r = 0; r < 16; ++r) acc_o[j][b][r] = 0.f;
+    m_run[j] = -1e30f;
+    l_run[j] = 0.f;
+  }
 
-    // ---- P fragments (MFMA B operand), k-slot e of MFMA c <-> register 8c+e ----------------------
-    bf16x8 pf[2];
+  const bf16_t* Kb = p.K + (int64_t)kb * p.kv_rows * p.ldk + head * D;
+  const bf16_t* Vb = p.V + (int64_t)kb * p.kv_rows * p.ldv + head * D;
+  const int32_t* kidx = IDX ? p.key_index + (int64_t)frame * p.Lk : nullptr;   // IDX: keys gathered through a list
+  const float sl2 = p.scale * 1.4426950408889634f;   // scores are kept in the log2 domain (v_exp_f32 is 2^x)
+
+  const int ntiles = (p.Lk + 31) / 32;
+  // Software pipeline, two tiles deep: the global loads of tile t+2 are issued before the MFMA/softmax work of
+  // tile t and parked in registers; the registers holding tile t+1 (issued one tile earlier) are written to the
+  // other LDS stage after it; one barrier per tile.  K: [32 keys][DK] row-major.  V: transposed [DV][32 keys] so
+  // the P.V operand is a contiguous 8-byte read per lane; a thread transposes the same 8 channels of two adjacent
+  // keys, so the LDS writes are 4-byte {key 2j, key 2j+1} pairs.
+  // Every thread loads on every tile (idle threads and the tiles past the end are clamped onto valid rows): with
+  // no branch around the loads the compiler can count them, and waits for tile t+1 with tile t+2 still in flight.
+  // Out-of-range keys of the last tile are clamped to the last valid row instead of zero-filled: their scores
+  // are masked to -1e30 below, so their probabilities are exactly 0 and any finite K/V row will do.
+  struct Regs { uint4 k[NKV]; uint4 v[NVV][2]; };
+  Regs ra, rb;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      uint4 v;
-      v.x = pack2bf(s[8 * c + 0], s[8 * c + 1]);
-      v.y = pack2bf(s[8 * c + 2], s[8 * c + 3]);
-      v.z = pack2bf(s[8 * c + 4], s[8 * c + 5]);
-      v.w = pack2bf(s[8 * c + 6], s[8 * c + 7]);
-      pf[c] = __builtin_bit_cast(bf16x8, v);
+  for (int u = 0; u < NKV; ++u) ra.k[u] = rb.k[u] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+  for (int u = 0; u < NVV; ++u) ra.v[u][0] = ra.v[u][1] = rb.v[u][0] = rb.v[u][1] = make_uint4(0, 0, 0, 0);
+  const int vtid = (tid + 256 - VROT) & 255;   // tid - (KITEMS mod 256), wrapped
+  auto gload = [&](int t, Regs& r) {
+    t = min(t, ntiles - 1);
+    int krow[NKV], vrow[NVV][2];
+#pragma unroll
+    for (int u = 0; u < NKV; ++u) {
+      const int v = min(tid + u * 256, KITEMS - 1);
+      const int kk = min(t * 32 + v / KVEC, p.Lk - 1);
+      krow[u] = IDX ? kidx[kk] : kk;
+    }
+#pragma unroll
+    for (int u = 0; u < NVV; ++u) {
+      const int v = min(vtid + u * 256, VITEMS - 1);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int kk = min(t * 32 + 2 * (v & 15) + h, p.Lk - 1);
+        vrow[u][h] = IDX ? kidx[kk] : kk;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NKV; ++u) {
+      const int v = min(tid + u * 256, KITEMS - 1);
+      r.k[u] = *reinterpret_cast<const uint4*>(Kb + (int64_t)krow[u] * p.ldk + (v % KVEC) * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < NVV; ++u) {
+      const int v = min(vtid + u * 256, VITEMS - 1);
+      r.v[u][0] = *reinterpret_cast<const uint4*>(Vb + (int64_t)vrow[u][0] * p.ldv + (v >> 4) * 8);
+      r.v[u][1] = *reinterpret_cast<const uint4*>(Vb + (int64_t)vrow[u][1] * p.ldv + (v >> 4) * 8);
+    }
+  };
+  auto lstore = [&](int st, const Regs& r) {
+#pragma unroll
+    for (int u = 0; u < NKV; ++u) {
+      const int v = tid + u * 256;
+      if (v < KITEMS) {
+        const int key = v / KVEC;
+        const int dv = (v - key * KVEC) * 8;
+        *reinterpret_cast<uint4*>(&sK[st][key * KS + dv]) = r.k[u];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NVV; ++u) {
+      const int v = vtid + u * 256;
+      if (v < VITEMS) {
+        const int j = v & 15;
+        const int dv = (v >> 4) * 8;
+        const uint4 a = r.v[u][0], b = r.v[u][1];
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&sVt[st][dv * VS + 2 * j]);
+        constexpr int RS = VS / 2;   // row stride in dwords
+        dst[0 * RS] = __builtin_amdgcn_perm(b.x, a.x, 0x05040100u); dst[1 * RS] = __builtin_amdgcn_perm(b.x, a.x, 0x07060302u);
+        dst[2 * RS] = __builtin_amdgcn_perm(b.y, a.y, 0x05040100u); dst[3 * RS] = __builtin_amdgcn_perm(b.y, a.y, 0x07060302u);
+        dst[4 * RS] = __builtin_amdgcn_perm(b.z, a.z, 0x05040100u); dst[5 * RS] = __builtin_amdgcn_perm(b.z, a.z, 0x07060302u);
+        dst[6 * RS] = __builtin_amdgcn_perm(b.w, a.w, 0x05040100u); dst[7 * RS] = __builtin_amdgcn_perm(b.w, a.w, 0x07060302u);
+      }
+    }
+  };
+  gload(0, ra);
+  __syncthreads();   // zero fill complete
+  if (ONES) {
+    if (tid < 32) { sVt[0][D * VS + tid] = 0x3f80; sVt[1][D * VS + tid] = 0x3f80; }
+  }
+  lstore(0, ra);
+  // every prologue load (Q fragments, tile 0) has landed: tells the compiler's wait-count pass that the loop
+  // need not wait on them again, or it would drain the prefetch before the first MFMA of each tile
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+  gload(1, ra);
+
+  // one tile: `cur` holds tile t+1 (loaded during tile t-1), `nxt` receives tile t+2
+  auto tile = [&](const int t, const Regs& cur, Regs& nxt) {
+    const int st = t & 1;
+    __syncthreads();   // stage st written; every wave is done reading stage st^1 (tile t-1)
+    gload(t + 2, nxt);
+    const bool tail = (t + 1 == ntiles) && (p.Lk & 31);
+
+    bf16x8 pf[QB][2];
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+      // ---- S^T[key][query] = K . Q^T -------------------------------------------------------------
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCK; ++c) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&sK[st][l31 * KS + c * 16 + half * 8]);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[j][c], s, 0, 0, 0);
+      }
+
+      // ---- online softmax: lane owns query l31, keys (r&3) + 8*(r>>2) + 4*half -------------------
+      if (tail) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (t * 32 + key >= p.Lk) s[r] = -1e30f;
+        }
+      }
+      // max(a, b) as med3(a, b, +inf): one instruction, no NaN-quieting pre-pass (scores are finite)
+      float pmax = s[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) pmax = __builtin_amdgcn_fmed3f(pmax, s[r], __builtin_inff());
+      const float mt = pmax * sl2;   // max of this lane's 16 keys; the other 16 of the tile sit on lane ^ 32
+      // The running max is only raised (and the accumulators rescaled) when some query of the wave exceeds it by
+      // more than 2^8: a stale max just scales numerator and denominator alike, and both accumulate in f32.
+      // The decision covers this tile's probabilities, which are exponentiated after it; tile t-1's P.V is done.
+      if (__builtin_amdgcn_ballot_w64(mt > m_run[j] + 8.f) != 0) {
+        const float m_new = fmaxf(m_run[j], fmaxf(mt, __shfl_xor(mt, 32, 64)));   // same value on both halves
+        const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new);
+        m_run[j] = m_new;
+        l_run[j] *= alpha;
+#pragma unroll
+        for (int b = 0; b < NDB; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc_o[j][b][r] *= alpha;
+      }
+      const hw_f32x2 nm2 = {-m_run[j], -m_run[j]}, sl22 = {sl2, sl2};
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const hw_f32x2 x = {s[r], s[r + 1]};
+        const hw_f32x2 y = __builtin_elementwise_fma(x, sl22, nm2);   // v_pk_fma_f32
+        s[r] = __builtin_amdgcn_exp2f(y[0]);
+        s[r + 1] = __builtin_amdgcn_exp2f(y[1]);
+      }
+      if (!ONES) {
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) psum += s[r];
+        l_run[j] += psum;
+      }
+
+      // ---- P fragments (MFMA B operand), k-slot e of MFMA c <-> register 8c+e ------------------
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        uint4 v;
+        v.x = pack2bf(s[8 * c + 0], s[8 * c + 1]);
+        v.y = pack2bf(s[8 * c + 2], s[8 * c + 3]);
+        v.z = pack2bf(s[8 * c + 4], s[8 * c + 5]);
+        v.w = pack2bf(s[8 * c + 6], s[8 * c + 7]);
+        pf[j][c] = __builtin_bit_cast(bf16x8, v);
+      }
     }
 
     // ---- O^T[dcol][query] += V^T . P^T ; V^T k-slots follow the same key permutation -------------
 #pragma unroll
     for (int b = 0; b < NDB; ++b) {
-      const bf16_t* vrow = sVt + (b * 32 + l31) * VS + 4 * half;
+      const bf16_t* vrow = &sVt[st][(b * 32 + l31) * VS + 4 * half];
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const uint2 lo = *reinterpret_cast<const uint2*>(vrow + 16 * c);
         const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16 * c + 8);
-        const uint4 vv = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        acc_o[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[c], acc_o[b], 0, 0, 0);
+        const bf16x8 vv = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+#pragma unroll
+        for (int j = 0; j < QB; ++j)
+          acc_o[j][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vv, pf[j][c], acc_o[j][b], 0, 0, 0);
       }
     }
-    __syncthreads();
+    if (t + 1 < ntiles) lstore(st ^ 1, cur);
+  };
+  for (int t = 0; t < ntiles; t += 2) {
+    tile(t, ra, rb);
+    if (t + 1 < ntiles) tile(t + 1, rb, ra);
   }
 
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
-  if (qvalid) {
-    bf16_t* orow = p.O + ((int64_t)qb * p.Lq + q) * p.ldo + head * D;
 #pragma unroll
-    for (int b = 0; b < NDB; ++b)
+  for (int j = 0; j < QB; ++j) {
+    float l_tot;
+    if (ONES) {
+      const float mine = acc_o[j][LB][LR];            // row D of O^T: lanes of half LH hold the denominator
+      const float other = __shfl_xor(mine, 32, 64);
+      l_tot = (half == LH) ? mine : other;
+    } else {
+      l_tot = l_run[j] + __shfl_xor(l_run[j], 32, 64);
+    }
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + 32 * j;
+    if (q < p.Lq) {
+      bf16_t* orow = p.O + ((int64_t)qb * p.Lq + q) * p.ldo + head * D;
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const int dcol = b * 32 + 8 * qd + 4 * half;
-        if (dcol < D) {
-          uint2 st;
-          st.x = pack2bf(acc_o[b][4 * qd + 0] * inv, acc_o[b][4 * qd + 1] * inv);
-          st.y = pack2bf(acc_o[b][4 * qd + 2] * inv, acc_o[b][4 * qd + 3] * inv);
-          *reinterpret_cast<uint2*>(orow + dcol) = st;
+      for (int b = 0; b < NDB; ++b)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int dcol = b * 32 + 8 * qd + 4 * half;
+          if (dcol < D) {
+            uint2 st;
+            st.x = pack2bf(acc_o[j][b][4 * qd + 0] * inv, acc_o[j][b][4 * qd + 1] * inv);
+            st.y = pack2bf(acc_o[j][b][4 * qd + 2] * inv, acc_o[j][b][4 * qd + 3] * inv);
+            *reinterpret_cast<uint2*>(orow + dcol) = st;
+          }
         }
-      }
+    }
   }
+}
+
+template <int D, int QB>
+int launch_attn_qb(const AttnArgs& a, int Bq, int heads, hipStream_t s) {
+  dim3 grid((unsigned)((a.Lq + 128 * QB - 1) / (128 * QB)), (unsigned)heads, (unsigned)Bq);
+  if (a.key_index) hipLaunchKernelGGL((attn_kernel<D, QB, true>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((attn_kernel<D, QB, false>), grid, dim3(256), 0, s, a);
+  AVSD_CHECK_LAUNCH("attention launch");
+  return AVSD_OK;
 }
 
 template <int D>
 int launch_attn(const AttnArgs& a, int Bq, int heads, hipStream_t s) {
-  dim3 grid((unsigned)((a.Lq + 127) / 128), (unsigned)heads, (unsigned)Bq);
-  hipLaunchKernelGGL((attn_kernel<D>), grid, dim3(256), 0, s, a);
-  AVSD_CHECK_LAUNCH("attention launch");
-  return AVSD_OK;
+  static const int force_qb = [] { const char* e = getenv("AVSD_ATTN_QB"); return e ? atoi(e) : 0; }();
+  // (64 queries per wave measured slower on every UNet shape: 83 vs 72 us on the 32x32 spatial attention)
+  const bool wide = force_qb == 2;
+  if constexpr (D <= 64) {   // beyond that the second accumulator set no longer fits 256 registers
+    if (wide) return launch_attn_qb<D, 2>(a, Bq, heads, s);
+  }
+  return launch_attn_qb<D, 1>(a, Bq, heads, s);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -375,6 +472,7 @@ extern "C" int avsd_attention(const void* Q, int ldq, const void* K, int ldk, co
   AVSD_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "attention: row strides must be multiples of 8 (ldo: 4)");
   AVSD_REQUIRE(q_per_kv > 0 && Bq % q_per_kv == 0, "attention: Bq (%d) must be a multiple of q_per_kv (%d)", Bq, q_per_kv);
   AVSD_REQUIRE(frames > 0, "attention: frames must be positive");
+  AVSD_REQUIRE(scale > 0.f, "attention: scale must be positive");
   AVSD_REQUIRE(kv_rows >= Lk || key_index, "attention: kv_rows (%d) < Lk (%d) without a gather list", kv_rows, Lk);
   AttnArgs a;
   a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V; a.O = (bf16_t*)O;

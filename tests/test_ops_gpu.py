@@ -322,13 +322,30 @@ def test_attention_key_gather_matches_bool_mask(ops):
     assert rel_l2(out, ref) < TOL_BF16
 
 
-def test_attention_online_softmax_rescale(ops):
-    # a key far above the rest in a LATER tile forces the running-max rescale path
-    heads, d, Lq, Lk = 1, 64, 32, 96
+@pytest.mark.parametrize("d", [40, 64, 80, 160])
+def test_attention_online_softmax_rescale(ops, d):
+    # keys far above the rest in LATER tiles force the (rare, deferred) running-max rescale: one spike on each
+    # half of the wave (keys 4..7 mod 8 live on lanes 32..63), each aimed at a different query
+    heads, Lq, Lk = 1, 32, 160
     q = rnd(Lq, d, seed=1)
     k = rnd(Lk, d, seed=2)
     v = rnd(Lk, d, seed=3)
     k[70] = q[5] * 4
+    k[97] = q[11] * 6
+    k[130] = q[5] * 8
+    out = ops.attention(q, k, v, bq=1, lq=Lq, lk=Lk, kv_rows=Lk, heads=heads, q_per_kv=1, frames=1)
+    ref = _sdpa_ref(q[None], k[None], v[None], heads)
+    assert rel_l2(out, ref) < TOL_BF16
+    assert (out.float() - ref).abs().max() < 0.05      # no row is left at a stale scale
+
+
+@pytest.mark.parametrize("d", [40, 64])
+def test_attention_slowly_growing_max(ops, d):
+    # the row maximum creeps up by less than the rescale threshold per tile: the stale-max path must stay exact
+    heads, Lq, Lk = 1, 64, 256
+    q = rnd(Lq, d, seed=1)
+    k = rnd(Lk, d, seed=2) * torch.linspace(0.5, 3.0, Lk, device=dev())[:, None].to(torch.bfloat16)
+    v = rnd(Lk, d, seed=3)
     out = ops.attention(q, k, v, bq=1, lq=Lq, lk=Lk, kv_rows=Lk, heads=heads, q_per_kv=1, frames=1)
     ref = _sdpa_ref(q[None], k[None], v[None], heads)
     assert rel_l2(out, ref) < TOL_BF16

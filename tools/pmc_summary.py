@@ -18,5 +18,5 @@ for (k, d), cs in agg.items():
     for c, v in cs.items():
         per[k][c].append(sum(v))
 for k, cs in per.items():
-    if "gemm" not in k: continue
+    if (sys.argv[2] if len(sys.argv) > 2 else "gemm") not in k: continue
     print(k, {c: (len(v), round(sum(v) / len(v), 1)) for c, v in cs.items()})

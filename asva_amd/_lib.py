@@ -64,6 +64,10 @@ SIGNATURES = {
                                  c_int, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_int, c_void_p]),
     "avsd_vae_postprocess": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "avsd_vae_postprocess_u8": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "avsd_kaldi_fbank": (c_int, [c_void_p, c_int, c_int, C.c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int,
+                                 c_void_p, c_int, c_float, c_float, c_void_p]),
+    "avsd_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "avsd_vit_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
 }
 
 _lib = None

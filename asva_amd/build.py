@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libavsd_hip.so")
-SOURCES = ["lib.hip", "gemm.hip", "attention.hip", "norm.hip", "elementwise.hip"]
+SOURCES = ["lib.hip", "gemm.hip", "attention.hip", "norm.hip", "elementwise.hip", "audio.hip"]
 HEADERS = [os.path.join(CSRC, "avsd_common.h"), os.path.join(HERE, "..", "include", "avsd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

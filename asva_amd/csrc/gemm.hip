@@ -92,6 +92,7 @@ __device__ __forceinline__ void epilogue(const avsd_gemm_desc& p, f32x16 (&acc)[
   const int frow = lane & 31;
   const bool geglu = (p.flags & AVSD_GEMM_GEGLU) != 0;
   const bool out_f32 = (p.flags & AVSD_GEMM_OUT_F32) != 0;
+  const bool gelu = (p.flags & AVSD_GEMM_GELU) != 0;
   const bf16_t* R1 = reinterpret_cast<const bf16_t*>(p.res1);
   const bf16_t* R2 = reinterpret_cast<const bf16_t*>(p.res2);
   const int hsel = (lane >> 5) * 4;
@@ -119,6 +120,10 @@ __device__ __forceinline__ void epilogue(const avsd_gemm_desc& p, f32x16 (&acc)[
           if (rv) {
             const float4 bb = *reinterpret_cast<const float4*>(rv + n);
             v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+          }
+          if (gelu) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = gelu_erf_f(v[i]);
           }
           if (R1) {
             const uint2 rr = *reinterpret_cast<const uint2*>(R1 + bz * p.batch_stride_out + (int64_t)m * p.ldr1 + n);
@@ -667,6 +672,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const avsd_gemm_desc
       const float4 bb = *reinterpret_cast<const float4*>(p.rowvec + (int64_t)(m / p.rows_per_vec) * p.ldv + n);
       v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
     }
+    if (p.flags & AVSD_GEMM_GELU) {
+      for (int i = 0; i < 4; ++i) v[i] = gelu_erf_f(v[i]);
+    }
     if (R1) {
       const uint2 rr = *reinterpret_cast<const uint2*>(R1 + (int64_t)m * p.ldr1 + n);
       v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
@@ -780,6 +788,7 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
   AVSD_REQUIRE(d.lda % 8 == 0, "gemm: lda (%d) must be a multiple of 8", d.lda);
   if (d.batch <= 0) d.batch = 1;
   if (d.flags & AVSD_GEMM_GEGLU) AVSD_REQUIRE(d.N % 32 == 0, "gemm: GEGLU needs N %% 32 == 0 (got %d)", d.N);
+  AVSD_REQUIRE(!((d.flags & AVSD_GEMM_GEGLU) && (d.flags & AVSD_GEMM_GELU)), "gemm: GEGLU and GELU are exclusive");
   if (d.res1) AVSD_REQUIRE(d.ldr1 % 4 == 0, "gemm: ldr1 must be a multiple of 4");
   if (d.res2) AVSD_REQUIRE(d.ldr2 % 4 == 0, "gemm: ldr2 must be a multiple of 4");
   if (d.rowvec) AVSD_REQUIRE(d.rows_per_vec > 0 && d.ldv % 4 == 0, "gemm: rowvec needs rows_per_vec > 0 and ldv %% 4 == 0");

@@ -16,7 +16,7 @@ from . import _lib
 from ._lib import GemmDesc, check
 
 PLAIN, TMIX, CONV3 = 0, 1, 2
-GEGLU, OUT_F32 = 1, 2
+GEGLU, OUT_F32, GELU = 1, 2, 4
 BF16, F32 = torch.bfloat16, torch.float32
 
 
@@ -175,6 +175,7 @@ def gemm(
     res2: Optional[torch.Tensor] = None,
     alpha: float = 1.0,
     geglu: bool = False,
+    gelu: bool = False,
     out_f32: bool = False,
     out: Optional[torch.Tensor] = None,
     mode: int = PLAIN,
@@ -240,7 +241,7 @@ def gemm(
         d.res2, d.ldr2 = _p(res2), _ld(res2)
     d.alpha = alpha
     d.mode = mode
-    d.flags = (GEGLU if geglu else 0) | (OUT_F32 if out_f32 else 0)
+    d.flags = (GEGLU if geglu else 0) | (OUT_F32 if out_f32 else 0) | (GELU if gelu else 0)
     d.batch = 1
     ws = None
 
@@ -471,4 +472,46 @@ def vae_postprocess_u8(rows: torch.Tensor, n_img: int, H: int, W: int) -> torch.
     _req(rows, BF16, "rows")
     out = torch.empty((n_img, H, W, 3), dtype=torch.uint8, device=rows.device)
     check(_lib.lib().avsd_vae_postprocess_u8(_p(rows), _ld(rows), _p(out), n_img, H * W, _stream()), "avsd_vae_postprocess_u8")
+    return out
+
+
+# ---- audio conditioning front-end ------------------------------------------------------------------
+def kaldi_fbank(wave: torch.Tensor, window: torch.Tensor, mel_fb: torch.Tensor, *, shift: int, nfft: int, t_out: int,
+                preemph: float = 0.97, remove_dc: bool = True, mean: float = 0.0, std: float = 1.0) -> torch.Tensor:
+    """wave (B, n_samples) f32 -> normalised log-mel (B, n_mel, t_out) f32; see avsd_kaldi_fbank."""
+    _req(wave, F32, "wave")
+    _req(window, F32, "window")
+    _req(mel_fb, F32, "mel_fb")
+    if wave.dim() != 2 or not mel_fb.is_contiguous() or mel_fb.shape[1] != nfft // 2 + 1:
+        raise ValueError("kaldi_fbank: wave must be (B, n), mel_fb contiguous [n_mel][nfft/2+1]")
+    B, n = wave.shape
+    out = torch.empty((B, mel_fb.shape[0], t_out), dtype=F32, device=wave.device)
+    check(_lib.lib().avsd_kaldi_fbank(_p(wave), B, n, wave.stride(0), _p(window), _p(mel_fb), window.numel(), shift, nfft,
+                                      mel_fb.shape[0], float(preemph), int(remove_dc), _p(out), t_out, float(mean), float(std),
+                                      _stream()), "avsd_kaldi_fbank")
+    return out
+
+
+def patchify(x: torch.Tensor, kh: int, kw: int, stride: int) -> torch.Tensor:
+    """(B, C, H, W) f32 -> bf16 rows [B*ph*pw, C*kh*kw]."""
+    _req(x, F32, "x")
+    if not x.is_contiguous():
+        raise ValueError("patchify: x must be contiguous")
+    B, Cc, H, W = x.shape
+    ph, pw = (H - kh) // stride + 1, (W - kw) // stride + 1
+    out = torch.empty((B * ph * pw, Cc * kh * kw), dtype=BF16, device=x.device)
+    check(_lib.lib().avsd_patchify(_p(x), _p(out), B, Cc, H, W, kh, kw, stride, _stream()), "avsd_patchify")
+    return out
+
+
+def vit_tokens(patches: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, b: int, tail_rows: int = 0) -> torch.Tensor:
+    """bf16 patch embeddings [b*np, C] + cls [C] + pos [1+np, C] (f32) -> bf16 [b*(1+np+tail_rows), C]."""
+    _req(patches, BF16, "patches")
+    _req(cls, F32, "cls")
+    _req(pos, F32, "pos")
+    n_p, Cc = patches.shape[0] // b, patches.shape[1]
+    if not patches.is_contiguous() or pos.shape != (1 + n_p, Cc) or cls.numel() != Cc:
+        raise ValueError("vit_tokens: shape mismatch")
+    out = torch.empty((b * (1 + n_p + tail_rows), Cc), dtype=BF16, device=patches.device)
+    check(_lib.lib().avsd_vit_tokens(_p(patches), _p(cls), _p(pos), _p(out), b, n_p, Cc, tail_rows, _stream()), "avsd_vit_tokens")
     return out

@@ -29,6 +29,7 @@ from .engine import DenoiseEngine
 from .schedulers import DDIMScheduler, PNDMScheduler
 from .unet import AudioUNet3DConditionModel
 from .vae import AutoencoderKL
+from .audio_features import AudioMelspectrogramExtractor
 
 MELSPECTROGRAM_SHAPE = (128, 204)   # pipeline_audio_cond_animation.py:77
 
@@ -42,7 +43,7 @@ class AudioCondAnimationPipeline:
             self.null_text_encoding = torch.load(null_text_encodings_path).view(1, 77, 768)
         self.melspectrogram_shape = MELSPECTROGRAM_SHAPE
         self.vae_scale_factor = 2 ** (len(self.vae.config.block_out_channels) - 1) if vae is not None else 8
-        self.audio_processor = None          # callable(list of waveforms) -> (b, 1, 128, 204) mel-spectrograms
+        self.audio_processor = AudioMelspectrogramExtractor()   # (:81) waveforms -> (b, 1, 128, 204) log-mel, on the device
         self._progress = {}
         self._device = torch.device("cpu")
         self._dtype = torch.float32
@@ -126,7 +127,7 @@ class AudioCondAnimationPipeline:
         if audio_encodings is None:
             if self.audio_encoder is None or self.audio_processor is None:
                 raise ValueError("pass audio_encodings=/null_audio_encodings= or attach audio_encoder and audio_processor")
-            mel = self.audio_processor(audios).to(device=device, dtype=dtype)
+            mel = self.audio_processor(audios, device=device).to(dtype=dtype)
             _, audio_encodings, audio_masks = self.audio_encoder(mel, normalize=False, return_dict=False)
             if do_audio_classifier_free_guidance:
                 null_mel = torch.zeros(1, 1, *self.melspectrogram_shape, device=device, dtype=dtype)
@@ -363,11 +364,12 @@ def generate_videos_for_dataset(exp_root: str, checkpoint: int, dataset: str = "
     scheduler = PNDMScheduler.from_pretrained(sd15, subfolder="scheduler")
     text_encoder = CLIPTextModel.from_pretrained(sd15, subfolder="text_encoder").to(device=device, dtype=dtype)
     vae = AutoencoderKL.from_pretrained(sd15, subfolder="vae").to(device=device)
-    try:
-        from avgen.models.audio_encoders import ImageBindSegmaskAudioEncoder  # type: ignore
-    except Exception as e:  # noqa: BLE001
-        raise RuntimeError("ImageBindSegmaskAudioEncoder needs the un-vendored ImageBind submodule (README.md:61)") from e
-    audio_encoder = ImageBindSegmaskAudioEncoder(n_segment=video_num_frame).to(device=device, dtype=dtype).eval()
+    from .audio_encoder import ImageBindSegmaskAudioEncoder
+
+    # (:514) ImageBind-Huge audio branch from ImageBind's own checkpoint file + identity final_layer_norm, frozen
+    audio_encoder = ImageBindSegmaskAudioEncoder(n_segment=video_num_frame,
+                                                 imagebind_checkpoint=ImageBindSegmaskAudioEncoder.IMAGEBIND_CKPT)
+    audio_encoder = audio_encoder.to(device=device).eval()
     unet = AudioUNet3DConditionModel.from_pretrained(ckpt, subfolder="unet").to(device=device)
     pipe = AudioCondAnimationPipeline(text_encoder=text_encoder, tokenizer=tokenizer, unet=unet, scheduler=scheduler, vae=vae,
                                       audio_encoder=audio_encoder, null_text_encodings_path=null_text)

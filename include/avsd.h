@@ -61,15 +61,16 @@ int avsd_device_info(char* name_host, int len, int* num_cu_host);
  *                    row m = (n, ho, wo); stride 1 or 2; `ups`=1 reads the input through a
  *                    nearest x2 upsample (ff_spatio_temp_resnet_3d.py:48); `pad` = top/left padding.
  *
- * epilogue, in f32:  v = alpha*acc + bias[n] + rowvec[(m / rows_per_vec)*ldv + n]
+ * epilogue, in f32:  v = act(alpha*acc + bias[n] + rowvec[(m / rows_per_vec)*ldv + n])
  *                                   + res1[m*ldr1 + n] + res2[m*ldr2 + n]
+ *   AVSD_GEMM_GELU:  act = gelu_erf (the MLP of the audio front-end's ViT blocks); identity otherwise.
  *   AVSD_GEMM_GEGLU: W rows are packed per 32-row block as [16 value rows | 16 gate rows];
  *                    out[M, N/2] = value * gelu_erf(gate)   (diffusers GEGLU)
  *   AVSD_GEMM_OUT_F32: out is f32 instead of bf16.
  * blockIdx.z batches: pointers advance by batch_stride_* elements (0 = shared).
  */
 enum { AVSD_GEMM_PLAIN = 0, AVSD_GEMM_TMIX = 1, AVSD_GEMM_CONV3 = 2 };
-enum { AVSD_GEMM_GEGLU = 1, AVSD_GEMM_OUT_F32 = 2 };
+enum { AVSD_GEMM_GEGLU = 1, AVSD_GEMM_OUT_F32 = 2, AVSD_GEMM_GELU = 4 };
 
 typedef struct avsd_gemm_desc {
   const void* A;        /* bf16 */
@@ -200,6 +201,24 @@ int avsd_vae_postprocess(const void* src, int ld, float* dst, int N, int HW, voi
  * by generate_videos' `(video.permute(0, 2, 3, 1) * 255).byte()` (pipeline_audio_cond_animation.py:448), on device —
  * 4x fewer bytes cross PCIe per clip. */
 int avsd_vae_postprocess_u8(const void* src, int ld, void* dst_u8, int N, int HW, void* stream);
+
+/* ---- audio conditioning front-end (once per clip, not on the denoising loop) --------------------------
+ * Kaldi-compatible log-mel filterbank + transpose + pad/crop + normalisation: replaces
+ * `waveform_to_melspectrogram` (avgen/data/utils.py:26-55) = ImageBind `waveform2melspec` (torchaudio.compliance.
+ * kaldi.fbank: htk_compat, hanning window, dither 0, snip_edges) followed by `Normalize(mean, std)`.
+ *   wave [batch][wave_stride] f32 (n_samples valid), window [win] f32, mel_fb [n_mel][nfft/2+1] f32 (host-built,
+ *   asva_amd/audio_features.py) -> out [batch][n_mel][t_out] f32; frames past 1 + (n_samples - win) / shift are the
+ *   normalised zero padding.  nfft must be a power of two; win <= 512. */
+int avsd_kaldi_fbank(const float* wave, int batch, int n_samples, int64_t wave_stride, const float* window,
+                     const float* mel_fb, int win, int shift, int nfft, int n_mel, float preemph, int remove_dc,
+                     float* out, int t_out, float mean, float std, void* stream);
+/* im2col of non-padded strided patches: src (B, C, H, W) f32 -> dst bf16 [B*ph*pw][C*kh*kw] (c-major, then kh, kw:
+ * the order of a flattened nn.Conv2d weight).  Front of ImageBind's audio stem Conv2d(1, 768, 16, stride 10). */
+int avsd_patchify(const float* src, void* dst, int B, int C, int H, int W, int kh, int kw, int stride, void* stream);
+/* ViT token matrix: out bf16 [B][1 + n_patches + tail_rows][C]; row 0 = cls + pos[0], row 1+p = patches[b, p] + pos[1+p],
+ * tail rows = 0 (the add_bias_kv slot of the ImageBind audio trunk's attention).  cls [C], pos [1+n_patches][C] f32. */
+int avsd_vit_tokens(const void* patches, const float* cls, const float* pos, void* out, int B, int n_patches, int C,
+                    int tail_rows, void* stream);
 
 #ifdef __cplusplus
 }

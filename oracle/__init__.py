@@ -10,6 +10,8 @@ the reference file:line it follows:
                    (avgen/models/unets/**; U1-U13 of SURVEY.md §8a)
   vae_ref.py       AutoencoderKL.decode as called at pipeline_audio_cond_animation.py:206-213 (V1)
   sched_ref.py     PNDMScheduler / DDIMScheduler as called at :325-327,337,364 (S1)
+  audio_ref.py     waveform -> log-mel (avgen/data/utils.py:26-55) and ImageBindSegmaskAudioEncoder.forward
+                   (segmask_imagebind.py:80-123); ImageBind / torchaudio absent -> PARITY UNPINNED
   pipeline_ref.py  latent preparation, denoising loop, guidance, first-frame pinning, decode
                    post-processing (:234-261, :330-375; P1, P3)
 

@@ -17,7 +17,7 @@ BF16, F32 = torch.bfloat16, torch.float32
 
 
 def gemm(a, w, *, n=None, k=None, a2=None, bias=None, rowvec=None, rows_per_vec=0, res1=None, res2=None, alpha=1.0,
-         geglu=False, out_f32=False, out=None, mode=PLAIN, tmix=None, conv=None, m=None, tile=0, split_k=1):
+         geglu=False, gelu=False, out_f32=False, out=None, mode=PLAIN, tmix=None, conv=None, m=None, tile=0, split_k=1):
     assert a.dtype == BF16 and w.dtype == BF16
     wf = w.float()
     if mode == PLAIN:
@@ -51,6 +51,8 @@ def gemm(a, w, *, n=None, k=None, a2=None, bias=None, rowvec=None, rows_per_vec=
             v = v + bias
         if rowvec is not None:
             v = v + rowvec.repeat_interleave(rows_per_vec, 0)[: v.shape[0]]
+        if gelu:
+            v = F.gelu(v)
         if res1 is not None:
             v = v + res1.float()
         if res2 is not None:
@@ -60,6 +62,9 @@ def gemm(a, w, *, n=None, k=None, a2=None, bias=None, rowvec=None, rows_per_vec=
             acc = acc + bias
         blk = acc.reshape(acc.shape[0], -1, 32)
         v = (blk[:, :, :16] * F.gelu(blk[:, :, 16:])).reshape(acc.shape[0], -1)
+    if out is not None:
+        out.copy_(v.to(out.dtype))
+        return out
     return v if out_f32 else v.to(BF16)
 
 
@@ -169,3 +174,34 @@ def vae_postprocess(rows, n_img, H, W):
 def vae_postprocess_u8(rows, n_img, H, W):
     v = (rows[:, :3].float().reshape(n_img, H, W, 3) / 2 + 0.5).clamp(0, 1)
     return (v * 255).to(torch.uint8)
+
+
+def kaldi_fbank(wave, window, mel_fb, *, shift, nfft, t_out, preemph=0.97, remove_dc=True, mean=0.0, std=1.0):
+    B, n = wave.shape
+    win = window.numel()
+    nfr = 0 if n < win else 1 + (n - win) // shift
+    out = torch.full((B, mel_fb.shape[0], t_out), (0.0 - mean) / std, dtype=F32)
+    if nfr:
+        fr = wave.unfold(1, win, shift)[:, :nfr].to(torch.float64)
+        if remove_dc:
+            fr = fr - fr.mean(-1, keepdim=True)
+        prev = torch.cat([fr[..., :1], fr[..., :-1]], -1)
+        fr = (fr - preemph * prev) * window.to(torch.float64)
+        spec = torch.fft.rfft(fr, n=nfft).abs() ** 2
+        mel = torch.clamp(spec @ mel_fb.to(torch.float64).T, min=1.1920928955078125e-07).log()
+        k = min(nfr, t_out)
+        out[:, :, :k] = ((mel[:, :k] - mean) / std).transpose(1, 2).float()
+    return out
+
+
+def patchify(x, kh, kw, stride):
+    B, Cc = x.shape[:2]
+    cols = F.unfold(x, (kh, kw), stride=stride)                  # [B, C*kh*kw, L]
+    return cols.transpose(1, 2).reshape(-1, Cc * kh * kw).to(BF16)
+
+
+def vit_tokens(patches, cls, pos, b, tail_rows=0):
+    n_p, Cc = patches.shape[0] // b, patches.shape[1]
+    x = patches.float().reshape(b, n_p, Cc) + pos[1:]
+    c = (cls.reshape(1, 1, Cc) + pos[:1]).expand(b, 1, Cc)
+    return torch.cat([c, x, torch.zeros(b, tail_rows, Cc)], 1).reshape(-1, Cc).to(BF16)

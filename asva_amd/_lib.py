@@ -12,7 +12,7 @@ import torch  # noqa: F401  — must be imported BEFORE the .so is loaded: libav
 #                runtime torch already mapped (one runtime, one device context) instead of a second copy
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libavsd_hip.so")
+LIB_PATH = os.environ.get("AVSD_LIB_PATH") or os.path.join(_HERE, "libavsd_hip.so")   # override: A/B-testing a kernel build
 
 c_void_p, c_int, c_float, c_int64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 

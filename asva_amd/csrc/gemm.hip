@@ -206,8 +206,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const avsd_gemm_desc p) {
     const int xcd = bid & 7, idx = bid >> 3;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tn = wg % ntn;
-  const int tm = wg / ntn;
+  // Each XCD owns a contiguous range of `wg`.  Default: row-major tiles, so an XCD covers a band of M and its L2
+  // fetches that band of A once while EVERY XCD streams all of W.  AVSD_GEMM_XCD_N: column-major, an XCD covers a
+  // band of N — W is fetched once chip-wide and A by every XCD (the host picks whichever operand is larger).
+  const bool nmaj = (p.flags & AVSD_GEMM_XCD_N) != 0;
+  const int tn = nmaj ? wg / ntm : wg % ntn;
+  const int tm = nmaj ? wg % ntm : wg / ntn;
 
   const int64_t bz = blockIdx.z;
   const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + bz * p.batch_stride_a;
@@ -423,21 +427,31 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_kernel(const avsd_gemm_des
   const int ntm = (p.M + BM - 1) / BM;
   const int ntn = (p.N + BN - 1) / BN;
   const int nwg = ntm * ntn;
-  int wg;
+  const int nsplit = p.split_k > 1 ? p.split_k : 1;
+  // Workgroups go to the 8 XCDs round-robin by their LINEAR id (x fastest, then y; tools/probes/xcd_map_probe.hip):
+  // give every XCD one contiguous range of (tile, K-slice) work items, the slices of a tile adjacent, so the banding
+  // below also holds for split-K launches (gridDim.x = tiles, gridDim.y = slices).
+  int wg, ksplit;
   {
-    const int bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7;
+    const int total = nwg * nsplit;
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q = total >> 3, r = total & 7;
     const int xcd = bid & 7, idx = bid >> 3;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int c = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    wg = c / nsplit;
+    ksplit = c - wg * nsplit;
   }
-  const int tn = wg % ntn;
-  const int tm = wg / ntn;
+  // Each XCD owns a contiguous range of `wg`.  Default: row-major tiles, so an XCD covers a band of M and its L2
+  // fetches that band of A once while EVERY XCD streams all of W.  AVSD_GEMM_XCD_N: column-major, an XCD covers a
+  // band of N — W is fetched once chip-wide and A by every XCD (the host picks whichever operand is larger).
+  const bool nmaj = (p.flags & AVSD_GEMM_XCD_N) != 0;
+  const int tn = nmaj ? wg / ntm : wg % ntn;
+  const int tm = nmaj ? wg % ntm : wg / ntn;
   const int64_t bz = blockIdx.z;
   // split-K: this workgroup owns K tiles [kt0, kt1)
   const int nk_all = (p.K + BK - 1) / BK;
-  const int nsplit = p.split_k > 1 ? p.split_k : 1;
   const int per_split = (nk_all + nsplit - 1) / nsplit;
-  const int kt0 = blockIdx.y * per_split;
+  const int kt0 = ksplit * per_split;
   const int kt1 = min(nk_all, kt0 + per_split);
 
   const bf16_t* Ab = reinterpret_cast<const bf16_t*>(p.A) + bz * p.batch_stride_a;
@@ -628,7 +642,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_kernel(const avsd_gemm_des
 
   if (p.split_k > 1) {
     // raw f32 partial tile -> ws[split][m][n]; the reduce kernel applies the epilogue
-    float* ws = p.splitk_ws + (int64_t)blockIdx.y * p.M * p.N;
+    float* ws = p.splitk_ws + (int64_t)ksplit * p.M * p.N;
     const int hsel = (lane >> 5) * 4;
 #pragma unroll
     for (int b = 0; b < FM; ++b) {

@@ -16,7 +16,8 @@ from . import _lib
 from ._lib import GemmDesc, check
 
 PLAIN, TMIX, CONV3 = 0, 1, 2
-GEGLU, OUT_F32, GELU = 1, 2, 4
+GEGLU, OUT_F32, GELU, XCD_N = 1, 2, 4, 8
+_XCD_MODE = os.environ.get("AVSD_XCD_MODE", "auto")     # auto | m | n  (which operand each XCD's L2 fetches once)
 BF16, F32 = torch.bfloat16, torch.float32
 
 
@@ -86,6 +87,28 @@ def set_autotune(on: bool) -> None:
 
 def tile_cache() -> dict:
     return _TILE_CACHE
+
+
+def save_tile_cache(path: str) -> None:
+    """Writes the tuned (shape -> tile, split_k) table as JSON; AVSD_TILE_CACHE=<path> loads it at import, so a
+    profiling run (rocprofv3 --pmc serialises every dispatch) can skip the tuning launches."""
+    import json
+
+    with open(path, "w") as f:
+        json.dump([[list(k), list(v)] for k, v in _TILE_CACHE.items()], f)
+
+
+def load_tile_cache(path: str) -> int:
+    import json
+
+    with open(path) as f:
+        for k, v in json.load(f):
+            _TILE_CACHE[tuple(k)] = tuple(v)
+    return len(_TILE_CACHE)
+
+
+if os.environ.get("AVSD_TILE_CACHE") and os.path.isfile(os.environ["AVSD_TILE_CACHE"]):
+    load_tile_cache(os.environ["AVSD_TILE_CACHE"])
 
 
 _TUNE_COLD = os.environ.get("AVSD_TUNE_COLD", "1") != "0"
@@ -242,6 +265,10 @@ def gemm(
     d.alpha = alpha
     d.mode = mode
     d.flags = (GEGLU if geglu else 0) | (OUT_F32 if out_f32 else 0) | (GELU if gelu else 0)
+    # XCD banding: the 8 L2s are not shared, so whichever operand is NOT banded is fetched by all 8 of them
+    a_bytes = M * (K // 9 if mode == CONV3 else K // 3 if mode == TMIX else K)
+    if _XCD_MODE == "n" or (_XCD_MODE == "auto" and N * K > a_bytes):
+        d.flags |= XCD_N
     d.batch = 1
     ws = None
 

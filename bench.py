@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--save-tiles", default="", help="write the autotuned tile table here (reload with AVSD_TILE_CACHE=<file>)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--clips-per-gpu", type=int, default=1,
@@ -204,6 +205,17 @@ def main():
                            "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                            "traffic": None, "launches_per_step": launches, "ms_per_step": round(ms, 4),
                            "avg_launch_us": round(ms * 1e3 / launches, 2), "tflop_per_step": round(fl / 1e12, 4)}
+        # HBM-side traffic of the same family from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected in separate
+        # runs of this script, FETCH_SIZE doubled per the gfx950 correction); counters cannot be read from inside
+        # the timed process, so the committed summary of the last profiled run is reported, with its provenance
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+        if os.path.isfile(tpath):
+            with open(tpath) as f:
+                tr = json.load(f)
+            out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_detail"] = {k: tr[k] for k in ("fetch_bytes_x2_per_launch", "write_bytes_per_launch",
+                                                                    "launches_profiled", "source") if k in tr}
+        out["roofline"]["algorithmic_bytes_per_launch"] = round(sum(f["bytes"] for f in mm) / launches)
         out["kernel_families"] = {
             k: {"launches": v["launches"], "ms": round(v["ms"], 4),
                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
@@ -212,6 +224,8 @@ def main():
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(unet, clip)
         out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+    if a.save_tiles:
+        ops.save_tile_cache(a.save_tiles)
     print(json.dumps(out), flush=True)
 
 

@@ -67,10 +67,12 @@ int avsd_device_info(char* name_host, int len, int* num_cu_host);
  *   AVSD_GEMM_GEGLU: W rows are packed per 32-row block as [16 value rows | 16 gate rows];
  *                    out[M, N/2] = value * gelu_erf(gate)   (diffusers GEGLU)
  *   AVSD_GEMM_OUT_F32: out is f32 instead of bf16.
+ *   AVSD_GEMM_XCD_N: scheduling hint, no effect on the result — tiles are dealt to the 8 XCDs in bands of N instead of
+ *                    bands of M, so the weights (not the activations) are the operand each L2 fetches only once.
  * blockIdx.z batches: pointers advance by batch_stride_* elements (0 = shared).
  */
 enum { AVSD_GEMM_PLAIN = 0, AVSD_GEMM_TMIX = 1, AVSD_GEMM_CONV3 = 2 };
-enum { AVSD_GEMM_GEGLU = 1, AVSD_GEMM_OUT_F32 = 2, AVSD_GEMM_GELU = 4 };
+enum { AVSD_GEMM_GEGLU = 1, AVSD_GEMM_OUT_F32 = 2, AVSD_GEMM_GELU = 4, AVSD_GEMM_XCD_N = 8 };
 
 typedef struct avsd_gemm_desc {
   const void* A;        /* bf16 */

@@ -384,45 +384,43 @@ __device__ __forceinline__ unsigned a_voffset(const avsd_gemm_desc& p, const Row
   }
 }
 
+// s_waitcnt vmcnt(N) with N a compile-time constant (0..63), everything else unconstrained.  gfx9 encoding of the
+// immediate: vmcnt[3:0] in bits 3:0, vmcnt[5:4] in bits 15:14, expcnt (7 = no wait) in 6:4, lgkmcnt (15) in 11:8.
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-  else static_assert(N < 0, "add the vmcnt literal");
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
+  asm volatile("" ::: "memory");
 }
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int BM, int BN, int WM, int WN, int STAGES, int MODE>
-__global__ __launch_bounds__(64 * WM * WN) void gemm2_kernel(const avsd_gemm_desc p) {
+// LW > 0 adds LW loader waves to the WM x WN MFMA waves: they alone issue the global->LDS loads (and own the
+// per-piece address state), so the ~100-cycle issue cost of each 1-KiB LDS-DMA piece (every wave of the block pushing
+// its pieces into the texture path right after the barrier) no longer sits in front of the MFMA waves' matrix work.
+// All waves meet at the one barrier per K tile; loaders wait for their loads to land before it.
+template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int LW = 0>
+__global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm2_kernel(const avsd_gemm_desc p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem2[];
-  constexpr int NWAVES = WM * WN;
-  constexpr int NT = 64 * NWAVES;
+  constexpr int NC = WM * WN;               // MFMA waves
+  constexpr int NWAVES = LW > 0 ? LW : NC;  // waves that issue loads
   constexpr int A_BYTES = BM * 128;
   constexpr int W_BYTES = BN * 128;
   constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
-  constexpr int PA = (BM / 8) / NWAVES;   // 1-KiB pieces of the A tile per wave
+  constexpr int PA = (BM / 8) / NWAVES;   // 1-KiB pieces of the A tile per loading wave
   constexpr int PW = (BN / 8) / NWAVES;
   static_assert(PA * NWAVES * 8 == BM && PW * NWAVES * 8 == BN, "tile rows must split evenly into 1-KiB pieces per wave");
-  constexpr int LPT = PA + PW;            // loads per tile per wave
+  constexpr int LPT = PA + PW;            // loads per tile per loading wave
   constexpr int FM = BM / WM / 32;
   constexpr int FN = BN / WN / 32;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave % WM;
-  const int wn = wave / WM;
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_loader = LW == 0 || wave_all >= NC;
+  const int wave = LW == 0 ? wave_all : (wave_all >= NC ? wave_all - NC : 0);   // index among the loading waves
+  const int wm = wave_all % WM;
+  const int wn = (wave_all / WM) % WN;
 
   const int ntm = (p.M + BM - 1) / BM;
   const int ntn = (p.N + BN - 1) / BN;
@@ -602,12 +600,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_kernel(const avsd_gemm_des
   const int chalf = lane >> 5;
 
   const int nk = max(kt1 - kt0, 0);
-#pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s)
-    if (s < nk) issue(s);
-
-  for (int kt = 0; kt < nk; ++kt) {
-    // tiles kt+1 .. kt+STAGES-2 may stay in flight
+  auto wait_stage = [&](int kt) {   // tiles kt+1 .. kt+STAGES-2 may stay in flight
     if constexpr (STAGES == 3) {
       if (kt + 1 < nk) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
     } else if constexpr (STAGES == 4) {
@@ -615,8 +608,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_kernel(const avsd_gemm_des
     } else {   // STAGES == 2: the tile issued during the previous iteration must have landed
       wait_vmcnt<0>();
     }
+  };
+  if (is_loader) {
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+      if (s < nk) issue(s);
+  }
+  if (LW > 0 && is_loader) {
+    for (int kt = 0; kt < nk; ++kt) {
+      wait_stage(kt);
+      __builtin_amdgcn_s_barrier();
+      if (kt + STAGES - 1 < nk) issue((kt + STAGES - 1) % STAGES);
+    }
+    return;
+  }
+
+  for (int kt = 0; kt < nk; ++kt) {
+    if (LW == 0) wait_stage(kt);
     __builtin_amdgcn_s_barrier();
-    if (kt + STAGES - 1 < nk) issue((kt + STAGES - 1) % STAGES);
+    if (LW == 0 && kt + STAGES - 1 < nk) issue((kt + STAGES - 1) % STAGES);
 
     const unsigned char* sA = smem2 + (kt % STAGES) * STAGE_BYTES;
     const unsigned char* sW = sA + A_BYTES;
@@ -711,12 +721,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const avsd_gemm_desc
   }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int MODE>
+template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int LW = 0>
 int launch2(const avsd_gemm_desc& d, hipStream_t s) {
   constexpr size_t lds = (size_t)STAGES * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<BM, BN, WM, WN, STAGES, MODE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<BM, BN, WM, WN, STAGES, MODE, LW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       avsd_set_error("gemm2: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
@@ -727,7 +737,7 @@ int launch2(const avsd_gemm_desc& d, hipStream_t s) {
   const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
   const int nsplit = d.split_k > 1 ? d.split_k : 1;
   dim3 grid((unsigned)(ntm * ntn), (unsigned)nsplit, (unsigned)d.batch);
-  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM, WN, STAGES, MODE>), grid, dim3(64 * WM * WN), lds, s, d);
+  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM, WN, STAGES, MODE, LW>), grid, dim3(64 * (WM * WN + LW)), lds, s, d);
   AVSD_CHECK_LAUNCH("gemm2 launch");
   if (nsplit > 1) {
     const int64_t total = (int64_t)d.M * (d.N / 4);
@@ -761,6 +771,19 @@ int dispatch_tile(const avsd_gemm_desc& d, int tile, hipStream_t s) {
     case 15: return launch2<128, 320, 2, 2, 2, MODE>(d, s);   // 112 KB, 4 waves, 64x160 wave tiles
     case 16: return launch2<64, 320, 2, 2, 3, MODE>(d, s);    // 144 KB, 4 waves, 32x160 wave tiles
     case 17: return launch2<128, 320, 4, 2, 2, MODE>(d, s);   // 112 KB, 8 waves, 32x160 wave tiles
+    // 256-row tiles for the widest layers: (BM + BN) / (BM * BN) global->LDS bytes per MFMA is what the texture path pays
+    case 18: return launch2<256, 256, 4, 2, 2, MODE>(d, s);   // 128 KB, 8 waves, 64x128 wave tiles
+    case 19: return launch2<256, 320, 4, 2, 2, MODE>(d, s);   // 144 KB, 8 waves, 64x160 wave tiles
+    // the same tiles with 2 extra loader waves (LW): the MFMA waves issue no loads
+    case 20: return launch2<256, 128, 4, 2, 3, MODE, 4>(d, s);
+    case 21: return launch2<256, 128, 4, 2, 2, MODE, 4>(d, s);
+    case 22: return launch2<128, 128, 2, 2, 3, MODE, 2>(d, s);
+    case 23: return launch2<128, 320, 4, 2, 2, MODE, 4>(d, s);
+    case 24: return launch2<128, 64, 2, 2, 3, MODE, 2>(d, s);
+    case 25: return launch2<64, 64, 2, 2, 4, MODE, 2>(d, s);
+    case 26: return launch2<128, 128, 2, 4, 3, MODE, 2>(d, s);
+    case 27: return launch2<256, 64, 4, 2, 3, MODE, 2>(d, s);
+    case 28: return launch2<64, 320, 2, 2, 3, MODE, 2>(d, s);
     default: return launch<64, 64, MODE>(d, s);
   }
 }
@@ -827,7 +850,7 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
   if (d.split_k > 1) {
     AVSD_REQUIRE(d.splitk_ws != nullptr, "gemm: split_k needs a workspace");
     AVSD_REQUIRE(!(d.flags & AVSD_GEMM_GEGLU) && d.batch == 1, "gemm: split_k cannot be combined with GEGLU or batching");
-    AVSD_REQUIRE(d.tile >= 4 && d.tile <= 17, "gemm: split_k needs an LDS-direct tile (4..17), got %d", d.tile);
+    AVSD_REQUIRE(d.tile >= 4 && d.tile <= 28, "gemm: split_k needs an LDS-direct tile (4..28), got %d", d.tile);
     AVSD_REQUIRE(d.split_k <= (d.K + 63) / 64, "gemm: split_k (%d) exceeds the number of K tiles", d.split_k);
   }
   int tile = d.tile;
@@ -844,7 +867,7 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
       tile = (d.N > 64 && d.M > 2048) ? 2 : 3;
     }
   }
-  if (tile < 1 || tile > 17) tile = pick_tile(d.M, (d.flags & AVSD_GEMM_GEGLU) ? d.N : d.N, d.batch);
+  if (tile < 1 || tile > 28) tile = pick_tile(d.M, (d.flags & AVSD_GEMM_GEGLU) ? d.N : d.N, d.batch);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (d.mode) {
     case AVSD_GEMM_PLAIN: return dispatch_tile<AVSD_GEMM_PLAIN>(d, tile, s);

@@ -130,14 +130,22 @@ def _evict_weights(warm):
             t.view(torch.int16 if t.element_size() == 2 else torch.int32).max()
 
 
-def _time_hot(launch, cand, reps=4):
+def _time_hot(launch, cand, reps=8):
+    """GPU time per launch of `reps` back-to-back launches replayed from a captured graph: eager launches through
+    Python/ctypes cannot be issued faster than one per ~11 us, which would hide every difference between candidates
+    for the many GEMMs of this UNet that run 10-20 us."""
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            launch(*cand)
+    g.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        launch(*cand)
+    g.replay()
+    g.replay()
     e1.record()
     e1.synchronize()
-    return e0.elapsed_time(e1) / reps
+    return e0.elapsed_time(e1) / (2 * reps)
 
 
 def _time_cold(launch, cand, warm, reps=7):

@@ -7,10 +7,10 @@ import sys
 
 
 def short(name: str) -> str:
-    m = re.search(r"gemm2_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", name)
+    m = re.search(r"gemm2_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?>", name)
     if m:
-        bm, bn, wm, wn, st, mode = m.groups()
-        return f"gemm2<{bm}x{bn},{wm}x{wn}w,{st}st,{('plain','tmix','conv3')[int(mode)]}>"
+        bm, bn, wm, wn, st, mode, lw = m.groups()
+        return f"gemm2<{bm}x{bn},{wm}x{wn}w{'+' + lw + 'L' if lw and lw != '0' else ''},{st}st,{('plain','tmix','conv3')[int(mode)]}>"
     m = re.search(r"gemm_kernel<(\d+), (\d+), (\d+)>", name)
     if m:
         bm, bn, mode = m.groups()

@@ -105,7 +105,61 @@ __device__ __forceinline__ void epilogue(const avsd_gemm_desc& p, f32x16 (&acc)[
     for (int a = 0; a < FN; ++a) {
       const int nb = n_base + a * 32;  // first packed column of this fragment
       if (nb >= p.N) continue;
-      if (!geglu) {
+      // bf16 output, fragment fully inside N, 16-byte-aligned rows: the two lanes that share a row (l, l ^ 32) trade
+      // halves with v_permlane32_swap so each stores (and reads the residuals as) 32 contiguous bytes — two dwordx4
+      // per fragment instead of four dwordx2 scattered 8 bytes apart (store issue, not bandwidth, bounds this tail).
+      const bool wide = !geglu && !out_f32 && nb + 32 <= p.N && (p.ldc & 7) == 0 && (!R1 || (p.ldr1 & 7) == 0) &&
+                        (!R2 || (p.ldr2 & 7) == 0);
+      if (wide) {
+        float v[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = nb + 8 * q + hsel;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[q][i] = p.alpha * acc[a][b][4 * q + i];
+          if (p.bias) {
+            const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+            v[q][0] += bb.x; v[q][1] += bb.y; v[q][2] += bb.z; v[q][3] += bb.w;
+          }
+          if (rv) {
+            const float4 bb = *reinterpret_cast<const float4*>(rv + n);
+            v[q][0] += bb.x; v[q][1] += bb.y; v[q][2] += bb.z; v[q][3] += bb.w;
+          }
+          if (gelu) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[q][i] = gelu_erf_f(v[q][i]);
+          }
+        }
+        const int ncol = nb + 4 * hsel;   // this lane's 16 columns after the swap: nb (lanes 0-31) or nb + 16
+        auto add_res = [&](const bf16_t* R, int ldr) {
+          const bf16_t* rp = R + bz * p.batch_stride_out + (int64_t)m * ldr + ncol;
+          const uint4 lo = *reinterpret_cast<const uint4*>(rp);
+          const uint4 hi = *reinterpret_cast<const uint4*>(rp + 8);
+          const unsigned s0[2] = {lo.x, lo.y}, s1[2] = {lo.z, lo.w}, s2[2] = {hi.x, hi.y}, s3[2] = {hi.z, hi.w};
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            const auto e = __builtin_amdgcn_permlane32_swap(s0[d], s1[d], false, false);   // -> quads 0 and 2
+            const auto o = __builtin_amdgcn_permlane32_swap(s2[d], s3[d], false, false);   // -> quads 1 and 3
+            v[0][2 * d] += __uint_as_float(e[0] << 16); v[0][2 * d + 1] += __uint_as_float(e[0] & 0xffff0000u);
+            v[2][2 * d] += __uint_as_float(e[1] << 16); v[2][2 * d + 1] += __uint_as_float(e[1] & 0xffff0000u);
+            v[1][2 * d] += __uint_as_float(o[0] << 16); v[1][2 * d + 1] += __uint_as_float(o[0] & 0xffff0000u);
+            v[3][2 * d] += __uint_as_float(o[1] << 16); v[3][2 * d + 1] += __uint_as_float(o[1] & 0xffff0000u);
+          }
+        };
+        if (R1) add_res(R1, p.ldr1);
+        if (R2) add_res(R2, p.ldr2);
+        unsigned x[2][2], y[2][2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const auto e = __builtin_amdgcn_permlane32_swap(pack2bf(v[0][2 * d], v[0][2 * d + 1]), pack2bf(v[2][2 * d], v[2][2 * d + 1]), false, false);
+          const auto o = __builtin_amdgcn_permlane32_swap(pack2bf(v[1][2 * d], v[1][2 * d + 1]), pack2bf(v[3][2 * d], v[3][2 * d + 1]), false, false);
+          x[0][d] = e[0]; x[1][d] = e[1];
+          y[0][d] = o[0]; y[1][d] = o[1];
+        }
+        bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + bz * p.batch_stride_out + (int64_t)m * p.ldc + ncol;
+        *reinterpret_cast<uint4*>(op) = make_uint4(x[0][0], x[0][1], x[1][0], x[1][1]);
+        *reinterpret_cast<uint4*>(op + 8) = make_uint4(y[0][0], y[0][1], y[1][0], y[1][1]);
+      } else if (!geglu) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int n = nb + 8 * q + hsel;

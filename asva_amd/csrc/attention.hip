@@ -297,17 +297,35 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
     if (q < p.Lq) {
       bf16_t* orow = p.O + ((int64_t)qb * p.Lq + q) * p.ldo + head * D;
 #pragma unroll
-      for (int b = 0; b < NDB; ++b)
+      for (int b = 0; b < NDB; ++b) {
+        if (b * 32 + 32 <= D && (p.ldo & 7) == 0) {
+          // whole 32-channel block: lanes l and l ^ 32 (same query) trade halves so each stores 32 contiguous bytes
+          unsigned x[2][2], y[2][2];
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const int dcol = b * 32 + 8 * qd + 4 * half;
-          if (dcol < D) {
-            uint2 st;
-            st.x = pack2bf(acc_o[j][b][4 * qd + 0] * inv, acc_o[j][b][4 * qd + 1] * inv);
-            st.y = pack2bf(acc_o[j][b][4 * qd + 2] * inv, acc_o[j][b][4 * qd + 3] * inv);
-            *reinterpret_cast<uint2*>(orow + dcol) = st;
+          for (int d = 0; d < 2; ++d) {
+            const auto e = __builtin_amdgcn_permlane32_swap(pack2bf(acc_o[j][b][2 * d] * inv, acc_o[j][b][2 * d + 1] * inv),
+                                                            pack2bf(acc_o[j][b][8 + 2 * d] * inv, acc_o[j][b][8 + 2 * d + 1] * inv), false, false);
+            const auto o = __builtin_amdgcn_permlane32_swap(pack2bf(acc_o[j][b][4 + 2 * d] * inv, acc_o[j][b][4 + 2 * d + 1] * inv),
+                                                            pack2bf(acc_o[j][b][12 + 2 * d] * inv, acc_o[j][b][12 + 2 * d + 1] * inv), false, false);
+            x[0][d] = e[0]; x[1][d] = e[1];
+            y[0][d] = o[0]; y[1][d] = o[1];
+          }
+          bf16_t* op = orow + b * 32 + 16 * half;
+          *reinterpret_cast<uint4*>(op) = make_uint4(x[0][0], x[0][1], x[1][0], x[1][1]);
+          *reinterpret_cast<uint4*>(op + 8) = make_uint4(y[0][0], y[0][1], y[1][0], y[1][1]);
+        } else {
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            const int dcol = b * 32 + 8 * qd + 4 * half;
+            if (dcol < D) {
+              uint2 st;
+              st.x = pack2bf(acc_o[j][b][4 * qd + 0] * inv, acc_o[j][b][4 * qd + 1] * inv);
+              st.y = pack2bf(acc_o[j][b][4 * qd + 2] * inv, acc_o[j][b][4 * qd + 3] * inv);
+              *reinterpret_cast<uint2*>(orow + dcol) = st;
+            }
           }
         }
+      }
     }
   }
 }

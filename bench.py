@@ -197,13 +197,17 @@ def main():
         ops.set_timer(None)
         fam = timer.summary()
         mm = [fam[k] for k in ("gemm_plain", "gemm_tmix", "gemm_conv3") if k in fam]
-        ms = sum(f["ms"] for f in mm)
+        ms_events = sum(f["ms"] for f in mm)            # sum of per-launch event pairs of the eager pass
         fl = sum(f["flops"] for f in mm)
         launches = sum(f["launches"] for f in mm)
+        # the family's launches of that step re-issued back to back from one captured graph: the event pairs of the eager
+        # pass each carry ~4 us of command-processor time that the graph-replayed step (and its rocprofv3 trace) does not
+        ms = timer.replay_ms(("gemm_plain", "gemm_tmix", "gemm_conv3")) if not a.no_graph else ms_events
         ach = fl / (ms * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<BM,BN,MODE> family (linear / temporal-mix / conv3x3 implicit GEMM)",
                            "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                            "traffic": None, "launches_per_step": launches, "ms_per_step": round(ms, 4),
+                           "ms_per_step_event_pairs": round(ms_events, 4),
                            "avg_launch_us": round(ms * 1e3 / launches, 2), "tflop_per_step": round(fl / 1e12, 4)}
         # HBM-side traffic of the same family from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected in separate
         # runs of this script, FETCH_SIZE doubled per the gfx950 correction); counters cannot be read from inside

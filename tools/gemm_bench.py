@@ -18,7 +18,7 @@ def timeit(fn, iters=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e-3
 
-def bench_plain(M, N, K, tiles=(9, 20, 21, 6, 22, 17, 23, 4, 24, 7, 25, 18), **kw):
+def bench_plain(M, N, K, tiles=(0, 4, 6, 9, 13, 17, 18, 20, 23, 24, 25, 26), **kw):
     a = torch.randn(M, K, device=dev).bfloat16(); w = (torch.randn(N, K, device=dev) * K ** -0.5).bfloat16()
     out = torch.empty(M, N if not kw.get("geglu") else N // 2, device=dev, dtype=torch.bfloat16)
     r = {}
@@ -27,7 +27,7 @@ def bench_plain(M, N, K, tiles=(9, 20, 21, 6, 22, 17, 23, 4, 24, 7, 25, 18), **k
         r[t] = 2.0 * M * N * K / dt / 1e12
     return r
 
-def bench_conv(n_img, h, w_, cin, cout, tiles=(9, 20, 21, 6, 22, 17, 23, 4, 24, 7, 25, 18)):
+def bench_conv(n_img, h, w_, cin, cout, tiles=(0, 4, 6, 9, 13, 17, 18, 20, 23, 24, 25, 26)):
     x = torch.randn(n_img * h * w_, cin, device=dev).bfloat16()
     w = pack_conv3x3((torch.randn(cout, cin, 3, 3, device=dev) * (9 * cin) ** -0.5))
     out = torch.empty(n_img * h * w_, cout, device=dev, dtype=torch.bfloat16)
@@ -37,7 +37,7 @@ def bench_conv(n_img, h, w_, cin, cout, tiles=(9, 20, 21, 6, 22, 17, 23, 4, 24, 
         r[t] = 2.0 * n_img * h * w_ * cout * 9 * cin / dt / 1e12
     return r
 
-def bench_tmix(B, F, hw, C, tiles=(9, 20, 21, 6, 22, 17, 23, 4, 24, 7, 25, 18)):
+def bench_tmix(B, F, hw, C, tiles=(0, 4, 6, 9, 13, 17, 18, 20, 23, 24, 25, 26)):
     y = torch.randn(B * F * hw, C, device=dev).bfloat16(); w = (torch.randn(C, 3 * C, device=dev) * (3 * C) ** -0.5).bfloat16()
     out = torch.empty_like(y)
     r = {}

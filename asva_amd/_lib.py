@@ -35,6 +35,7 @@ class GemmDesc(C.Structure):
         ("cin", C.c_int32), ("stride", C.c_int32), ("ups", C.c_int32), ("pad", C.c_int32),
         ("tile", C.c_int32),
         ("split_k", C.c_int32), ("splitk_ws", c_void_p),
+        ("rowstats", c_void_p), ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("ln_nblk", C.c_int32), ("ln_eps", C.c_float),
     ]
 
 

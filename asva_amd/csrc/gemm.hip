@@ -84,15 +84,41 @@ __device__ __forceinline__ uint4 load_a(const avsd_gemm_desc& p, const bf16_t* A
   return *reinterpret_cast<const uint4*>(ptr);
 }
 
+// LayerNorm statistics of row m of A folded from the producer's per-32-column (sum, sumsq) pairs -> (rstd, mean * rstd)
+__device__ __forceinline__ void ln_row_stats(const avsd_gemm_desc& p, int m, int64_t bz, float& rstd, float& mr) {
+  const float2* st = reinterpret_cast<const float2*>(p.ln_stats) + ((int64_t)bz * (p.batch_stride_a / p.lda) + m) * p.ln_nblk;
+  float sm = 0.f, sq = 0.f;
+  int j = 0;
+  for (; j + 10 <= p.ln_nblk; j += 10) {      // ten independent loads in flight (C = 320 k -> 10 k pairs)
+    float2 t[10];
+#pragma unroll
+    for (int u = 0; u < 10; ++u) t[u] = st[j + u];
+#pragma unroll
+    for (int u = 0; u < 10; ++u) { sm += t[u].x; sq += t[u].y; }
+  }
+  for (; j < p.ln_nblk; ++j) {
+    const float2 t = st[j];
+    sm += t.x;
+    sq += t.y;
+  }
+  const float inv_k = 1.0f / (float)(p.ln_nblk * 32);
+  const float mean = sm * inv_k;
+  const float var = fmaxf(sq * inv_k - mean * mean, 0.f);
+  rstd = rsqrtf(var + p.ln_eps);
+  mr = mean * rstd;
+}
+
 // ---- shared f32 epilogue: lane holds row m = m_base + (lane&31) of fragment b, and columns
 // n = n_base + 32*a + 8q + 4*(lane>>5) + {0..3} of fragment a (see header of this file) ----------------
 template <int FN, int FM>
 __device__ __forceinline__ void epilogue(const avsd_gemm_desc& p, f32x16 (&acc)[FN][FM], int m_base, int n_base,
-                                         int lane, int64_t bz) {
+                                         int lane, int64_t bz, const float (&pre_ln)[2 * FM], bool have_pre) {
   const int frow = lane & 31;
   const bool geglu = (p.flags & AVSD_GEMM_GEGLU) != 0;
   const bool out_f32 = (p.flags & AVSD_GEMM_OUT_F32) != 0;
   const bool gelu = (p.flags & AVSD_GEMM_GELU) != 0;
+  const bool lnfuse = (p.flags & AVSD_GEMM_LNFUSE) != 0;
+  const bool rowstats = (p.flags & AVSD_GEMM_ROWSTATS) != 0;
   const bf16_t* R1 = reinterpret_cast<const bf16_t*>(p.res1);
   const bf16_t* R2 = reinterpret_cast<const bf16_t*>(p.res2);
   const int hsel = (lane >> 5) * 4;
@@ -101,6 +127,13 @@ __device__ __forceinline__ void epilogue(const avsd_gemm_desc& p, f32x16 (&acc)[
     const int m = m_base + b * 32 + frow;
     if (m >= p.M) continue;
     const float* rv = p.rowvec ? p.rowvec + (int64_t)(m / p.rows_per_vec) * p.ldv : nullptr;
+    // AVSD_GEMM_LNFUSE: LayerNorm statistics of this lane's row of A (rstd, mean * rstd)
+    float ln_rstd = 1.f, ln_mr = 0.f;
+    if (lnfuse) {
+      if (have_pre) { ln_rstd = pre_ln[2 * b]; ln_mr = pre_ln[2 * b + 1]; }
+      else ln_row_stats(p, m, bz, ln_rstd, ln_mr);
+    }
+    float2* rs_out = rowstats ? reinterpret_cast<float2*>(p.rowstats) + ((int64_t)bz * p.M + m) * (p.N >> 5) : nullptr;
 #pragma unroll
     for (int a = 0; a < FN; ++a) {
       const int nb = n_base + a * 32;  // first packed column of this fragment
@@ -117,6 +150,11 @@ __device__ __forceinline__ void epilogue(const avsd_gemm_desc& p, f32x16 (&acc)[
           const int n = nb + 8 * q + hsel;
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[q][i] = p.alpha * acc[a][b][4 * q + i];
+          if (lnfuse) {
+            const float4 cs = *reinterpret_cast<const float4*>(p.ln_colsum + n);
+            v[q][0] = fmaf(v[q][0], ln_rstd, -ln_mr * cs.x); v[q][1] = fmaf(v[q][1], ln_rstd, -ln_mr * cs.y);
+            v[q][2] = fmaf(v[q][2], ln_rstd, -ln_mr * cs.z); v[q][3] = fmaf(v[q][3], ln_rstd, -ln_mr * cs.w);
+          }
           if (p.bias) {
             const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
             v[q][0] += bb.x; v[q][1] += bb.y; v[q][2] += bb.z; v[q][3] += bb.w;
@@ -159,6 +197,22 @@ __device__ __forceinline__ void epilogue(const avsd_gemm_desc& p, f32x16 (&acc)[
         bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + bz * p.batch_stride_out + (int64_t)m * p.ldc + ncol;
         *reinterpret_cast<uint4*>(op) = make_uint4(x[0][0], x[0][1], x[1][0], x[1][1]);
         *reinterpret_cast<uint4*>(op + 8) = make_uint4(y[0][0], y[0][1], y[1][0], y[1][1]);
+        if (rs_out) {
+          // (sum, sum of squares) of the 16 rounded values this lane just stored, plus the partner lane's 16
+          float sm = 0.f, sq = 0.f;
+          const unsigned w8[8] = {x[0][0], x[0][1], x[1][0], x[1][1], y[0][0], y[0][1], y[1][0], y[1][1]};
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float lo = __uint_as_float(w8[i] << 16), hi = __uint_as_float(w8[i] & 0xffff0000u);
+            sm += lo + hi;
+            sq = fmaf(lo, lo, fmaf(hi, hi, sq));
+          }
+          const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(sm), __float_as_uint(sm), false, false);
+          const auto u = __builtin_amdgcn_permlane32_swap(__float_as_uint(sq), __float_as_uint(sq), false, false);
+          // lanes 0-31: t = (own, partner's); fixed order low half + high half on both lanes
+          if (hsel == 0) rs_out[nb >> 5] = make_float2(__uint_as_float(t[0]) + __uint_as_float(t[1]),
+                                                       __uint_as_float(u[0]) + __uint_as_float(u[1]));
+        }
       } else if (!geglu) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -167,6 +221,11 @@ __device__ __forceinline__ void epilogue(const avsd_gemm_desc& p, f32x16 (&acc)[
           float v[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[i] = p.alpha * acc[a][b][4 * q + i];
+          if (lnfuse) {
+            const float4 cs = *reinterpret_cast<const float4*>(p.ln_colsum + n);
+            v[0] = fmaf(v[0], ln_rstd, -ln_mr * cs.x); v[1] = fmaf(v[1], ln_rstd, -ln_mr * cs.y);
+            v[2] = fmaf(v[2], ln_rstd, -ln_mr * cs.z); v[3] = fmaf(v[3], ln_rstd, -ln_mr * cs.w);
+          }
           if (p.bias) {
             const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
             v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
@@ -210,6 +269,10 @@ __device__ __forceinline__ void epilogue(const avsd_gemm_desc& p, f32x16 (&acc)[
           for (int i = 0; i < 4; ++i) {
             float val = p.alpha * acc[a][b][4 * q + i];
             float gate = p.alpha * acc[a][b][4 * (q + 2) + i];
+            if (lnfuse) {
+              val = fmaf(val, ln_rstd, -ln_mr * p.ln_colsum[nval + i]);
+              gate = fmaf(gate, ln_rstd, -ln_mr * p.ln_colsum[ngate + i]);
+            }
             if (p.bias) {
               val += p.bias[nval + i];
               gate += p.bias[ngate + i];
@@ -343,7 +406,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const avsd_gemm_desc p) {
     __syncthreads();
   }
 
-  epilogue<FN, FM>(p, acc, tm * BM + wm * (BM / 2), tn * BN + wn * (BN / 2), lane, bz);
+  const float no_pre[2 * FM] = {};
+  epilogue<FN, FM>(p, acc, tm * BM + wm * (BM / 2), tn * BN + wn * (BN / 2), lane, bz, no_pre, false);
 }
 
 template <int BM, int BN, int MODE>
@@ -668,6 +732,18 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm2_kernel(const avsd_g
     for (int s = 0; s < STAGES - 1; ++s)
       if (s < nk) issue(s);
   }
+  // LayerNorm statistics of this wave's rows, fetched while the prologue tiles are in flight (their round trip would
+  // otherwise sit in the epilogue)
+  float pre_ln[2 * FM] = {};
+  const bool pre = (p.flags & AVSD_GEMM_LNFUSE) != 0 && !(LW > 0 && is_loader);
+  if (pre) {
+#pragma unroll
+    for (int b = 0; b < FM; ++b) {
+      const int m = tm * BM + wm * (BM / WM) + b * 32 + (lane & 31);
+      pre_ln[2 * b] = 1.f; pre_ln[2 * b + 1] = 0.f;
+      if (m < p.M) ln_row_stats(p, m, bz, pre_ln[2 * b], pre_ln[2 * b + 1]);
+    }
+  }
   if (LW > 0 && is_loader) {
     for (int kt = 0; kt < nk; ++kt) {
       wait_stage(kt);
@@ -724,7 +800,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm2_kernel(const avsd_g
     }
     return;
   }
-  epilogue<FN, FM>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz);
+  epilogue<FN, FM>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
 }
 
 // out = epilogue(sum_s ws[s]) for split-K launches: one thread per 4 consecutive columns
@@ -742,6 +818,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const avsd_gemm_desc
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
     float v[4] = {p.alpha * acc.x, p.alpha * acc.y, p.alpha * acc.z, p.alpha * acc.w};
+    if (p.flags & AVSD_GEMM_LNFUSE) {
+      const float2* st = reinterpret_cast<const float2*>(p.ln_stats) + (int64_t)m * p.ln_nblk;
+      float sm = 0.f, sq = 0.f;
+      for (int j = 0; j < p.ln_nblk; ++j) { const float2 t = st[j]; sm += t.x; sq += t.y; }
+      const float inv_k = 1.0f / (float)(p.ln_nblk * 32);
+      const float mean = sm * inv_k;
+      const float rstd = rsqrtf(fmaxf(sq * inv_k - mean * mean, 0.f) + p.ln_eps);
+      const float4 cs = *reinterpret_cast<const float4*>(p.ln_colsum + n);
+      v[0] = fmaf(v[0], rstd, -mean * rstd * cs.x); v[1] = fmaf(v[1], rstd, -mean * rstd * cs.y);
+      v[2] = fmaf(v[2], rstd, -mean * rstd * cs.z); v[3] = fmaf(v[3], rstd, -mean * rstd * cs.w);
+    }
     if (p.bias) {
       const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
       v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
@@ -771,6 +858,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const avsd_gemm_desc
       st.x = pack2bf(v[0], v[1]);
       st.y = pack2bf(v[2], v[3]);
       *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + o) = st;
+      if (p.flags & AVSD_GEMM_ROWSTATS) {
+        // 8 consecutive threads hold one 32-column block of row m (N % 32 == 0, 256 % 8 == 0): fold in a fixed order
+        const float a0 = __uint_as_float(st.x << 16), a1 = __uint_as_float(st.x & 0xffff0000u);
+        const float a2 = __uint_as_float(st.y << 16), a3 = __uint_as_float(st.y & 0xffff0000u);
+        float sm = (a0 + a1) + (a2 + a3);
+        float sq = fmaf(a0, a0, fmaf(a1, a1, fmaf(a2, a2, a3 * a3)));
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+          sm += __shfl_xor(sm, off, 64);
+          sq += __shfl_xor(sq, off, 64);
+        }
+        if ((threadIdx.x & 7) == 0)
+          reinterpret_cast<float2*>(p.rowstats)[(int64_t)m * (p.N >> 5) + (n >> 5)] = make_float2(sm, sq);
+      }
     }
   }
 }
@@ -880,6 +981,18 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
   if (d.batch <= 0) d.batch = 1;
   if (d.flags & AVSD_GEMM_GEGLU) AVSD_REQUIRE(d.N % 32 == 0, "gemm: GEGLU needs N %% 32 == 0 (got %d)", d.N);
   AVSD_REQUIRE(!((d.flags & AVSD_GEMM_GEGLU) && (d.flags & AVSD_GEMM_GELU)), "gemm: GEGLU and GELU are exclusive");
+  if (d.flags & AVSD_GEMM_ROWSTATS) {
+    AVSD_REQUIRE(d.rowstats, "gemm: ROWSTATS without a rowstats buffer");
+    AVSD_REQUIRE(!(d.flags & (AVSD_GEMM_GEGLU | AVSD_GEMM_OUT_F32)) && d.N % 32 == 0 && d.ldc % 8 == 0 &&
+                     (!d.res1 || d.ldr1 % 8 == 0) && (!d.res2 || d.ldr2 % 8 == 0),
+                 "gemm: ROWSTATS needs bf16 output, N %% 32 == 0 and 16-byte-aligned rows");
+  }
+  if (d.flags & AVSD_GEMM_LNFUSE) {
+    AVSD_REQUIRE(d.ln_stats && d.ln_colsum && d.ln_nblk > 0 && d.mode == AVSD_GEMM_PLAIN && !d.A2,
+                 "gemm: LNFUSE needs ln_stats, ln_colsum, ln_nblk and a single-source PLAIN operand");
+    AVSD_REQUIRE(d.ln_nblk * 32 == d.K, "gemm: LNFUSE statistics cover %d columns, K = %d", d.ln_nblk * 32, d.K);
+    AVSD_REQUIRE(d.batch == 1 || d.batch_stride_a % d.lda == 0, "gemm: LNFUSE batch stride must be whole rows");
+  }
   if (d.res1) AVSD_REQUIRE(d.ldr1 % 4 == 0, "gemm: ldr1 must be a multiple of 4");
   if (d.res2) AVSD_REQUIRE(d.ldr2 % 4 == 0, "gemm: ldr2 must be a multiple of 4");
   if (d.rowvec) AVSD_REQUIRE(d.rows_per_vec > 0 && d.ldv % 4 == 0, "gemm: rowvec needs rows_per_vec > 0 and ldv %% 4 == 0");

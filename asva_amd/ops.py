@@ -16,7 +16,7 @@ from . import _lib
 from ._lib import GemmDesc, check
 
 PLAIN, TMIX, CONV3 = 0, 1, 2
-GEGLU, OUT_F32, GELU, XCD_N = 1, 2, 4, 8
+GEGLU, OUT_F32, GELU, XCD_N, ROWSTATS, LNFUSE = 1, 2, 4, 8, 16, 32
 _XCD_MODE = os.environ.get("AVSD_XCD_MODE", "auto")     # auto | m | n  (which operand each XCD's L2 fetches once)
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -240,6 +240,8 @@ def gemm(
     alpha: float = 1.0,
     geglu: bool = False,
     gelu: bool = False,
+    rowstats: Optional[torch.Tensor] = None,   # out: f32 [M, N/32, 2] (sum, sumsq) of the rounded outputs per 32 columns
+    ln: Optional[tuple] = None,                # (stats [rows, K/32, 2] f32, colsum [N] f32, eps): LayerNorm(A) folded in
     out_f32: bool = False,
     out: Optional[torch.Tensor] = None,
     mode: int = PLAIN,
@@ -306,6 +308,20 @@ def gemm(
     d.alpha = alpha
     d.mode = mode
     d.flags = (GEGLU if geglu else 0) | (OUT_F32 if out_f32 else 0) | (GELU if gelu else 0)
+    if rowstats is not None:
+        _req(rowstats, F32, "rowstats")
+        if not rowstats.is_contiguous() or rowstats.numel() != M * (N // 32) * 2:
+            raise ValueError("gemm: rowstats must be contiguous f32 [M, N/32, 2]")
+        d.rowstats = _p(rowstats)
+        d.flags |= ROWSTATS
+    if ln is not None:
+        st, colsum, eps = ln
+        _req(st, F32, "ln stats")
+        _req(colsum, F32, "ln colsum")
+        if not st.is_contiguous() or st.shape[-2:] != (K // 32, 2) or colsum.numel() != N:
+            raise ValueError("gemm: ln = (stats [rows, K/32, 2], colsum [N], eps)")
+        d.ln_stats, d.ln_colsum, d.ln_nblk, d.ln_eps = _p(st), _p(colsum), K // 32, float(eps)
+        d.flags |= LNFUSE
     # XCD banding: the 8 L2s are not shared, so whichever operand is NOT banded is fetched by all 8 of them
     a_bytes = M * (K // 9 if mode == CONV3 else K // 3 if mode == TMIX else K)
     if _XCD_MODE == "n" or (_XCD_MODE == "auto" and N * K > a_bytes):
@@ -339,14 +355,14 @@ def gemm(
         fam = ("gemm_plain", "gemm_tmix", "gemm_conv3")[mode]
         dc = GemmDesc.from_buffer_copy(d)
         _TIMER.add_replay(fam, lambda dc=dc: check(_lib.lib().avsd_gemm_bf16(C.byref(dc), _stream()), "avsd_gemm_bf16"),
-                          (a, a2, w, out, bias, rowvec, res1, res2, ws))
+                          (a, a2, w, out, bias, rowvec, res1, res2, ws, rowstats, ln))
         _TIMER.stop(ev, fam, 2.0 * M * N * K, 2.0 * M * K * (1.0 / 9 if mode == CONV3 else 1.0 / 3 if mode == TMIX else 1.0)
                     + 2.0 * N * K + _nbytes(out, res1, res2))
     return out
 
 
 def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, alpha: float = 1.0, out_f32: bool = False,
-                 bias: Optional[torch.Tensor] = None, tile: int = 0) -> torch.Tensor:
+                 bias: Optional[torch.Tensor] = None, tile: int = 0, ln: Optional[tuple] = None) -> torch.Tensor:
     """out[b] = alpha * a[b] . w[b]^T for 3-D a [B, M, K], w [B, N, K] (VAE mid-block attention)."""
     _req(a, BF16, "a")
     _req(w, BF16, "w")
@@ -362,6 +378,12 @@ def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, alpha: float = 1.0, out_f3
     if bias is not None:
         _req(bias, F32, "bias")
         d.bias = _p(bias)
+    if ln is not None:          # statistics are indexed by the row of the full tensor the batches are views of
+        st, colsum, eps = ln
+        _req(st, F32, "ln stats")
+        _req(colsum, F32, "ln colsum")
+        d.ln_stats, d.ln_colsum, d.ln_nblk, d.ln_eps = _p(st), _p(colsum), K // 32, float(eps)
+        d.flags |= LNFUSE
     if tile == 0:
         def _launch(t):
             d.tile = t

@@ -33,6 +33,9 @@ UP_TYPES = ("FFSpatioAudioTempCrossAttnUpBlock3D", "FFSpatioTempCrossAttnUpBlock
 MID_TYPES = ("FFSpatioAudioTempCrossAttnUNetMidBlock3D", "FFSpatioTempCrossAttnUNetMidBlock3D")
 
 
+_FUSE_LN = os.environ.get("AVSD_FUSE_LN", "1") != "0"    # fold LayerNorm 1 / audio / 2 / 3 into the GEMMs around them
+
+
 class FrozenConfig(dict):
     """Attribute-style read access, like diffusers' FrozenDict (`unet.config.in_channels`)."""
 
@@ -523,7 +526,19 @@ class AudioUNet3DConditionModel(nn.Module):
         def conv1(m: _Conv):
             return _Pk(w=reg(pack_conv1x1(m.weight.float())), b=reg(m.bias.detach().float()))
 
-        def attn(m: _Attention, fuse_qkv: bool):
+        def lnfold(w: torch.Tensor, norm: _Affine, bias: Optional[torch.Tensor] = None):
+            """Linear(LayerNorm(x)) as one GEMM on the raw x (AVSD_GEMM_LNFUSE, include/avsd.h): the gain goes into the
+            weight, the shift into the bias, and the column sums of the ROUNDED folded weight carry the mean."""
+            g, be = norm.weight.detach().float(), norm.bias.detach().float()
+            wf = pack_linear(w * g[None, :])
+            cb = w @ be
+            if bias is not None:
+                cb = cb + bias
+            return wf, wf.float().sum(1), cb
+
+        def attn(m: _Attention, fuse_qkv: bool, norm: Optional[_Affine] = None, fold_kv: bool = False):
+            """norm: the LayerNorm in front of this attention; when given, its affine is folded into to_q (and, for the
+            self-attention, into to_k/to_v) so the layer reads the un-normalised residual stream."""
             wq, wk, wv = (x.weight.detach().float() for x in (m.to_q, m.to_k, m.to_v))
             o = m.to_out[0]
             p = _Pk(wo=reg(pack_linear(o.weight.float())), bo=reg(o.bias.detach().float()))
@@ -532,6 +547,12 @@ class AudioUNet3DConditionModel(nn.Module):
             else:
                 p.wq = reg(pack_linear(wq))
                 p.wkv = reg(pack_linear(torch.cat([wk, wv], 0)))
+            if norm is not None:
+                wf, cs, cb = lnfold(wq, norm)
+                p.wq_ln, p.sq_ln, p.bq_ln = reg(wf), reg(cs), reg(cb)
+                if fold_kv:
+                    wf, cs, cb = lnfold(torch.cat([wk, wv], 0), norm)
+                    p.wkv_ln, p.skv_ln, p.bkv_ln = reg(wf), reg(cs), reg(cb)
             return p
 
         temb_w, temb_b, temb_off = [], [], [0]
@@ -548,16 +569,20 @@ class AudioUNet3DConditionModel(nn.Module):
         def tr(m: _Transformer3D):
             b = m.transformer_blocks[0]
             w1, b1 = pack_geglu(b.ff.net[0].proj.weight.detach().float(), b.ff.net[0].proj.bias.detach().float())
+            w1f = b.ff.net[0].proj.weight.detach().float()
+            g3, be3 = b.norm3.weight.detach().float(), b.norm3.bias.detach().float()
+            w1_ln, b1_ln = pack_geglu(w1f * g3[None, :], w1f @ be3 + b.ff.net[0].proj.bias.detach().float())
             p = _Pk(norm=aff(m.norm), proj_in=conv1(m.proj_in), proj_out=conv1(m.proj_out),
-                    norm1=aff(b.norm1), attn1=attn(b.attn1, False),
-                    norm2=aff(b.norm2), attn2=attn(b.attn2, False),
+                    norm1=aff(b.norm1), attn1=attn(b.attn1, False, b.norm1, fold_kv=True),
+                    norm2=aff(b.norm2), attn2=attn(b.attn2, False, b.norm2),
+                    w1_ln=reg(w1_ln), b1_ln=reg(b1_ln), s1_ln=reg(w1_ln.float().sum(1)),
                     norm_temp=aff(b.norm_temp), attn_temp=attn(b.attn_temp, True),
                     pos1=lin(b.pos_embedding_temp.linear_1), pos2=lin(b.pos_embedding_temp.linear_2),
                     norm3=aff(b.norm3), w1=reg(w1), b1=reg(b1), ff2=lin(b.ff.net[2]),
                     dim=m.proj_in.weight.shape[0], audio=hasattr(b, "attn_audio"))
             if p.audio:
                 p.norm_audio = aff(b.norm_audio)
-                p.attn_audio = attn(b.attn_audio, False)
+                p.attn_audio = attn(b.attn_audio, False, b.norm_audio)
             return p
 
         def block(m: _Block):
@@ -845,36 +870,80 @@ class AudioUNet3DConditionModel(nn.Module):
         c = st.cond.blocks[st.tr_i]
         st.tr_i += 1
         n = ops.groupnorm(x, None, B * Fr, L, st.groups, p.norm.g, p.norm.b, 1e-6, False)
-        h = ops.gemm(n, p.proj_in.w, bias=p.proj_in.b)
-        # 1. first-frame attention: Q from every frame, K/V projected for frame 0 only (utils.py:133-143)
-        n1 = ops.layernorm(h, p.norm1.g, p.norm1.b)
-        q = ops.gemm(n1, p.attn1.wq)
-        kv = ops.gemm_batched(n1.view(B, Fr * L, C)[:, :L], p.attn1.wkv.unsqueeze(0).expand(B, 2 * C, C)).view(B * L, 2 * C)
-        o = ops.attention(q, kv[:, :C], kv[:, C:], bq=B * Fr, lq=L, lk=L, kv_rows=L, heads=heads, q_per_kv=Fr, frames=Fr)
-        h = ops.gemm(o, p.attn1.wo, bias=p.attn1.bo, res1=h)
-        # 2. audio cross-attention: cached K/V, segment mask as a key gather (:315-325)
-        if p.audio:
-            na = ops.layernorm(h, p.norm_audio.g, p.norm_audio.b)
-            q = ops.gemm(na, p.attn_audio.wq)
-            idx = st.cond.key_index
-            o = ops.attention(q, c.audio_kv[:, :C], c.audio_kv[:, C:], bq=B * Fr, lq=L,
-                              lk=idx.shape[1] if idx is not None else c.audio_len, kv_rows=c.audio_len, heads=heads,
-                              q_per_kv=Fr if c.audio_pf == 1 else 1, frames=st.cond.idx_frames if idx is not None else Fr,
-                              key_index=idx)
-            h = ops.gemm(o, p.attn_audio.wo, bias=p.attn_audio.bo, res1=h)
-        # 3. text cross-attention: cached K/V (:328-341)
-        n2 = ops.layernorm(h, p.norm2.g, p.norm2.b)
-        q = ops.gemm(n2, p.attn2.wq)
-        o = ops.attention(q, c.text_kv[:, :C], c.text_kv[:, C:], bq=B * Fr, lq=L, lk=c.text_len, kv_rows=c.text_len,
-                          heads=heads, q_per_kv=Fr if c.text_pf == 1 else 1, frames=Fr)
-        h = ops.gemm(o, p.attn2.wo, bias=p.attn2.bo, res1=h)
-        # 4. temporal attention across frames per pixel; LN(h + pos[f]); residual is h itself (:346-358)
-        nt = ops.layernorm(h, p.norm_temp.g, p.norm_temp.b, pos=c.pos, hw=L, frames=Fr)
-        qkv = ops.gemm(nt, p.attn_temp.wqkv)
-        o = ops.temporal_attention(qkv, b=B, frames=Fr, hw=L, heads=heads)
-        h = ops.gemm(o, p.attn_temp.wo, bias=p.attn_temp.bo, res1=h)
-        # 5. GEGLU feed-forward, activation fused in the first GEMM's epilogue (:361-371)
-        n3 = ops.layernorm(h, p.norm3.g, p.norm3.b)
-        g = ops.gemm(n3, p.w1, bias=p.b1, geglu=True)
-        h = ops.gemm(g, p.ff2.w, bias=p.ff2.b, res1=h)
+        if C % 32 == 0 and getattr(self, "fuse_layernorm", _FUSE_LN):
+            # LayerNorms 1 / audio / 2 / 3 are not launched: the GEMM that produces the residual stream also emits per-row
+            # (sum, sumsq) pairs, and the projections that follow fold mean / rstd into their epilogue (gain and shift live
+            # in the packed weights: pack().lnfold).  norm_temp (+ position table) stays a kernel.
+            eps = 1e-5
+            M = B * Fr * L
+            stats = [torch.empty((M, C // 32, 2), dtype=torch.float32, device=x.device) for _ in range(2)]
+            si = 0
+            h = ops.gemm(n, p.proj_in.w, bias=p.proj_in.b, rowstats=stats[si])
+            # 1. first-frame attention: Q from every frame, K/V projected for frame 0 only (utils.py:133-143)
+            a1 = p.attn1
+            q = ops.gemm(h, a1.wq_ln, bias=a1.bq_ln, ln=(stats[si], a1.sq_ln, eps))
+            kv = ops.gemm_batched(h.view(B, Fr * L, C)[:, :L], a1.wkv_ln.unsqueeze(0).expand(B, 2 * C, C), bias=a1.bkv_ln,
+                                  ln=(stats[si], a1.skv_ln, eps)).view(B * L, 2 * C)
+            o = ops.attention(q, kv[:, :C], kv[:, C:], bq=B * Fr, lq=L, lk=L, kv_rows=L, heads=heads, q_per_kv=Fr, frames=Fr)
+            si ^= 1
+            h = ops.gemm(o, a1.wo, bias=a1.bo, res1=h, rowstats=stats[si])
+            # 2. audio cross-attention: cached K/V, segment mask as a key gather (:315-325)
+            if p.audio:
+                aa = p.attn_audio
+                q = ops.gemm(h, aa.wq_ln, bias=aa.bq_ln, ln=(stats[si], aa.sq_ln, eps))
+                idx = st.cond.key_index
+                o = ops.attention(q, c.audio_kv[:, :C], c.audio_kv[:, C:], bq=B * Fr, lq=L,
+                                  lk=idx.shape[1] if idx is not None else c.audio_len, kv_rows=c.audio_len, heads=heads,
+                                  q_per_kv=Fr if c.audio_pf == 1 else 1, frames=st.cond.idx_frames if idx is not None else Fr,
+                                  key_index=idx)
+                si ^= 1
+                h = ops.gemm(o, aa.wo, bias=aa.bo, res1=h, rowstats=stats[si])
+            # 3. text cross-attention: cached K/V (:328-341)
+            a2 = p.attn2
+            q = ops.gemm(h, a2.wq_ln, bias=a2.bq_ln, ln=(stats[si], a2.sq_ln, eps))
+            o = ops.attention(q, c.text_kv[:, :C], c.text_kv[:, C:], bq=B * Fr, lq=L, lk=c.text_len, kv_rows=c.text_len,
+                              heads=heads, q_per_kv=Fr if c.text_pf == 1 else 1, frames=Fr)
+            h = ops.gemm(o, a2.wo, bias=a2.bo, res1=h)
+            # 4. temporal attention across frames per pixel; LN(h + pos[f]); residual is h itself (:346-358)
+            nt = ops.layernorm(h, p.norm_temp.g, p.norm_temp.b, pos=c.pos, hw=L, frames=Fr)
+            qkv = ops.gemm(nt, p.attn_temp.wqkv)
+            o = ops.temporal_attention(qkv, b=B, frames=Fr, hw=L, heads=heads)
+            si ^= 1
+            h = ops.gemm(o, p.attn_temp.wo, bias=p.attn_temp.bo, res1=h, rowstats=stats[si])
+            # 5. GEGLU feed-forward, activation fused in the first GEMM's epilogue (:361-371)
+            g = ops.gemm(h, p.w1_ln, bias=p.b1_ln, geglu=True, ln=(stats[si], p.s1_ln, eps))
+            h = ops.gemm(g, p.ff2.w, bias=p.ff2.b, res1=h)
+        else:      # channel counts the 32-column statistics blocks do not tile (tiny test configurations)
+            h = ops.gemm(n, p.proj_in.w, bias=p.proj_in.b)
+            # 1. first-frame attention: Q from every frame, K/V projected for frame 0 only (utils.py:133-143)
+            n1 = ops.layernorm(h, p.norm1.g, p.norm1.b)
+            q = ops.gemm(n1, p.attn1.wq)
+            kv = ops.gemm_batched(n1.view(B, Fr * L, C)[:, :L], p.attn1.wkv.unsqueeze(0).expand(B, 2 * C, C)).view(B * L, 2 * C)
+            o = ops.attention(q, kv[:, :C], kv[:, C:], bq=B * Fr, lq=L, lk=L, kv_rows=L, heads=heads, q_per_kv=Fr, frames=Fr)
+            h = ops.gemm(o, p.attn1.wo, bias=p.attn1.bo, res1=h)
+            # 2. audio cross-attention: cached K/V, segment mask as a key gather (:315-325)
+            if p.audio:
+                na = ops.layernorm(h, p.norm_audio.g, p.norm_audio.b)
+                q = ops.gemm(na, p.attn_audio.wq)
+                idx = st.cond.key_index
+                o = ops.attention(q, c.audio_kv[:, :C], c.audio_kv[:, C:], bq=B * Fr, lq=L,
+                                  lk=idx.shape[1] if idx is not None else c.audio_len, kv_rows=c.audio_len, heads=heads,
+                                  q_per_kv=Fr if c.audio_pf == 1 else 1, frames=st.cond.idx_frames if idx is not None else Fr,
+                                  key_index=idx)
+                h = ops.gemm(o, p.attn_audio.wo, bias=p.attn_audio.bo, res1=h)
+            # 3. text cross-attention: cached K/V (:328-341)
+            n2 = ops.layernorm(h, p.norm2.g, p.norm2.b)
+            q = ops.gemm(n2, p.attn2.wq)
+            o = ops.attention(q, c.text_kv[:, :C], c.text_kv[:, C:], bq=B * Fr, lq=L, lk=c.text_len, kv_rows=c.text_len,
+                              heads=heads, q_per_kv=Fr if c.text_pf == 1 else 1, frames=Fr)
+            h = ops.gemm(o, p.attn2.wo, bias=p.attn2.bo, res1=h)
+            # 4. temporal attention across frames per pixel; LN(h + pos[f]); residual is h itself (:346-358)
+            nt = ops.layernorm(h, p.norm_temp.g, p.norm_temp.b, pos=c.pos, hw=L, frames=Fr)
+            qkv = ops.gemm(nt, p.attn_temp.wqkv)
+            o = ops.temporal_attention(qkv, b=B, frames=Fr, hw=L, heads=heads)
+            h = ops.gemm(o, p.attn_temp.wo, bias=p.attn_temp.bo, res1=h)
+            # 5. GEGLU feed-forward, activation fused in the first GEMM's epilogue (:361-371)
+            n3 = ops.layernorm(h, p.norm3.g, p.norm3.b)
+            g = ops.gemm(n3, p.w1, bias=p.b1, geglu=True)
+            h = ops.gemm(g, p.ff2.w, bias=p.ff2.b, res1=h)
         return ops.gemm(h, p.proj_out.w, bias=p.proj_out.b, res1=x)

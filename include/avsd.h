@@ -33,7 +33,7 @@ extern "C" {
 #define AVSD_ELAUNCH (-2)  /* hipLaunch / runtime error                          */
 #define AVSD_ENODEV (-3)   /* no gfx950 device / wrong architecture              */
 
-#define AVSD_ABI_VERSION 1
+#define AVSD_ABI_VERSION 2
 
 /* ---- library ------------------------------------------------------------------------ */
 int avsd_abi_version(void);
@@ -72,7 +72,8 @@ int avsd_device_info(char* name_host, int len, int* num_cu_host);
  * blockIdx.z batches: pointers advance by batch_stride_* elements (0 = shared).
  */
 enum { AVSD_GEMM_PLAIN = 0, AVSD_GEMM_TMIX = 1, AVSD_GEMM_CONV3 = 2 };
-enum { AVSD_GEMM_GEGLU = 1, AVSD_GEMM_OUT_F32 = 2, AVSD_GEMM_GELU = 4, AVSD_GEMM_XCD_N = 8 };
+enum { AVSD_GEMM_GEGLU = 1, AVSD_GEMM_OUT_F32 = 2, AVSD_GEMM_GELU = 4, AVSD_GEMM_XCD_N = 8, AVSD_GEMM_ROWSTATS = 16,
+       AVSD_GEMM_LNFUSE = 32 };
 
 typedef struct avsd_gemm_desc {
   const void* A;        /* bf16 */
@@ -103,6 +104,20 @@ typedef struct avsd_gemm_desc {
    * Deterministic (no atomics).  split_k <= 1 disables it.  Not combinable with GEGLU or batch > 1. */
   int32_t split_k;
   float* splitk_ws;
+  /* LayerNorm folded into the GEMMs around it (ff_spatio_audio_temp_transformer_3d.py:300-371: every LayerNorm there
+   * feeds linear layers only).  Producer side, AVSD_GEMM_ROWSTATS: besides `out`, the epilogue writes for every row m and
+   * every 32-column block j the pair (sum, sum of squares) of the bf16-ROUNDED outputs to rowstats[(m * N/32 + j) * 2]
+   * (N % 32 == 0; deterministic, no atomics).  Consumer side, AVSD_GEMM_LNFUSE: A is the un-normalised tensor, W has
+   * the LayerNorm gain folded in (W' = W * gamma along K), ln_colsum[n] = sum_k W'[n, k], `bias` carries
+   * sum_k beta[k] W[n, k] (+ the layer's own bias), and the epilogue computes
+   *     v = rstd[m] * (alpha * acc - mean[m] * ln_colsum[n]) + bias[n] + ...
+   * with mean / rstd of row m folded from the ln_nblk (= K / 32) pairs of ln_stats — exactly LayerNorm(A) . W^T + b.
+   * Batched launches read the statistics of row (batch * batch_stride_a / lda + m). */
+  float* rowstats;
+  const float* ln_stats;
+  const float* ln_colsum;
+  int32_t ln_nblk;
+  float ln_eps;
 } avsd_gemm_desc;
 
 int avsd_gemm_bf16(const avsd_gemm_desc* desc_host, void* stream);

@@ -17,7 +17,8 @@ BF16, F32 = torch.bfloat16, torch.float32
 
 
 def gemm(a, w, *, n=None, k=None, a2=None, bias=None, rowvec=None, rows_per_vec=0, res1=None, res2=None, alpha=1.0,
-         geglu=False, gelu=False, out_f32=False, out=None, mode=PLAIN, tmix=None, conv=None, m=None, tile=0, split_k=1):
+         geglu=False, gelu=False, out_f32=False, out=None, mode=PLAIN, tmix=None, conv=None, m=None, tile=0, split_k=1,
+         rowstats=None, ln=None):
     assert a.dtype == BF16 and w.dtype == BF16
     wf = w.float()
     if mode == PLAIN:
@@ -45,6 +46,8 @@ def gemm(a, w, *, n=None, k=None, a2=None, bias=None, rowvec=None, rows_per_vec=
         x = cols.reshape(n_img, cin, 9, L).permute(0, 3, 2, 1).reshape(n_img * L, 9 * cin)   # tap-major, c-minor
     assert x.shape[1] == wf.shape[1], (x.shape, wf.shape)
     acc = alpha * (x @ wf.T)
+    if ln is not None:          # LayerNorm(A) folded in: W carries gamma, bias carries beta . W^T (see avsd.h)
+        acc = _ln_fold(acc, ln, torch.arange(x.shape[0]))
     if not geglu:
         v = acc
         if bias is not None:
@@ -62,14 +65,31 @@ def gemm(a, w, *, n=None, k=None, a2=None, bias=None, rowvec=None, rows_per_vec=
             acc = acc + bias
         blk = acc.reshape(acc.shape[0], -1, 32)
         v = (blk[:, :, :16] * F.gelu(blk[:, :, 16:])).reshape(acc.shape[0], -1)
+    if rowstats is not None:
+        r = v.to(BF16).float().reshape(v.shape[0], -1, 32)
+        rowstats.copy_(torch.stack([r.sum(-1), (r * r).sum(-1)], -1))
     if out is not None:
         out.copy_(v.to(out.dtype))
         return out
     return v if out_f32 else v.to(BF16)
 
 
-def gemm_batched(a, w, *, alpha=1.0, out_f32=False, bias=None, tile=0):
+def _ln_fold(acc, ln, rows):
+    st, colsum, eps = ln
+    st = st.reshape(-1, st.shape[-2], 2)[rows]
+    k = st.shape[1] * 32
+    mean = st[..., 0].sum(-1) / k
+    rstd = torch.rsqrt((st[..., 1].sum(-1) / k - mean * mean).clamp_min(0) + eps)
+    return rstd[:, None] * (acc - mean[:, None] * colsum[None, :])
+
+
+def gemm_batched(a, w, *, alpha=1.0, out_f32=False, bias=None, tile=0, ln=None):
     v = alpha * torch.einsum("bmk,bnk->bmn", a.float(), w.float())
+    if ln is not None:
+        # `a` is a batch of row-views into the tensor the statistics belong to
+        assert a.stride(-1) == 1 and a.stride(0) % a.stride(1) == 0
+        rows = (torch.arange(a.shape[0])[:, None] * (a.stride(0) // a.stride(1)) + torch.arange(a.shape[1])[None, :]).reshape(-1)
+        v = _ln_fold(v.reshape(-1, v.shape[-1]), ln, rows).reshape(v.shape)
     if bias is not None:
         v = v + bias
     return v if out_f32 else v.to(BF16)

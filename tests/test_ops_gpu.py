@@ -160,6 +160,44 @@ def test_gemm_conv3x3(ops, stride, ups, n_img, hs, ws, cin, cout, tile):
     assert rel_l2(out, ref) < TOL_BF16
 
 
+@pytest.mark.parametrize("tile,split", [(0, 1), (3, 1), (6, 1), (13, 1), (17, 1), (20, 1), (25, 1), (7, 2), (26, 4)])
+def test_gemm_layernorm_fusion(ops, tile, split):
+    """LayerNorm folded into the GEMMs around it (AVSD_GEMM_ROWSTATS / AVSD_GEMM_LNFUSE): the producer's per-32-column
+    (sum, sumsq) pairs are exact for its rounded output, and consumer(raw h) == Linear(LayerNorm(h))."""
+    torch.manual_seed(0)
+    M, C, N = 24 * 40, 640, 1280
+    a = rnd(M, C, seed=1)
+    wp = (0.05 * torch.randn(C, C, device=dev())).bfloat16()
+    res = rnd(M, C, seed=2) * 3 + 1.5                       # a residual stream with a clear mean
+    stats = torch.empty(M, C // 32, 2, device=dev())
+    h = ops.gemm(a, wp, bias=torch.randn(C, device=dev()), res1=res, rowstats=stats, tile=tile, split_k=split)
+    hb = h.float().reshape(M, C // 32, 32)
+    assert torch.allclose(stats[..., 0], hb.sum(-1), atol=2e-3, rtol=1e-5) and torch.allclose(stats[..., 1], (hb * hb).sum(-1), rtol=1e-5, atol=1e-3)
+    # consumer: y = LN(h; gamma, beta) @ W^T + b  with W' = W * gamma, colsum = sum_k W', bias' = beta @ W^T + b
+    g, be = 1 + 0.2 * torch.randn(C, device=dev()), 0.3 * torch.randn(C, device=dev())
+    w = 0.05 * torch.randn(N, C, device=dev())
+    b = torch.randn(N, device=dev())
+    wf = (w * g).bfloat16()
+    colsum = wf.float().sum(1)
+    bias2 = w @ be + b
+    y = ops.gemm(h, wf, bias=bias2, ln=(stats, colsum, 1e-5), tile=tile, split_k=split)
+    ref = F.layer_norm(h.float(), (C,), g, be, 1e-5) @ w.T + b
+    assert rel_l2(y, ref) < TOL_BF16
+    # GEGLU consumer (norm3 -> ff.net.0) and a batched consumer reading a strided subset of rows (norm1 -> to_k/to_v of frame 0)
+    from asva_amd.weights import pack_geglu
+    w1 = 0.05 * torch.randn(2 * N, C, device=dev())
+    b1 = torch.randn(2 * N, device=dev())
+    wpk, bpk = pack_geglu((w1 * g), w1 @ be + b1)
+    yg = ops.gemm(h, wpk, bias=bpk, geglu=True, ln=(stats, wpk.float().sum(1), 1e-5), tile=tile if split == 1 else 0)
+    t = F.layer_norm(h.float(), (C,), g, be, 1e-5) @ w1.T + b1
+    assert rel_l2(yg, t[:, :N] * F.gelu(t[:, N:])) < TOL_BF16
+    if split == 1:
+        hv = h.view(2, 12 * 40, C)[:, :40]
+        yb = ops.gemm_batched(hv, wf.unsqueeze(0).expand(2, N, C), bias=bias2, ln=(stats, colsum, 1e-5), tile=tile if tile in (0, 3, 6, 13) else 0)
+        refb = (F.layer_norm(hv.float(), (C,), g, be, 1e-5) @ w.T + b)
+        assert rel_l2(yb, refb) < TOL_BF16
+
+
 @pytest.mark.parametrize("tile,split", [(4, 2), (6, 4), (7, 3), (9, 2), (8, 5), (20, 4), (22, 2), (25, 3), (18, 2), (26, 8), (24, 3)])
 def test_gemm_split_k(ops, tile, split):
     from asva_amd.weights import pack_conv3x3

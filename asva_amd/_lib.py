@@ -47,10 +47,9 @@ SIGNATURES = {
     "avsd_gemm_bf16": (c_int, [C.POINTER(GemmDesc), c_void_p]),
     "avsd_sizeof_gemm_desc": (c_int, []),
     "avsd_linear_small_m": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "avsd_groupnorm_stats": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
-                                     c_void_p, c_int, c_void_p]),
-    "avsd_groupnorm_apply": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
-                                     c_int, c_void_p, c_int, c_void_p]),
+    "avsd_groupnorm_stats": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "avsd_groupnorm_apply": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
+                                     c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "avsd_groupnorm_nchunks": (c_int, [c_int, c_int, c_int]),
     "avsd_groupnorm_scratch_floats": (c_int, [c_int, c_int, c_int, c_int]),
     "avsd_layernorm": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p]),

@@ -10,12 +10,12 @@
 namespace {
 
 // ---- GroupNorm statistics -----------------------------------------------------------------------
-// Three launches, all deterministic (no atomics):
+// Two launches, both deterministic (no atomics):
 //   gn_stats_kernel    grid (nchunks, nb): thread -> (channel vector t % nvec, position t / nvec), striding ppb
 //                      positions over its chunk of rows; per-thread sums are laid out in LDS [ppb][2C] and the
 //                      first `groups` threads fold (positions x channels-of-group) -> partial[nb][nchunks][g][2]
-//   gn_finalize_kernel grid nb: 8 lanes per group tree-reduce the chunks in double -> stat[nb][g] = (mean, rstd)
-//   gn_apply_kernel    streams rows: y = act(x * scale[c] + shift[c]) with scale/shift built once per block in LDS
+//   gn_apply_kernel    every block folds the chunk partials of its batch in double -> (mean, rstd) per group ->
+//                      scale/shift per channel in LDS, then streams its rows: y = act(x * scale[c] + shift[c])
 __global__ void gn_stats_kernel(const bf16_t* x1, int ld1, int c1, const bf16_t* x2, int ld2, int c2,
                                 int rows_per_batch, int groups, float* partial, int nchunks, int nvec,
                                 int ppb) {
@@ -76,81 +76,78 @@ __global__ void gn_stats_kernel(const bf16_t* x1, int ld1, int c1, const bf16_t*
   }
 }
 
-__global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* partial, int nchunks, int groups, int rows_per_batch,
-                                                           int cg, float eps, const float* gamma, const float* beta,
-                                                           float* scale_shift) {
-  // 16 lanes per group, 2 independent accumulator pairs per lane so the loads overlap; then every thread turns
-  // (mean, rstd) into per-channel (scale, shift) so the apply kernel is a pure stream
+// ---- GroupNorm apply (+ optional SiLU, + channel concat) ---------------------------------------------------------
+// grid (blocks per batch, nb).  Every block first folds the chunk partials of ITS batch into (mean, rstd) per group —
+// 256 / groups lanes per group, double accumulation, fixed order — and builds scale[c] = rstd * gamma, shift[c] =
+// beta - mean * scale in LDS (a separate finalize launch cost a full ~5 us kernel boundary for a few KB of work), then
+// streams its share of the batch's rows: y = act(x * scale + shift), 2 vectors in flight per thread.
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x1, int ld1, int c1, const bf16_t* x2, int ld2, int c2,
+                                                       int rows_per_batch, const float* partial, int nchunks, int groups,
+                                                       float eps, const float* gamma, const float* beta, int act,
+                                                       bf16_t* y, int ldy) {
+  extern __shared__ float gn_ss[];   // [C] scale | [C] shift
   __shared__ float smean[64], srstd[64];
-  const int b = blockIdx.x;
-  const int g = threadIdx.x >> 4;
-  const int sub = threadIdx.x & 15;
-  double a0 = 0.0, q0 = 0.0, a1 = 0.0, q1 = 0.0;
-  if (g < groups) {
+  const int C = c1 + c2;
+  const int cg = C / groups;
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  {
+    const int lpg = 256 / groups;            // lanes per group: a power of two between 4 and 64 (host-checked)
+    const int g = tid / lpg, sub = tid % lpg;
+    double a = 0.0, q = 0.0;
     const float2* base = reinterpret_cast<const float2*>(partial) + (int64_t)b * nchunks * groups + g;
-    int k = sub;
-    for (; k + 16 < nchunks; k += 32) {
+    for (int k = sub; k < nchunks; k += lpg) {
       const float2 u = base[(int64_t)k * groups];
-      const float2 v = base[(int64_t)(k + 16) * groups];
-      a0 += (double)u.x; q0 += (double)u.y;
-      a1 += (double)v.x; q1 += (double)v.y;
+      a += (double)u.x;
+      q += (double)u.y;
     }
-    if (k < nchunks) {
-      const float2 u = base[(int64_t)k * groups];
-      a0 += (double)u.x; q0 += (double)u.y;
+    for (int off = lpg >> 1; off > 0; off >>= 1) {
+      a += __shfl_xor(a, off, 64);
+      q += __shfl_xor(q, off, 64);
     }
-  }
-  double a = a0 + a1, q = q0 + q1;
-#pragma unroll
-  for (int off = 8; off > 0; off >>= 1) {
-    a += __shfl_xor(a, off, 64);
-    q += __shfl_xor(q, off, 64);
-  }
-  if (g < groups && sub == 0) {
-    const double n = (double)rows_per_batch * cg;
-    const double mean = a / n;
-    double var = q / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    smean[g] = (float)mean;
-    srstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+    if (sub == 0) {
+      const double n = (double)rows_per_batch * cg;
+      const double mean = a / n;
+      double var = q / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      smean[g] = (float)mean;
+      srstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
   }
   __syncthreads();
-  const int C = groups * cg;
-  float* out = scale_shift + (int64_t)b * 2 * C;        // [C] scale | [C] shift
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  for (int c = tid; c < C; c += 256) {
     const int gg = c / cg;
     const float sc = srstd[gg] * gamma[c];
-    out[c] = sc;
-    out[C + c] = beta[c] - smean[gg] * sc;
+    gn_ss[c] = sc;
+    gn_ss[C + c] = beta[c] - smean[gg] * sc;
   }
-}
+  __syncthreads();
 
-// ---- GroupNorm apply (+ optional SiLU, + channel concat): flat grid-stride stream, 2 vectors in flight per thread
-__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x1, int ld1, int c1, const bf16_t* x2, int ld2, int c2,
-                                                       int rows_per_batch, int nb, const float* scale_shift, int act,
-                                                       bf16_t* y, int ldy) {
-  const int C = c1 + c2;
   const int nvec = C / 8;
-  const int64_t total = (int64_t)nb * rows_per_batch * nvec;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i0 < total; i0 += 2 * stride) {
+  const int rpb = (rows_per_batch + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * rpb;
+  const int r1 = min(rows_per_batch, r0 + rpb);
+  const int64_t row_base = (int64_t)b * rows_per_batch;
+  const int total = max(r1 - r0, 0) * nvec;
+  for (int i0 = tid; i0 < total; i0 += 512) {
     uint4 v[2];
     int cc[2];
     int64_t gr[2];
     bool ok[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int64_t i = i0 + u * stride;
+      const int i = i0 + u * 256;
       ok[u] = i < total;
-      gr[u] = ok[u] ? i / nvec : 0;
-      cc[u] = ok[u] ? (int)(i - gr[u] * nvec) * 8 : 0;
+      const int r = ok[u] ? i / nvec : 0;
+      gr[u] = row_base + r0 + r;
+      cc[u] = ok[u] ? (i - r * nvec) * 8 : 0;
       const bf16_t* src = (cc[u] < c1) ? x1 + gr[u] * ld1 + cc[u] : x2 + gr[u] * ld2 + (cc[u] - c1);
       v[u] = ok[u] ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       if (!ok[u]) continue;
-      const float* ss = scale_shift + (gr[u] / rows_per_batch) * 2 * C + cc[u];
+      const float* ss = gn_ss + cc[u];
       const float4 s0 = *reinterpret_cast<const float4*>(ss), s1 = *reinterpret_cast<const float4*>(ss + 4);
       const float4 h0 = *reinterpret_cast<const float4*>(ss + C), h1 = *reinterpret_cast<const float4*>(ss + C + 4);
       const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
@@ -284,14 +281,15 @@ extern "C" int avsd_groupnorm_nchunks(int nb, int rows_per_batch, int channels) 
   int n = 1024 / nb;                 // ~1024 blocks in flight
   int cap = rows_per_batch / 16;     // >= 16 rows per chunk
   if (n > cap) n = cap;
-  if (n > 512) n = 512;
+  if (n > 128) n = 128;              // every apply block folds the nchunks partials of its batch
   if (n < 1) n = 1;
   return n;
 }
 
-// floats of scratch the stats + apply pair needs: partial[nb][nchunks][groups][2] then scale_shift[nb][2][channels]
+// floats of scratch the stats + apply pair needs: partial[nb][nchunks][groups][2]
 extern "C" int avsd_groupnorm_scratch_floats(int nb, int nchunks, int groups, int channels) {
-  return nb * nchunks * groups * 2 + nb * 2 * channels;
+  (void)channels;
+  return nb * nchunks * groups * 2;
 }
 
 static int gn_check(const void* x1, int ld1, int c1, const void* x2, int ld2, int c2, int nb,
@@ -299,18 +297,18 @@ static int gn_check(const void* x1, int ld1, int c1, const void* x2, int ld2, in
   AVSD_REQUIRE(x1 && c1 > 0 && c1 % 8 == 0 && ld1 % 8 == 0 && ld1 >= c1, "groupnorm: bad first source (c1=%d ld1=%d)", c1, ld1);
   AVSD_REQUIRE(c2 >= 0 && c2 % 8 == 0 && (c2 == 0 || (x2 && ld2 % 8 == 0 && ld2 >= c2)), "groupnorm: bad second source (c2=%d ld2=%d)", c2, ld2);
   const int C = c1 + c2;
-  AVSD_REQUIRE(groups > 0 && groups <= 64 && C % groups == 0, "groupnorm: channels (%d) not divisible by groups (%d)", C, groups);
+  AVSD_REQUIRE(groups >= 4 && groups <= 64 && (groups & (groups - 1)) == 0 && C % groups == 0,
+               "groupnorm: groups (%d) must be a power of two in 4..64 dividing the channels (%d)", groups, C);
   AVSD_REQUIRE(C <= 4096, "groupnorm: at most 4096 channels (got %d)", C);
   AVSD_REQUIRE(nb > 0 && rows_per_batch > 0 && nchunks > 0 && nchunks <= rows_per_batch, "groupnorm: bad batch geometry nb=%d rows=%d nchunks=%d", nb, rows_per_batch, nchunks);
   return AVSD_OK;
 }
 
 extern "C" int avsd_groupnorm_stats(const void* x1, int ld1, int c1, const void* x2, int ld2, int c2, int nb,
-                                    int rows_per_batch, int groups, const float* gamma, const float* beta, float eps,
-                                    float* scratch, int nchunks, void* stream) {
+                                    int rows_per_batch, int groups, float* scratch, int nchunks, void* stream) {
   int rc = gn_check(x1, ld1, c1, x2, ld2, c2, nb, rows_per_batch, groups, nchunks);
   if (rc) return rc;
-  AVSD_REQUIRE(scratch && gamma && beta, "groupnorm_stats: null pointer");
+  AVSD_REQUIRE(scratch, "groupnorm_stats: null pointer");
   const int C = c1 + c2;
   int nvec, ppb, threads;
   gn_geometry(C, &nvec, &ppb, &threads);
@@ -319,28 +317,27 @@ extern "C" int avsd_groupnorm_stats(const void* x1, int ld1, int c1, const void*
   hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)nchunks, (unsigned)nb), dim3((unsigned)threads), lds, s,
                      (const bf16_t*)x1, ld1, c1, (const bf16_t*)x2, ld2, c2, rows_per_batch, groups, scratch, nchunks, nvec, ppb);
   AVSD_CHECK_LAUNCH("groupnorm_stats launch");
-  float* scale_shift = scratch + (size_t)nb * nchunks * groups * 2;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)nb), dim3(1024), 0, s, scratch, nchunks, groups, rows_per_batch,
-                     C / groups, eps, gamma, beta, scale_shift);
-  AVSD_CHECK_LAUNCH("groupnorm_finalize launch");
   return AVSD_OK;
 }
 
 extern "C" int avsd_groupnorm_apply(const void* x1, int ld1, int c1, const void* x2, int ld2, int c2, int nb,
-                                    int rows_per_batch, int groups, const float* scratch, int nchunks, int act, void* y,
-                                    int ldy, void* stream) {
+                                    int rows_per_batch, int groups, const float* gamma, const float* beta, float eps,
+                                    const float* scratch, int nchunks, int act, void* y, int ldy, void* stream) {
   int rc = gn_check(x1, ld1, c1, x2, ld2, c2, nb, rows_per_batch, groups, nchunks);
   if (rc) return rc;
-  AVSD_REQUIRE(scratch && y, "groupnorm_apply: null pointer");
+  AVSD_REQUIRE(scratch && y && gamma && beta, "groupnorm_apply: null pointer");
   const int C = c1 + c2;
   AVSD_REQUIRE(ldy % 8 == 0 && ldy >= C, "groupnorm_apply: bad ldy %d", ldy);
-  const int64_t total = (int64_t)nb * rows_per_batch * (C / 8);
-  int64_t nblk = (total + 511) / 512;       // 2 vectors per thread per sweep
-  if (nblk > 4096) nblk = 4096;
-  const float* scale_shift = scratch + (size_t)nb * nchunks * groups * 2;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)nblk), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     (const bf16_t*)x1, ld1, c1, (const bf16_t*)x2, ld2, c2, rows_per_batch, nb, scale_shift, act,
-                     (bf16_t*)y, ldy);
+  // ~1024 blocks over the batches, each with at least 512 vectors to stream
+  const int64_t vec_per_batch = (int64_t)rows_per_batch * (C / 8);
+  int bpb = 1024 / nb;
+  if (bpb < 1) bpb = 1;
+  const int64_t cap = (vec_per_batch + 511) / 512;
+  if (bpb > cap) bpb = (int)cap;
+  if (bpb > rows_per_batch) bpb = rows_per_batch;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)bpb, (unsigned)nb), dim3(256), (size_t)2 * C * sizeof(float),
+                     reinterpret_cast<hipStream_t>(stream), (const bf16_t*)x1, ld1, c1, (const bf16_t*)x2, ld2, c2,
+                     rows_per_batch, scratch, nchunks, groups, eps, gamma, beta, act, (bf16_t*)y, ldy);
   AVSD_CHECK_LAUNCH("groupnorm_apply launch");
   return AVSD_OK;
 }

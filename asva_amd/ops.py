@@ -434,9 +434,10 @@ def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], nb: int, rows_per_ba
     s = _stream()
     ev = _TIMER.start() if _TIMER is not None else None
     check(L.avsd_groupnorm_stats(_p(x1), _ld(x1), c1, _p(x2), _ld(x2) if x2 is not None else 0, c2, nb, rows_per_batch,
-                                 groups, _p(gamma), _p(beta), float(eps), _p(partial), nchunks, s), "avsd_groupnorm_stats")
+                                 groups, _p(partial), nchunks, s), "avsd_groupnorm_stats")
     check(L.avsd_groupnorm_apply(_p(x1), _ld(x1), c1, _p(x2), _ld(x2) if x2 is not None else 0, c2, nb, rows_per_batch,
-                                 groups, _p(partial), nchunks, int(act), _p(out), _ld(out), s), "avsd_groupnorm_apply")
+                                 groups, _p(gamma), _p(beta), float(eps), _p(partial), nchunks, int(act), _p(out), _ld(out), s),
+          "avsd_groupnorm_apply")
     if ev is not None:
         _TIMER.stop(ev, "groupnorm", 0.0, 2.0 * _nbytes(x1, x2) + _nbytes(out))
     return out

@@ -137,18 +137,18 @@ int avsd_linear_small_m(const float* x, const void* W_bf16, const float* bias, f
  *   rows: F*H*W for the 5-D GroupNorm of ff_spatio_temp_resnet_3d.py:130,146 /
  *   audio_cond_unet_3d_condition.py:445, H*W for the per-frame GroupNorm of
  *   ff_spatio_audio_temp_transformer_3d.py:62) reduces (sum, sumsq) of each of `groups`
- *   channel groups over `nchunks` row chunks (deterministic, no atomics) and finalises
- *   per-channel (scale, shift) = (rstd*gamma, beta - mean*rstd*gamma) with biased variance and
- *   eps inside the sqrt, all inside `scratch` (avsd_groupnorm_scratch_floats floats).  The input is the channel concat
+ *   channel groups over `nchunks` row chunks (deterministic, no atomics) into `scratch`
+ *   (avsd_groupnorm_scratch_floats floats).  groups: a power of two in 4..64.  The input is the channel concat
  *   [x1 (c1 channels) | x2 (c2 channels)] (c2 may be 0) — the UNet skip concat is never
  *   materialised.
- * apply: y[m, c] = act( x * scale[c] + shift[c] ), act 0 none / 1 SiLU, bf16 (pure stream). */
+ * apply: every workgroup folds the partials of its batch (double, fixed order) into per-channel
+ *   (scale, shift) = (rstd*gamma, beta - mean*rstd*gamma), biased variance, eps inside the sqrt, then streams
+ *   y[m, c] = act( x * scale[c] + shift[c] ), act 0 none / 1 SiLU, bf16. */
 int avsd_groupnorm_stats(const void* x1, int ld1, int c1, const void* x2, int ld2, int c2,
-                         int nb, int rows_per_batch, int groups, const float* gamma,
-                         const float* beta, float eps, float* scratch, int nchunks, void* stream);
+                         int nb, int rows_per_batch, int groups, float* scratch, int nchunks, void* stream);
 int avsd_groupnorm_apply(const void* x1, int ld1, int c1, const void* x2, int ld2, int c2,
-                         int nb, int rows_per_batch, int groups, const float* scratch,
-                         int nchunks, int act, void* y, int ldy, void* stream);
+                         int nb, int rows_per_batch, int groups, const float* gamma, const float* beta, float eps,
+                         const float* scratch, int nchunks, int act, void* y, int ldy, void* stream);
 /* Suggested nchunks, and the scratch size in floats for it (pure host arithmetic). */
 int avsd_groupnorm_nchunks(int nb, int rows_per_batch, int channels);
 int avsd_groupnorm_scratch_floats(int nb, int nchunks, int groups, int channels);

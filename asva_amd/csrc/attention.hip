@@ -373,6 +373,22 @@ __global__ __launch_bounds__(1024) void tattn_kernel(const TAttnArgs p) {
   const int64_t row0 = ((int64_t)b * F) * p.hw + pix;  // row of frame f = row0 + f*hw
   const int tid = threadIdx.x;
 
+  const int s = tid % DS;
+  const int hi = tid / DS;            // head * F + i
+  const bool active = hi < p.heads * F;
+  const int head = active ? hi / F : 0;
+  const int i = active ? hi - head * F : 0;
+  const int coff = head * D + s * SL; // this lane's channel slice
+
+  // this thread's query slice is requested first, so its round trip overlaps the K/V staging below instead of
+  // following the barrier
+  uint4 qv[NV];
+  {
+    const bf16_t* qrow = p.QKV + (row0 + (int64_t)i * p.hw) * p.ldqkv + coff;
+#pragma unroll
+    for (int d = 0; d < NV; ++d) qv[d] = *reinterpret_cast<const uint4*>(qrow + d * 8);
+  }
+
   const int vec_per_row = 2 * C / 8;
   for (int v = tid; v < F * vec_per_row; v += blockDim.x) {
     const int f = v / vec_per_row;
@@ -382,19 +398,7 @@ __global__ __launch_bounds__(1024) void tattn_kernel(const TAttnArgs p) {
   }
   __syncthreads();
 
-  const int s = tid % DS;
-  const int hi = tid / DS;            // head * F + i
-  const bool active = hi < p.heads * F;
-  const int head = active ? hi / F : 0;
-  const int i = active ? hi - head * F : 0;
-  const int coff = head * D + s * SL; // this lane's channel slice
 
-  uint4 qv[NV];
-  {
-    const bf16_t* qrow = p.QKV + (row0 + (int64_t)i * p.hw) * p.ldqkv + coff;
-#pragma unroll
-    for (int d = 0; d < NV; ++d) qv[d] = *reinterpret_cast<const uint4*>(qrow + d * 8);
-  }
   float sc[FMAX];
   float mx = -1e30f;
 #pragma unroll

@@ -354,6 +354,7 @@ int launch_attn(const AttnArgs& a, int Bq, int heads, hipStream_t s) {
 struct TAttnArgs {
   const bf16_t* QKV; bf16_t* O;
   int ldqkv, ldo, frames, hw, heads;
+  int hpb;    // heads per workgroup (blockIdx.y = head group): low-resolution layers have too few pixels to fill the chip
   float scale;
 };
 
@@ -367,6 +368,8 @@ __global__ __launch_bounds__(1024) void tattn_kernel(const TAttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_t[];
   bf16_t* sKV = reinterpret_cast<bf16_t*>(smem_t);  // [frames][2*C] : k | v
   const int C = p.heads * D;
+  const int Cg = p.hpb * D;             // channels of this workgroup's head group
+  const int c0g = blockIdx.y * Cg;      // first channel of the group
   const int F = p.frames;
   const int b = blockIdx.x / p.hw;
   const int pix = blockIdx.x - b * p.hw;
@@ -374,11 +377,12 @@ __global__ __launch_bounds__(1024) void tattn_kernel(const TAttnArgs p) {
   const int tid = threadIdx.x;
 
   const int s = tid % DS;
-  const int hi = tid / DS;            // head * F + i
-  const bool active = hi < p.heads * F;
+  const int hi = tid / DS;            // local head * F + i
+  const bool active = hi < p.hpb * F;
   const int head = active ? hi / F : 0;
   const int i = active ? hi - head * F : 0;
-  const int coff = head * D + s * SL; // this lane's channel slice
+  const int loff = head * D + s * SL; // this lane's channel slice inside the group
+  const int coff = c0g + loff;        // ... and in the full row
 
   // this thread's query slice is requested first, so its round trip overlaps the K/V staging below instead of
   // following the barrier
@@ -389,15 +393,15 @@ __global__ __launch_bounds__(1024) void tattn_kernel(const TAttnArgs p) {
     for (int d = 0; d < NV; ++d) qv[d] = *reinterpret_cast<const uint4*>(qrow + d * 8);
   }
 
-  const int vec_per_row = 2 * C / 8;
+  const int vec_per_row = 2 * Cg / 8;   // [k slice | v slice] of the group
   for (int v = tid; v < F * vec_per_row; v += blockDim.x) {
     const int f = v / vec_per_row;
     const int cv = (v - f * vec_per_row) * 8;
-    *reinterpret_cast<uint4*>(sKV + f * 2 * C + cv) =
-        *reinterpret_cast<const uint4*>(p.QKV + (row0 + (int64_t)f * p.hw) * p.ldqkv + C + cv);
+    const int src = cv < Cg ? C + c0g + cv : 2 * C + c0g + (cv - Cg);
+    *reinterpret_cast<uint4*>(sKV + f * 2 * Cg + cv) =
+        *reinterpret_cast<const uint4*>(p.QKV + (row0 + (int64_t)f * p.hw) * p.ldqkv + src);
   }
   __syncthreads();
-
 
   float sc[FMAX];
   float mx = -1e30f;
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(1024) void tattn_kernel(const TAttnArgs p) {
   for (int j = 0; j < FMAX; ++j) {
     float dot = 0.f;
     if (j < F) {
-      const bf16_t* krow = sKV + j * 2 * C + coff;
+      const bf16_t* krow = sKV + j * 2 * Cg + loff;
 #pragma unroll
       for (int d = 0; d < NV; ++d) {
         float a[8], k[8];
@@ -441,7 +445,7 @@ __global__ __launch_bounds__(1024) void tattn_kernel(const TAttnArgs p) {
     for (int j = 0; j < FMAX; ++j) {
       if (j < F) {
         float vv[8];
-        unpack8(*reinterpret_cast<const uint4*>(sKV + j * 2 * C + C + coff + d * 8), vv);
+        unpack8(*reinterpret_cast<const uint4*>(sKV + j * 2 * Cg + Cg + loff + d * 8), vv);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = fmaf(sc[j], vv[e], o[e]);
       }
@@ -453,9 +457,13 @@ __global__ __launch_bounds__(1024) void tattn_kernel(const TAttnArgs p) {
 }
 
 template <int D, int FMAX>
-int launch_tattn(const TAttnArgs& a, int B, hipStream_t s) {
+int launch_tattn(const TAttnArgs& a0, int B, hipStream_t s) {
   constexpr int DS = D / ((D % 40 == 0) ? 40 : 32);
-  const size_t lds = (size_t)a.frames * 2 * a.heads * D * sizeof(bf16_t);
+  TAttnArgs a = a0;
+  // one workgroup per (clip branch, pixel, head group): split the heads until ~1024 workgroups exist
+  a.hpb = a.heads;
+  while (a.hpb > 1 && a.hpb % 2 == 0 && (long)B * a.hw * (a.heads / a.hpb) < 1024) a.hpb /= 2;
+  const size_t lds = (size_t)a.frames * 2 * a.hpb * D * sizeof(bf16_t);
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tattn_kernel<D, FMAX>),
@@ -466,12 +474,12 @@ int launch_tattn(const TAttnArgs& a, int B, hipStream_t s) {
     }
     attr_lds = lds;
   }
-  int threads = (a.heads * a.frames * DS + 63) / 64 * 64;
+  int threads = (a.hpb * a.frames * DS + 63) / 64 * 64;
   if (threads > 1024) {
-    avsd_set_error("temporal attention: heads*frames*%d = %d threads exceeds 1024", DS, a.heads * a.frames * DS);
+    avsd_set_error("temporal attention: heads*frames*%d = %d threads exceeds 1024", DS, a.hpb * a.frames * DS);
     return AVSD_EINVAL;
   }
-  hipLaunchKernelGGL((tattn_kernel<D, FMAX>), dim3((unsigned)(B * a.hw)), dim3(threads), lds, s, a);
+  hipLaunchKernelGGL((tattn_kernel<D, FMAX>), dim3((unsigned)(B * a.hw), (unsigned)(a.heads / a.hpb)), dim3(threads), lds, s, a);
   AVSD_CHECK_LAUNCH("temporal attention launch");
   return AVSD_OK;
 }

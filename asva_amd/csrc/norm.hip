@@ -78,10 +78,10 @@ __global__ void gn_stats_kernel(const bf16_t* x1, int ld1, int c1, const bf16_t*
 
 // ---- GroupNorm apply (+ optional SiLU, + channel concat) ---------------------------------------------------------
 // grid (blocks per batch, nb).  Every block first folds the chunk partials of ITS batch into (mean, rstd) per group —
-// 256 / groups lanes per group, double accumulation, fixed order — and builds scale[c] = rstd * gamma, shift[c] =
+// up to 64 lanes per group, double accumulation, fixed order — and builds scale[c] = rstd * gamma, shift[c] =
 // beta - mean * scale in LDS (a separate finalize launch cost a full ~5 us kernel boundary for a few KB of work), then
 // streams its share of the batch's rows: y = act(x * scale + shift), 2 vectors in flight per thread.
-__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x1, int ld1, int c1, const bf16_t* x2, int ld2, int c2,
+__global__ __launch_bounds__(1024) void gn_apply_kernel(const bf16_t* x1, int ld1, int c1, const bf16_t* x2, int ld2, int c2,
                                                        int rows_per_batch, const float* partial, int nchunks, int groups,
                                                        float eps, const float* gamma, const float* beta, int act,
                                                        bf16_t* y, int ldy) {
@@ -92,11 +92,27 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x1, int ld1
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
   {
-    const int lpg = 256 / groups;            // lanes per group: a power of two between 4 and 64 (host-checked)
-    const int g = tid / lpg, sub = tid % lpg;
+    const int lpg = min(1024 / groups, 64);  // lanes per group: a power of two, at most one wave (host-checked)
+    const int g = min(tid / lpg, groups - 1), sub = tid % lpg;
+    const bool gvalid = tid / lpg < groups;
     double a = 0.0, q = 0.0;
     const float2* base = reinterpret_cast<const float2*>(partial) + (int64_t)b * nchunks * groups + g;
-    for (int k = sub; k < nchunks; k += lpg) {
+    int k = sub;
+    for (; k + 15 * lpg < nchunks; k += 16 * lpg) {    // sixteen independent loads in flight: one round trip for
+      float2 u[16];                                     // the 128 chunks of a pooled (F, H, W) batch
+#pragma unroll
+      for (int t = 0; t < 16; ++t) u[t] = base[(int64_t)(k + t * lpg) * groups];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) { a += (double)u[t].x; q += (double)u[t].y; }
+    }
+    for (; k + 3 * lpg < nchunks; k += 4 * lpg) {
+      float2 u[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) u[t] = base[(int64_t)(k + t * lpg) * groups];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { a += (double)u[t].x; q += (double)u[t].y; }
+    }
+    for (; k < nchunks; k += lpg) {
       const float2 u = base[(int64_t)k * groups];
       a += (double)u.x;
       q += (double)u.y;
@@ -105,7 +121,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x1, int ld1
       a += __shfl_xor(a, off, 64);
       q += __shfl_xor(q, off, 64);
     }
-    if (sub == 0) {
+    if (sub == 0 && gvalid) {
       const double n = (double)rows_per_batch * cg;
       const double mean = a / n;
       double var = q / n - mean * mean;
@@ -115,7 +131,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x1, int ld1
     }
   }
   __syncthreads();
-  for (int c = tid; c < C; c += 256) {
+  for (int c = tid; c < C; c += 1024) {
     const int gg = c / cg;
     const float sc = srstd[gg] * gamma[c];
     gn_ss[c] = sc;
@@ -129,14 +145,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x1, int ld1
   const int r1 = min(rows_per_batch, r0 + rpb);
   const int64_t row_base = (int64_t)b * rows_per_batch;
   const int total = max(r1 - r0, 0) * nvec;
-  for (int i0 = tid; i0 < total; i0 += 512) {
-    uint4 v[2];
-    int cc[2];
-    int64_t gr[2];
-    bool ok[2];
+  constexpr int NV = 2;                 // vectors in flight per thread
+  for (int i0 = tid; i0 < total; i0 += NV * 1024) {
+    uint4 v[NV];
+    int cc[NV];
+    int64_t gr[NV];
+    bool ok[NV];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int i = i0 + u * 256;
+    for (int u = 0; u < NV; ++u) {
+      const int i = i0 + u * 1024;
       ok[u] = i < total;
       const int r = ok[u] ? i / nvec : 0;
       gr[u] = row_base + r0 + r;
@@ -145,7 +162,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x1, int ld1
       v[u] = ok[u] ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NV; ++u) {
       if (!ok[u]) continue;
       const float* ss = gn_ss + cc[u];
       const float4 s0 = *reinterpret_cast<const float4*>(ss), s1 = *reinterpret_cast<const float4*>(ss + 4);
@@ -281,7 +298,7 @@ extern "C" int avsd_groupnorm_nchunks(int nb, int rows_per_batch, int channels) 
   int n = 1024 / nb;                 // ~1024 blocks in flight
   int cap = rows_per_batch / 16;     // >= 16 rows per chunk
   if (n > cap) n = cap;
-  if (n > 128) n = 128;              // every apply block folds the nchunks partials of its batch
+  if (n > 64) n = 64;                // every apply workgroup folds the nchunks partials of its batch
   if (n < 1) n = 1;
   return n;
 }
@@ -328,14 +345,15 @@ extern "C" int avsd_groupnorm_apply(const void* x1, int ld1, int c1, const void*
   AVSD_REQUIRE(scratch && y && gamma && beta, "groupnorm_apply: null pointer");
   const int C = c1 + c2;
   AVSD_REQUIRE(ldy % 8 == 0 && ldy >= C, "groupnorm_apply: bad ldy %d", ldy);
-  // ~1024 blocks over the batches, each with at least 512 vectors to stream
+  // ~512 workgroups of 1024 threads over the batches (every workgroup re-folds the partials of its batch, so fewer,
+  // larger workgroups), each with at least 2048 vectors to stream
   const int64_t vec_per_batch = (int64_t)rows_per_batch * (C / 8);
-  int bpb = 1024 / nb;
+  int bpb = 512 / nb;
   if (bpb < 1) bpb = 1;
-  const int64_t cap = (vec_per_batch + 511) / 512;
+  const int64_t cap = (vec_per_batch + 2047) / 2048;
   if (bpb > cap) bpb = (int)cap;
   if (bpb > rows_per_batch) bpb = rows_per_batch;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)bpb, (unsigned)nb), dim3(256), (size_t)2 * C * sizeof(float),
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)bpb, (unsigned)nb), dim3(1024), (size_t)2 * C * sizeof(float),
                      reinterpret_cast<hipStream_t>(stream), (const bf16_t*)x1, ld1, c1, (const bf16_t*)x2, ld2, c2,
                      rows_per_batch, scratch, nchunks, groups, eps, gamma, beta, act, (bf16_t*)y, ldy);
   AVSD_CHECK_LAUNCH("groupnorm_apply launch");

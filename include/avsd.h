@@ -97,7 +97,7 @@ typedef struct avsd_gemm_desc {
   int32_t hs, ws, ho, wo, cin, stride, ups;
   int32_t pad;                          /* CONV3 top/left zero padding: 1 (symmetric "padding=1") or 0 (the VAE encoder's
                                            F.pad(0,1,0,1) + stride-2 conv); bottom/right reads beyond the image are zero */
-  int32_t tile;                         /* 0 = library heuristic; 1..3 register-staged tiles, 4..10 LDS-direct
+  int32_t tile;                         /* 0 = library heuristic; 1..3 register-staged tiles, 4..28 LDS-direct
                                            tiles (see gemm.hip dispatch_tile) */
   /* split-K (LDS-direct tiles only): K is cut into split_k slices computed by separate workgroups that
    * store f32 partial tiles to splitk_ws[split_k][M][N]; a second launch reduces them and applies the epilogue.

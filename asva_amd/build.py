@@ -14,7 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libavsd_hip.so")
-SOURCES = ["lib.hip", "gemm.hip", "attention.hip", "norm.hip", "elementwise.hip", "audio.hip"]
+SOURCES = ["lib.hip", "attention.hip", "norm.hip", "elementwise.hip", "audio.hip"]
+# gemm.hip instantiates ~270 kernels: compiled as four translation units (one per A-loader mode + the entry point)
+GEMM_UNITS = 4
 HEADERS = [os.path.join(CSRC, "avsd_common.h"), os.path.join(HERE, "..", "include", "avsd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -44,6 +46,12 @@ def build(verbose: bool = False, force: bool = False) -> str:
         objs.append(o)
         if force or _stale(o, [s] + HEADERS):
             jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+    gsrc = os.path.join(CSRC, "gemm.hip")
+    for u in range(GEMM_UNITS):
+        o = os.path.join(OBJ, f"gemm_tu{u}.o")
+        objs.append(o)
+        if force or _stale(o, [gsrc] + HEADERS):
+            jobs.insert(0, [hipcc, *FLAGS, f"-DAVSD_GEMM_TU={u}", "-c", gsrc, "-o", o])     # longest jobs first
 
     def run(cmd):
         if verbose:
@@ -54,7 +62,7 @@ def build(verbose: bool = False, force: bool = False) -> str:
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
 
-    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])

@@ -970,6 +970,23 @@ int pick_tile(int M, int N, int batch) {
 
 }  // namespace
 
+// The three A-loader modes instantiate ~90 kernels each: the build compiles this file once per mode (-DAVSD_GEMM_TU=0/1/2,
+// only that mode's dispatcher) and once for the entry point (-DAVSD_GEMM_TU=3), in parallel; without the macro one
+// translation unit carries everything.
+int avsd_gemm_dispatch_plain(const avsd_gemm_desc& d, int tile, hipStream_t s);
+int avsd_gemm_dispatch_tmix(const avsd_gemm_desc& d, int tile, hipStream_t s);
+int avsd_gemm_dispatch_conv3(const avsd_gemm_desc& d, int tile, hipStream_t s);
+#if !defined(AVSD_GEMM_TU) || AVSD_GEMM_TU == 0
+int avsd_gemm_dispatch_plain(const avsd_gemm_desc& d, int tile, hipStream_t s) { return dispatch_tile<AVSD_GEMM_PLAIN>(d, tile, s); }
+#endif
+#if !defined(AVSD_GEMM_TU) || AVSD_GEMM_TU == 1
+int avsd_gemm_dispatch_tmix(const avsd_gemm_desc& d, int tile, hipStream_t s) { return dispatch_tile<AVSD_GEMM_TMIX>(d, tile, s); }
+#endif
+#if !defined(AVSD_GEMM_TU) || AVSD_GEMM_TU == 2
+int avsd_gemm_dispatch_conv3(const avsd_gemm_desc& d, int tile, hipStream_t s) { return dispatch_tile<AVSD_GEMM_CONV3>(d, tile, s); }
+#endif
+
+#if !defined(AVSD_GEMM_TU) || AVSD_GEMM_TU == 3
 extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
   AVSD_REQUIRE(dp != nullptr, "gemm: null descriptor");
   avsd_gemm_desc d = *dp;
@@ -1037,8 +1054,9 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
   if (tile < 1 || tile > 28) tile = pick_tile(d.M, (d.flags & AVSD_GEMM_GEGLU) ? d.N : d.N, d.batch);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (d.mode) {
-    case AVSD_GEMM_PLAIN: return dispatch_tile<AVSD_GEMM_PLAIN>(d, tile, s);
-    case AVSD_GEMM_TMIX: return dispatch_tile<AVSD_GEMM_TMIX>(d, tile, s);
-    default: return dispatch_tile<AVSD_GEMM_CONV3>(d, tile, s);
+    case AVSD_GEMM_PLAIN: return avsd_gemm_dispatch_plain(d, tile, s);
+    case AVSD_GEMM_TMIX: return avsd_gemm_dispatch_tmix(d, tile, s);
+    default: return avsd_gemm_dispatch_conv3(d, tile, s);
   }
 }
+#endif  // AVSD_GEMM_TU

@@ -60,7 +60,7 @@ SIGNATURES = {
     "avsd_ncfhw_to_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "avsd_rows_to_ncfhw": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "avsd_timestep_embedding": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
-    "avsd_guided_step": (c_int, [c_void_p, c_int, c_float, c_void_p, c_int, c_float, C.POINTER(C.c_int32), C.POINTER(C.c_float),
+    "avsd_guided_step": (c_int, [c_void_p, c_int, c_float, c_float, c_void_p, c_int, c_float, C.POINTER(C.c_int32), C.POINTER(C.c_float),
                                  c_int, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_int, c_void_p]),
     "avsd_vae_postprocess": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "avsd_vae_postprocess_u8": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),

@@ -98,7 +98,7 @@ struct GuidedArgs {
   int n_branch, store_slot, n_hist;
   int hist_idx[4];
   float w[4];
-  float g, w_cur, ca, cb;
+  float g, g2, w_cur, ca, cb;
   int B, C, F, HW;
 };
 
@@ -107,7 +107,14 @@ __global__ void guided_step_kernel(const GuidedArgs a) {
   const int64_t fhw = (int64_t)a.F * a.HW;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.x * blockDim.x) {
     float eps = a.noise_pred[i];
-    if (a.n_branch == 2) eps = eps + a.g * (a.noise_pred[per + i] - eps);
+    if (a.n_branch >= 2) {
+      // e0 + g (e1 - e0) [+ g2 (e2 - e1)]: audio-only / text-only guidance, or the dual form of
+      // pipeline_audio_cond_animation.py:349-353 with branches [uncond, text, text+audio], g = text scale, g2 = audio scale
+      const float e1 = a.noise_pred[per + i];
+      float gsum = eps + a.g * (e1 - eps);
+      if (a.n_branch == 3) gsum = gsum + a.g2 * (a.noise_pred[2 * per + i] - e1);
+      eps = gsum;
+    }
     if (a.eps_hist && a.store_slot >= 0) a.eps_hist[(int64_t)a.store_slot * per + i] = eps;
     float e = a.w_cur * eps;
     for (int k = 0; k < a.n_hist; ++k) {
@@ -193,11 +200,11 @@ extern "C" int avsd_linear_small_m(const float* x, const void* W, const float* b
   return AVSD_OK;
 }
 
-extern "C" int avsd_guided_step(const float* noise_pred, int n_branch, float g, float* eps_hist, int store_slot,
+extern "C" int avsd_guided_step(const float* noise_pred, int n_branch, float g, float g2, float* eps_hist, int store_slot,
                                 float w_cur, const int32_t* hist_idx, const float* w, int n_hist, const float* x_in,
                                 float* x_out, float ca, float cb, int B, int C, int F, int HW, void* stream) {
   AVSD_REQUIRE(noise_pred && x_in && x_out, "guided_step: null pointer");
-  AVSD_REQUIRE(n_branch == 1 || n_branch == 2, "guided_step: n_branch must be 1 or 2");
+  AVSD_REQUIRE(n_branch >= 1 && n_branch <= 3, "guided_step: n_branch must be 1, 2 or 3");
   AVSD_REQUIRE(n_hist >= 0 && n_hist <= 4, "guided_step: n_hist must be in [0, 4]");
   AVSD_REQUIRE((n_hist == 0 && store_slot < 0) || eps_hist, "guided_step: history requested without eps_hist");
   AVSD_REQUIRE(n_hist == 0 || (hist_idx && w), "guided_step: null history tables");
@@ -206,7 +213,7 @@ extern "C" int avsd_guided_step(const float* noise_pred, int n_branch, float g, 
   a.noise_pred = noise_pred; a.eps_hist = eps_hist; a.x_in = x_in; a.x_out = x_out;
   a.n_branch = n_branch; a.store_slot = store_slot; a.n_hist = n_hist;
   for (int k = 0; k < 4; ++k) { a.hist_idx[k] = k < n_hist ? hist_idx[k] : 0; a.w[k] = k < n_hist ? w[k] : 0.f; }
-  a.g = g; a.w_cur = w_cur; a.ca = ca; a.cb = cb;
+  a.g = g; a.g2 = g2; a.w_cur = w_cur; a.ca = ca; a.cb = cb;
   a.B = B; a.C = C; a.F = F; a.HW = HW;
   const int64_t n = (int64_t)B * C * F * HW;
   hipLaunchKernelGGL(guided_step_kernel, dim3(grid_for(n, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);

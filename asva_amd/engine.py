@@ -21,13 +21,21 @@ from .schedulers import StepPlan
 class DenoiseEngine:
     def __init__(self, unet, scheduler, audio_guidance_scale: float = 4.0, text_guidance_scale: float = 1.0,
                  use_graph: bool = True):
-        if text_guidance_scale > 1.0:
-            raise NotImplementedError("text guidance (3-branch CFG) is off in every reference script "
-                                      "(scripts/animation_test_*.sh: text_guidance_scale 1.0)")
         self.unet = unet
         self.scheduler = scheduler
-        self.g = float(audio_guidance_scale)
-        self.n_branch = 2 if audio_guidance_scale > 1.0 else 1
+        # guidance mixes of the reference (pipeline_audio_cond_animation.py:349-361), as avsd_guided_step's (n_branch, g, g2):
+        #   dual   [uncond, text, text+audio]: e0 + tg (e1 - e0) + ag (e2 - e1)
+        #   text   [null-text+audio, text+audio]: e0 + tg (e1 - e0)
+        #   audio  [text+null-audio, text+audio]: e0 + ag (e1 - e0)
+        self.do_text = text_guidance_scale > 1.0
+        self.do_audio = audio_guidance_scale > 1.0
+        self.n_branch = 1 + int(self.do_text) + int(self.do_audio)
+        if self.do_text and self.do_audio:
+            self.g, self.g2 = float(text_guidance_scale), float(audio_guidance_scale)
+        elif self.do_text:
+            self.g, self.g2 = float(text_guidance_scale), 0.0
+        else:
+            self.g, self.g2 = float(audio_guidance_scale), 0.0
         # hipGraph replay needs a real device stream (the CPU contract emulation of the tests has none)
         self.use_graph = use_graph and torch.cuda.is_available() and not getattr(ops, "EMULATED", False)
         self._graph = None
@@ -35,17 +43,27 @@ class DenoiseEngine:
 
     # -- once per clip ---------------------------------------------------------------------------------
     def set_conditioning(self, text: torch.Tensor, audio: torch.Tensor, null_audio: Optional[torch.Tensor],
-                         audio_mask: torch.Tensor, video_length: int):
+                         audio_mask: torch.Tensor, video_length: int, null_text: Optional[torch.Tensor] = None):
         """text (b, 77, D); audio (b, 229, D); null_audio (1 or b, 229, D) = encoding of the all-zero
-        mel-spectrogram (pipeline :180-184); mask (F, 229).  Builds the CFG batch exactly as encode_text /
-        encode_audio do for audio-only guidance (:155, :193-194): text [t, t], audio [null, audio]."""
+        mel-spectrogram (pipeline :180-184); null_text (1 or b, 77, D) = encoding of "" (:124-148); mask (F, 229).
+        Builds the CFG batch exactly as encode_text / encode_audio do (:150-155, :186-194):
+        audio-only  text [t, t]      audio [null, a];   text-only  text [null, t]  audio [a, a];
+        dual        text [null, t, t]  audio [null, null, a]."""
         b = text.shape[0]
-        if self.n_branch == 2:
+        if self.do_audio:
             if null_audio is None:
                 raise ValueError("audio guidance needs the null-audio encoding")
             null_audio = null_audio.expand(b, *null_audio.shape[1:])
-            text = torch.cat([text, text], 0)
-            audio = torch.cat([null_audio, audio], 0)
+        if self.do_text:
+            if null_text is None:
+                raise ValueError("text guidance needs the null-text encoding")
+            null_text = null_text.expand(b, *null_text.shape[1:])
+        if self.do_text and self.do_audio:
+            text, audio = torch.cat([null_text, text, text], 0), torch.cat([null_audio, null_audio, audio], 0)
+        elif self.do_text:
+            text, audio = torch.cat([null_text, text], 0), torch.cat([audio, audio], 0)
+        elif self.do_audio:
+            text, audio = torch.cat([text, text], 0), torch.cat([null_audio, audio], 0)
         self.unet.set_conditioning(text, audio, audio_mask, video_length)
 
     # -- hot loop -----------------------------------------------------------------------------------------
@@ -88,14 +106,14 @@ class DenoiseEngine:
         self._saved = torch.empty_like(latents)
 
     def step(self, latents: torch.Tensor, i: int) -> None:
-        """One denoising step in place on `latents` (b, 4, F, H, W) f32: UNet on the CFG batch, then
-        eps = e_text + g (e_text_audio - e_text), scheduler update of frames 1.., frame 0 untouched."""
+        """One denoising step in place on `latents` (b, 4, F, H, W) f32: UNet on the CFG batch, then the guidance mix
+        (see __init__), scheduler update of frames 1.., frame 0 untouched."""
         p: StepPlan = self._plans[i]
         noise = self.unet_step(latents, self._ts[i:i + 1])
         if p.save_sample:
             self._saved.copy_(latents)
         ops.guided_step(noise, self.n_branch, self.g, self._saved if p.use_saved_sample else latents, latents, p.ca, p.cb,
-                        eps_hist=self._hist, store_slot=p.store_slot, w_cur=p.w_cur, hist_idx=p.hist_idx, w=p.hist_w)
+                        eps_hist=self._hist, store_slot=p.store_slot, w_cur=p.w_cur, hist_idx=p.hist_idx, w=p.hist_w, g2=self.g2)
 
     @torch.no_grad()
     def run(self, latents: torch.Tensor, num_inference_steps: int) -> torch.Tensor:

@@ -542,7 +542,7 @@ def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
 
 def guided_step(noise_pred: torch.Tensor, n_branch: int, g: float, x_in: torch.Tensor, x_out: torch.Tensor,
                 ca: float, cb: float, *, eps_hist: Optional[torch.Tensor] = None, store_slot: int = -1,
-                w_cur: float = 1.0, hist_idx=(), w=()) -> None:
+                w_cur: float = 1.0, hist_idx=(), w=(), g2: float = 0.0) -> None:
     _req(noise_pred, F32, "noise_pred")
     _req(x_in, F32, "x_in")
     _req(x_out, F32, "x_out")
@@ -550,7 +550,7 @@ def guided_step(noise_pred: torch.Tensor, n_branch: int, g: float, x_in: torch.T
     nh = len(hist_idx)
     idx = (C.c_int32 * 4)(*(list(hist_idx) + [0] * (4 - nh)))
     ws = (C.c_float * 4)(*(list(w) + [0.0] * (4 - nh)))
-    check(_lib.lib().avsd_guided_step(_p(noise_pred), n_branch, float(g), _p(eps_hist), store_slot, float(w_cur), idx, ws,
+    check(_lib.lib().avsd_guided_step(_p(noise_pred), n_branch, float(g), float(g2), _p(eps_hist), store_slot, float(w_cur), idx, ws,
                                       nh, _p(x_in), _p(x_out), float(ca), float(cb), B, Cc, Fr, H * W, _stream()),
           "avsd_guided_step")
 

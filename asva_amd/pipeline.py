@@ -195,13 +195,13 @@ class AudioCondAnimationPipeline:
         latents = self.prepare_video_latents(image_latents, self.unet.config.in_channels, video_length, height, width, device,
                                              f32, generator, noise)                                      # (b, 4, f, h, w)
 
-        if self.use_engine and not do_text and isinstance(self.scheduler, (PNDMScheduler, DDIMScheduler)):
-            ekey = (id(self.unet), id(self.scheduler), float(audio_guidance_scale))
+        if self.use_engine and isinstance(self.scheduler, (PNDMScheduler, DDIMScheduler)):
+            ekey = (id(self.unet), id(self.scheduler), float(audio_guidance_scale), float(text_guidance_scale))
             if getattr(self, "_engine_key", None) != ekey:      # keep the engine (and its captured graph) across clips
                 self._engine = DenoiseEngine(self.unet, self.scheduler, audio_guidance_scale, text_guidance_scale)
                 self._engine_key = ekey
             eng = self._engine
-            self.unet.set_conditioning(text, audio, masks, video_length)      # already in CFG order [null-audio, audio]
+            self.unet.set_conditioning(text, audio, masks, video_length)      # already in the CFG branch order of :150-155,:186-194
             eng.prepare(latents, num_inference_steps)
             latents = latents.contiguous().clone()
             for i in self.progress_bar(range(self.scheduler.num_forwards())):
@@ -258,31 +258,22 @@ class AudioCondAnimationPipeline:
 
 
 # ---- drivers ---------------------------------------------------------------------------------------------------------
-def _missing(name, needs):
-    def fn(*a, **k):
-        raise RuntimeError(f"{name} needs {needs}, which is not installed in this image; pass decoded clips with clips=... "
-                           "or install the backend")
-
-    return fn
-
-
-try:  # the reference's own data utilities, when their dependencies (torchvision, torchaudio, ImageBind) exist
-    from avgen.data.utils import (get_evaluation_data, load_audio_clips_uniformly, load_av_clips_uniformly,  # type: ignore
-                                  load_image)
-except Exception:  # noqa: BLE001
-    load_image = _missing("load_image", "torchvision")
-    load_av_clips_uniformly = _missing("load_av_clips_uniformly", "torchvision.io.VideoReader")
-    load_audio_clips_uniformly = _missing("load_audio_clips_uniformly", "torchaudio")
-    get_evaluation_data = _missing("get_evaluation_data", "the evaluation dataset lists")
+from .data_utils import get_evaluation_data, load_audio_clips_uniformly, load_av_clips_uniformly, load_image  # noqa: E402
 
 
 def write_video(filename, video_array, fps, audio_array=None, audio_fps=16000, audio_codec="aac"):
+    """torchvision.io.write_video when torchvision exists (the reference's writer, :451-458: H.264 + AAC in .mp4);
+    otherwise the codec-free Motion-JPEG / PCM writer of asva_amd.video_io, which keeps the requested file name's stem
+    and writes `<stem>.avi` (this image has no H.264 encoder)."""
     try:
-        import torchvision.io as tvio
-    except Exception as e:  # noqa: BLE001
-        raise RuntimeError("write_video needs torchvision.io (absent in this image)") from e
+        import torchvision.io as tvio  # type: ignore
+    except ImportError:
+        from .video_io import write_mjpeg_avi
+
+        return write_mjpeg_avi(os.path.splitext(filename)[0] + ".avi", video_array, fps, audio_array, audio_fps)
     tvio.write_video(filename=filename, video_array=video_array, fps=fps, audio_array=audio_array, audio_fps=audio_fps,
                      audio_codec=audio_codec)
+    return filename
 
 
 @torch.no_grad()
@@ -346,6 +337,12 @@ def generate_videos_for_dataset(exp_root: str, checkpoint: int, dataset: str = "
     (torchrun) the video list is sharded by rank (clip i -> rank i mod world) — the reference loops sequentially."""
     from transformers import CLIPTextModel, CLIPTokenizer
 
+    # one process per GPU (torchrun): every rank owns cuda:LOCAL_RANK.  The unchanged reference script passes
+    # torch.device("cuda") = cuda:0, which would stack all ranks on one GPU.
+    rank, local_rank, world = adist.env_rank_world()
+    if world > 1 and torch.cuda.is_available() and torch.device(device).type == "cuda":
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     ckpt = f"{exp_root}/ckpts/checkpoint-{checkpoint}/modules"
     save_root = (f"{exp_root}/evaluations/checkpoint-{checkpoint}/AG-{audio_guidance_scale}_TG-{text_guidance_scale}/"
                  f"seed-{random_seed}/videos")
@@ -375,7 +372,7 @@ def generate_videos_for_dataset(exp_root: str, checkpoint: int, dataset: str = "
                                       audio_encoder=audio_encoder, null_text_encodings_path=null_text)
     pipe.to(torch_device=device, dtype=dtype)
     pipe.set_progress_bar_config(disable=True)
-    rank, _, world = adist.env_rank_world()
+    os.makedirs(save_root, exist_ok=True)                      # exist_ok: the ranks race to create it
     todo = list(zip(filenames, categories))
     for i in adist.shard_clips(len(todo), rank, world):
         filename, category = todo[i]
@@ -383,7 +380,7 @@ def generate_videos_for_dataset(exp_root: str, checkpoint: int, dataset: str = "
                         category_text_encoding=enc_map[cat_map[category]].view(1, 77, 768), image_size=image_size,
                         video_fps=video_fps, video_num_frame=video_num_frame, num_clips_per_video=num_clips_per_video,
                         text_guidance_scale=text_guidance_scale, audio_guidance_scale=audio_guidance_scale, seed=random_seed,
-                        save_template=os.path.join(save_root, filename.replace(".mp4", "")), device=device)
+                        save_template=os.path.join(save_root, os.path.splitext(filename)[0]), device=device)
 
 
 # ---- synthetic driver (replaces dataset + mp4 I/O for tests and benches) -------------------------------------------------

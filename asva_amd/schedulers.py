@@ -56,9 +56,19 @@ class _Base:
     init_noise_sigma = 1.0
 
     def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
-                 steps_offset=1, set_alpha_to_one=False, prediction_type="epsilon", timestep_spacing="leading", **_):
+                 steps_offset=1, set_alpha_to_one=False, prediction_type="epsilon", timestep_spacing="leading",
+                 trained_betas=None, clip_sample=False, thresholding=False, rescale_betas_zero_snr=False, **unknown):
         if prediction_type != "epsilon" or timestep_spacing != "leading":
             raise NotImplementedError("only the SD1.5 scheduler configuration (epsilon, leading) is restated")
+        # options that change the samples must not be dropped silently (diffusers' DDIM default is clip_sample=True;
+        # the SD1.5 scheduler_config.json sets it to false)
+        if clip_sample or thresholding or rescale_betas_zero_snr or trained_betas is not None:
+            raise NotImplementedError("clip_sample / thresholding / rescale_betas_zero_snr / trained_betas are not restated: "
+                                      "the SD1.5 scheduler configuration sets none of them")
+        known_inert = {"clip_sample_range", "dynamic_thresholding_ratio", "sample_max_value", "skip_prk_steps"}
+        bad = sorted(k for k in unknown if not k.startswith("_") and k not in known_inert)
+        if bad:
+            raise NotImplementedError(f"unknown scheduler options {bad}")
         self.num_train_timesteps = num_train_timesteps
         self.steps_offset = steps_offset
         self.acp = alphas_cumprod(num_train_timesteps, beta_start, beta_end, beta_schedule)
@@ -71,6 +81,16 @@ class _Base:
 
     def scale_model_input(self, sample, timestep=None):
         return sample
+
+    @classmethod
+    def from_pretrained(cls, path: str, subfolder: Optional[str] = None):
+        import json
+        import os
+
+        p = os.path.join(path, subfolder) if subfolder else path
+        with open(os.path.join(p, "scheduler_config.json")) as f:
+            cfg = json.load(f)
+        return cls(**{k: v for k, v in cfg.items() if not k.startswith("_")})
 
     def _acp(self, t: int) -> float:
         return float(self.acp[t]) if t >= 0 else self.final_alpha_cumprod
@@ -183,7 +203,9 @@ class PNDMScheduler(_Base):
         else:
             prev, t = t, t + ratio
         if len(self.ets) == 1 and self.counter == 0:
-            self.cur_sample = sample
+            # diffusers keeps the caller's tensor itself (no clone): see __init__ for what that means for a caller that
+            # writes the result back into the same storage.  Textbook PLMS keeps a copy.
+            self.cur_sample = sample if self.cur_sample_aliases_latents else sample.clone()
         elif len(self.ets) == 1 and self.counter == 1:
             model_output = (model_output + self.ets[-1]) / 2
             sample = self.cur_sample
@@ -198,13 +220,3 @@ class PNDMScheduler(_Base):
         prev_sample = ca * sample + cb * model_output
         self.counter += 1
         return _Output(prev_sample) if return_dict else (prev_sample,)
-
-    @classmethod
-    def from_pretrained(cls, path: str, subfolder: Optional[str] = None):
-        import json
-        import os
-
-        p = os.path.join(path, subfolder) if subfolder else path
-        with open(os.path.join(p, "scheduler_config.json")) as f:
-            cfg = json.load(f)
-        return cls(**{k: v for k, v in cfg.items() if not k.startswith("_") and k != "trained_betas"})

@@ -644,6 +644,9 @@ class AudioUNet3DConditionModel(nn.Module):
         pk = self.pack()
         dev = pk.blob.device
         Fr = video_length
+        # a direct call replaces (or refreshes in place) the cache `forward` keys on its argument tensors
+        self._cond_key = None
+        self._cond_refs = None
 
         def rows(x):
             if x is None:

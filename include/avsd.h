@@ -33,7 +33,7 @@ extern "C" {
 #define AVSD_ELAUNCH (-2)  /* hipLaunch / runtime error                          */
 #define AVSD_ENODEV (-3)   /* no gfx950 device / wrong architecture              */
 
-#define AVSD_ABI_VERSION 2
+#define AVSD_ABI_VERSION 3
 
 /* ---- library ------------------------------------------------------------------------ */
 int avsd_abi_version(void);
@@ -198,15 +198,17 @@ int avsd_timestep_embedding(const float* t, float* out, int n, int dim, void* st
 
 /* Guidance + multistep scheduler update on (B, C, F, H, W) f32 latents, frame 0 pinned
  * (pipeline_audio_cond_animation.py:349-364):
- *   eps      = e[0] + g * (e[1] - e[0])      (e = noise_pred of the [null-audio, audio] UNet
- *                                            batch; g = audio guidance scale; n_branch = 1
- *                                            disables guidance)
+ *   n_branch 1: eps = e[0]                                         (no guidance)
+ *   n_branch 2: eps = e[0] + g * (e[1] - e[0])                     (:354-361; e = noise_pred of the [null-audio,
+ *               audio] batch with g = audio scale, or of [null-text, text] with g = text scale)
+ *   n_branch 3: eps = e[0] + g * (e[1] - e[0]) + g2 * (e[2] - e[1]) (:349-353, dual guidance; branches
+ *               [uncond, text, text+audio], g = text_guidance_scale, g2 = audio_guidance_scale)
  *   eps_hist[store_slot] = eps                (if store_slot >= 0)
  *   eps'     = w_cur * eps + sum_k w[k] * eps_hist[hist_idx[k]]      (n_hist <= 4 terms)
  *   x_out[:, :, 1:] = ca * x_in[:, :, 1:] + cb * eps'[:, :, 1:] ;  x_out[:, :, 0] = x_in[:, :, 0]
  * PNDM (PLMS, incl. its averaged second step on the saved sample) and DDIM (eta = 0) are both
  * of this form; the scalar schedule lives on the host (asva_amd/schedulers.py). */
-int avsd_guided_step(const float* noise_pred, int n_branch, float g, float* eps_hist,
+int avsd_guided_step(const float* noise_pred, int n_branch, float g, float g2, float* eps_hist,
                      int store_slot, float w_cur, const int32_t* hist_idx_host,
                      const float* w_host, int n_hist, const float* x_in, float* x_out, float ca,
                      float cb, int B, int C, int F, int HW, void* stream);

@@ -19,24 +19,40 @@ def prepare_video_latents(image_latents, noise, init_noise_sigma=1.0):
 
 
 def denoise(unet_sd, unet_cfg, latents, text, audio, null_audio, mask, steps, audio_guidance=4.0, scheduler="pndm",
-            trace=None):
-    """latents (b,4,f,h,w); text (b,77,D); audio / null_audio (b,229,D); mask (f,229) bool.  Audio-only guidance:
-    UNet batch [text+null-audio, text+audio] (:155,:193-194), eps = e0 + g (e1 - e0) (:358-361), scheduler on frames
-    1.. (:364)."""
+            trace=None, text_guidance=1.0, null_text=None):
+    """latents (b,4,f,h,w); text / null_text (b,77,D); audio / null_audio (b,229,D); mask (f,229) bool.  Guidance
+    mixes of :349-361 with the branch orders of :150-155 / :186-194:
+      audio-only  [text+null-audio, text+audio]         eps = e0 + ag (e1 - e0)
+      text-only   [null-text+audio, text+audio]         eps = e0 + tg (e1 - e0)
+      dual        [uncond, text+null-audio, text+audio] eps = e0 + tg (e1 - e0) + ag (e2 - e1)
+    scheduler on frames 1.. (:364)."""
     sch = RefPNDM() if scheduler == "pndm" else RefDDIM()
     sch.set_timesteps(steps)
     b, _, f = latents.shape[:3]
-    do_cfg = audio_guidance > 1.0
-    txt = (torch.cat([text, text]) if do_cfg else text)[:, None].expand(-1, f, -1, -1)
-    aud = (torch.cat([null_audio.expand_as(audio), audio]) if do_cfg else audio)[:, None].expand(-1, f, -1, -1)
+    do_audio, do_text = audio_guidance > 1.0, text_guidance > 1.0
+    k = 1 + int(do_audio) + int(do_text)
+    na = null_audio.expand_as(audio) if do_audio else None
+    nt = null_text.expand_as(text) if do_text else None
+    if do_text and do_audio:
+        txt, aud = torch.cat([nt, text, text]), torch.cat([na, na, audio])
+    elif do_text:
+        txt, aud = torch.cat([nt, text]), torch.cat([audio, audio])
+    elif do_audio:
+        txt, aud = torch.cat([text, text]), torch.cat([na, audio])
+    else:
+        txt, aud = text, audio
+    txt, aud = txt[:, None].expand(-1, f, -1, -1), aud[:, None].expand(-1, f, -1, -1)
     m = mask[None].expand(txt.shape[0], -1, -1)
     x = latents.clone().float()
     for t in sch.timesteps:
-        xin = torch.cat([x, x]) if do_cfg else x
+        xin = torch.cat([x] * k)
         n = unet_forward(unet_sd, unet_cfg, xin, int(t), txt, aud, m)
-        if do_cfg:
+        if do_text and do_audio:
+            n0, n1, n2 = n.chunk(3)
+            n = n0 + text_guidance * (n1 - n0) + audio_guidance * (n2 - n1)
+        elif k == 2:
             n0, n1 = n.chunk(2)
-            n = n0 + audio_guidance * (n1 - n0)
+            n = n0 + (text_guidance if do_text else audio_guidance) * (n1 - n0)
         x[:, :, 1:] = sch.step(n[:, :, 1:], t, x[:, :, 1:])
         if trace is not None:
             trace.append(x.clone())

@@ -172,11 +172,15 @@ def timestep_embedding(t, dim):
     return torch.cat([torch.cos(a), torch.sin(a)], -1)
 
 
-def guided_step(noise_pred, n_branch, g, x_in, x_out, ca, cb, *, eps_hist=None, store_slot=-1, w_cur=1.0, hist_idx=(), w=()):
+def guided_step(noise_pred, n_branch, g, x_in, x_out, ca, cb, *, eps_hist=None, store_slot=-1, w_cur=1.0, hist_idx=(), w=(),
+                g2=0.0):
     B = x_in.shape[0]
     eps = noise_pred[:B]
-    if n_branch == 2:
-        eps = eps + g * (noise_pred[B:] - eps)
+    if n_branch >= 2:
+        e1 = noise_pred[B:2 * B]
+        eps = eps + g * (e1 - eps)
+        if n_branch == 3:
+            eps = eps + g2 * (noise_pred[2 * B:] - e1)
     if store_slot >= 0:
         eps_hist[store_slot] = eps
     e = w_cur * eps

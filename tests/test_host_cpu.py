@@ -296,3 +296,110 @@ def test_non_audio_block_types_and_input_validation(emulated):
     ragged[0, 6] = True
     with pytest.raises(ValueError, match="different numbers of keys"):
         full(g["sample"], 1, g["text"], g["audio"], audio_attention_mask=ragged)
+
+
+def test_scheduler_rejects_options_it_does_not_restate(tmp_path):
+    """sample-changing options must not be swallowed (diffusers' DDIM default is clip_sample=True)."""
+    import json
+
+    from asva_amd.schedulers import DDIMScheduler, PNDMScheduler
+
+    for bad in (dict(clip_sample=True), dict(thresholding=True), dict(trained_betas=[0.1, 0.2]), dict(rescale_betas_zero_snr=True),
+                dict(some_new_option=3)):
+        with pytest.raises(NotImplementedError):
+            DDIMScheduler(**bad)
+    # the SD1.5 scheduler_config.json (PNDM) loads
+    cfg = {"_class_name": "PNDMScheduler", "_diffusers_version": "0.6.0", "beta_end": 0.012, "beta_schedule": "scaled_linear",
+           "beta_start": 0.00085, "num_train_timesteps": 1000, "set_alpha_to_one": False, "skip_prk_steps": True, "steps_offset": 1,
+           "trained_betas": None, "clip_sample": False}
+    (tmp_path / "scheduler").mkdir()
+    (tmp_path / "scheduler" / "scheduler_config.json").write_text(json.dumps(cfg))
+    s = PNDMScheduler.from_pretrained(str(tmp_path), subfolder="scheduler")
+    s.set_timesteps(50)
+    assert len(s.timesteps) == 51
+    d = DDIMScheduler.from_pretrained(str(tmp_path), subfolder="scheduler")
+    d.set_timesteps(25)
+    assert len(d.timesteps) == 25
+
+
+def test_pndm_step_textbook_mode_keeps_a_copy():
+    """cur_sample_aliases_latents=False: `.step()` (object protocol) and `plan_step` (engine) agree — the sample restored
+    at the repeated timestep is the one passed to step 0 even when the caller overwrites its storage in place."""
+    from asva_amd.schedulers import PNDMScheduler
+
+    for alias in (True, False):
+        s = PNDMScheduler(cur_sample_aliases_latents=alias)
+        s.set_timesteps(10)
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn(1, 4, 3, 4, 4, generator=g)
+        x0 = x.clone()
+        e0, e1 = torch.randn(x.shape, generator=g), torch.randn(x.shape, generator=g)
+        x[:] = s.step(e0, s.timesteps[0], x).prev_sample          # in-place write-back, like the reference loop (:364)
+        x1 = x.clone()
+        out = s.step(e1, s.timesteps[1], x).prev_sample
+        p = s.plan_step(1)
+        want = p.ca * (x1 if alias else x0) + p.cb * (0.5 * e1 + 0.5 * e0)
+        assert torch.allclose(out, want, atol=1e-6)
+
+
+def test_data_utils_image_audio_video_and_lists(tmp_path, monkeypatch):
+    """avgen.data.utils loaders (reference avgen/data/utils.py:118-470): value ranges, shapes, clip sampling, lists."""
+    import numpy as np
+    from PIL import Image
+    from scipy.io import wavfile
+
+    from avgen.data.utils import (get_evaluation_data, load_audio_clips_uniformly, load_av_clips_uniformly, load_image,
+                                  load_video_clips_uniformly)
+
+    rng = np.random.default_rng(0)
+    Image.fromarray(rng.integers(0, 255, (300, 400, 3), dtype=np.uint8)).save(tmp_path / "im.png")
+    im = load_image(str(tmp_path / "im.png"), (256, 256))
+    assert im.shape == (3, 256, 256) and 0.0 <= float(im.min()) and float(im.max()) <= 1.0
+    # centre crop to the target aspect ratio first: a constant-column image stays constant per column
+    grad = np.tile(np.arange(400, dtype=np.uint8)[None, :, None] // 2, (300, 1, 3))
+    Image.fromarray(grad).save(tmp_path / "g.png")
+    gi = load_image(str(tmp_path / "g.png"), (256, 256))
+    assert float(gi.std(dim=1).max()) < 1e-6 and float(gi[0, 0, 0]) * 255 >= 24.0     # (400-300)//2 = 50 columns trimmed
+
+    sr = 22050
+    wave = (np.sin(np.arange(sr * 5) * 2 * np.pi * 440 / sr) * 0.5 * 32767).astype(np.int16)
+    wavfile.write(tmp_path / "a.wav", sr, wave)
+    clips = load_audio_clips_uniformly(str(tmp_path / "a.wav"), 2.0, 3, load_audio_as_melspectrogram=False)
+    assert len(clips) == 3 and all(c.shape == (1, 32000) for c in clips)
+    # (load_audio_as_melspectrogram=True runs avsd_kaldi_fbank on the device: covered by tests/test_audio_gpu.py)
+
+    frames = rng.integers(0, 255, (60, 48, 64, 3), dtype=np.uint8)            # 2 s at 30 fps
+    frames[:, 0, 0, 0] = np.arange(60)                                         # frame id in a pixel
+    audio = rng.standard_normal((1, 32000)).astype(np.float32) * 0.1
+    np.savez(tmp_path / "v.npz", frames=frames, fps=30.0, audio=audio, audio_sr=16000)
+    vid, aud = load_av_clips_uniformly(str(tmp_path / "v.npz"), video_fps=6, video_num_frame=6, image_size=(48, 64), num_clips=2,
+                                       load_audio_as_melspectrogram=False)
+    assert vid.shape == (2, 6, 3, 48, 64) and len(aud) == 2 and aud[0].shape == (1, 16000)
+    ids = (vid[0, :, 0, 0, 0] * 255).round().int().tolist()
+    assert ids == [0, 5, 10, 15, 20, 25]                                       # first frame at or after each multiple of 1/6 s
+    assert load_video_clips_uniformly(str(tmp_path / "v.npz"), 6, 6, (48, 64), 1).shape == (1, 6, 3, 48, 64)
+    with pytest.raises(RuntimeError, match="torchvision"):
+        load_av_clips_uniformly(str(tmp_path / "v.mp4"))
+
+    root = tmp_path / "datasets" / "AVSync15"
+    root.mkdir(parents=True)
+    (root / "test.txt").write_text("dog/a.mp4\ncat/b.mp4\n")
+    monkeypatch.setenv("AVSD_DATASETS_ROOT", str(tmp_path / "datasets"))
+    vroot, paths, cats, kind = get_evaluation_data("AVSync15")
+    assert vroot.endswith("AVSync15/videos") and paths == ["dog/a.mp4", "cat/b.mp4"] and cats == ["dog", "cat"] and kind == "video"
+
+
+def test_mjpeg_avi_writer_roundtrip(tmp_path):
+    from asva_amd.pipeline import write_video
+    from asva_amd.video_io import read_mjpeg_avi
+
+    g = torch.Generator().manual_seed(0)
+    base = torch.rand(1, 16, 16, 3, generator=g)
+    video = (torch.nn.functional.interpolate(base.permute(0, 3, 1, 2), size=(64, 96), mode="bilinear").permute(0, 2, 3, 1)
+             .expand(5, -1, -1, -1) * 255).to(torch.uint8).contiguous()
+    audio = torch.sin(torch.arange(16000) * 0.05)[None] * 0.3
+    path = write_video(str(tmp_path / "clip.mp4"), video, 6, audio, 16000, "aac")
+    assert path.endswith("clip.avi")
+    v, fps, a, afps = read_mjpeg_avi(path)
+    assert v.shape == video.shape and abs(fps - 6.0) < 1e-6 and afps == 16000 and a.shape == audio.shape
+    assert (v.float() - video.float()).abs().mean() < 8.0 and (a - audio).abs().max() < 1e-4

@@ -444,6 +444,14 @@ def test_guided_step(ops):
     ref[:, :, 0] = x[:, :, 0]
     assert torch.allclose(xo, ref, atol=1e-5)
     assert torch.allclose(hist2[2], eps, atol=1e-6) and torch.equal(hist2[3], hist[3])
+    # dual guidance (pipeline_audio_cond_animation.py:349-353): [uncond, text, text+audio]
+    np3 = rndf(3 * B, C, Fr, H, W, seed=4)
+    xo3 = torch.empty_like(x)
+    ops.guided_step(np3, 3, 7.5, x, xo3, 0.9, -0.3, g2=4.0)
+    eps3 = np3[:B] + 7.5 * (np3[B:2 * B] - np3[:B]) + 4.0 * (np3[2 * B:] - np3[B:2 * B])
+    ref3 = 0.9 * x - 0.3 * eps3
+    ref3[:, :, 0] = x[:, :, 0]
+    assert torch.allclose(xo3, ref3, atol=2e-5)
     # DDIM form, no guidance, in place
     x2 = x.clone()
     ops.guided_step(npred[:B].contiguous(), 1, 1.0, x2, x2, 1.1, 0.2)

@@ -68,6 +68,32 @@ def test_pipeline_matches_oracle_pipeline(emu, kind):
     assert (u8.int() - (vid.permute(0, 1, 3, 4, 2) * 255).byte().int()).abs().max() <= 1
 
 
+@pytest.mark.parametrize("tg,ag", [(7.5, 4.0), (7.5, 1.0)])
+def test_text_and_dual_guidance_match_oracle(emu, tg, ag):
+    """Dual / text-only classifier-free guidance (pipeline :150-155, :186-194, :349-357) through the fused engine
+    (3-branch avsd_guided_step) and through the reference-style loop, against the oracle pipeline."""
+    from asva_amd.schedulers import DDIMScheduler
+    from oracle import pipeline_ref
+
+    g = load_golden("unet_tiny_e2e.pt")
+    c = _clip(g, seed=3)
+    pipe, unet, _ = _pipe(g, DDIMScheduler())
+    null_text = torch.randn(1, *c["text"].shape[1:], generator=torch.Generator().manual_seed(5))
+    pipe.null_text_encoding = null_text
+    steps = 3
+    kw = dict(texts=[""], text_encodings=[c["text"]], video_length=c["f"], height=c["hw"][0], width=c["hw"][1],
+              num_inference_steps=steps, audio_guidance_scale=ag, text_guidance_scale=tg, image_latents=c["image_latents"],
+              audio_encodings=c["audio"], null_audio_encodings=c["null_audio"], audio_masks=c["mask"], noise=c["noise"],
+              output_latents=True)
+    fused = pipe(**kw)
+    pipe.use_engine = False
+    looped = pipe(**kw)
+    x0 = pipeline_ref.prepare_video_latents(c["image_latents"], c["noise"])
+    ref = pipeline_ref.denoise(unet.state_dict(), dict(unet.config), x0, c["text"], c["audio"], c["null_audio"], c["mask"], steps,
+                               ag, "ddim", text_guidance=tg, null_text=null_text)
+    assert rel_l2(fused, ref) < 5e-2 and rel_l2(looped, ref) < 5e-2 and rel_l2(fused, looped) < 2e-2
+
+
 def test_pipeline_encodes_the_conditioning_image(emu):
     """images= path (pipeline :309-310): preprocess to [-1, 1], vae.encode(...).latent_dist.sample() * 0.18215."""
     from asva_amd.schedulers import DDIMScheduler

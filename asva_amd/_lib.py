@@ -11,8 +11,11 @@ import os
 import torch  # noqa: F401  — must be imported BEFORE the .so is loaded: libavsd_hip.so then binds to the HIP
 #                runtime torch already mapped (one runtime, one device context) instead of a second copy
 
+from . import precision as P
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AVSD_LIB_PATH") or os.path.join(_HERE, "libavsd_hip.so")   # override: A/B-testing a kernel build
+LIB_PATHS = {"bf16": LIB_PATH, "fp16": os.environ.get("AVSD_LIB_PATH_F16") or os.path.join(_HERE, "libavsd_hip_f16.so")}
 
 c_void_p, c_int, c_float, c_int64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 
@@ -36,12 +39,14 @@ class GemmDesc(C.Structure):
         ("tile", C.c_int32),
         ("split_k", C.c_int32), ("splitk_ws", c_void_p),
         ("rowstats", c_void_p), ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("ln_nblk", C.c_int32), ("ln_eps", C.c_float),
+        ("out_master", c_void_p), ("ldm", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
 # name -> (restype, argtypes); exactly the symbols include/avsd.h declares
 SIGNATURES = {
     "avsd_abi_version": (c_int, []),
+    "avsd_precision": (C.c_char_p, []),
     "avsd_last_error": (C.c_char_p, []),
     "avsd_device_info": (c_int, [C.c_char_p, c_int, C.POINTER(c_int)]),
     "avsd_gemm_bf16": (c_int, [C.POINTER(GemmDesc), c_void_p]),
@@ -70,7 +75,7 @@ SIGNATURES = {
     "avsd_vit_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
 }
 
-_lib = None
+_libs = {}
 
 
 class AvsdError(RuntimeError):
@@ -78,15 +83,17 @@ class AvsdError(RuntimeError):
 
 
 def lib() -> C.CDLL:
-    """Loads libavsd_hip.so (once).  Raises if it has not been built — there is no CPU path."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+    """The kernel library of the current storage precision (asva_amd.precision), loaded once per precision.  Raises if
+    it has not been built — there is no CPU path."""
+    handle = _libs.get(P.NAME)
+    if handle is None:
+        path = LIB_PATHS[P.NAME]
+        if not os.path.exists(path):
             raise AvsdError(
-                f"{LIB_PATH} not found: build it with `python -m asva_amd.build` "
+                f"{path} not found: build it with `python -m asva_amd.build` "
                 "(hipcc --offload-arch=gfx950).  asva_amd has no fallback compute path."
             )
-        handle = C.CDLL(LIB_PATH)
+        handle = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is missing
             fn.restype = res
@@ -95,8 +102,10 @@ def lib() -> C.CDLL:
             raise AvsdError(
                 f"avsd_gemm_desc layout mismatch: C {handle.avsd_sizeof_gemm_desc()} B vs ctypes {C.sizeof(GemmDesc)} B"
             )
-        _lib = handle
-    return _lib
+        if handle.avsd_precision().decode() != P.NAME:
+            raise AvsdError(f"{path} computes in {handle.avsd_precision().decode()}, expected {P.NAME}")
+        _libs[P.NAME] = handle
+    return handle
 
 
 def check(rc: int, what: str) -> None:

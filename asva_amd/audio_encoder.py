@@ -29,6 +29,8 @@ import os
 from typing import Any, Dict, Optional
 
 import torch
+
+from . import precision as P
 import torch.nn as nn
 
 from . import ops
@@ -223,7 +225,7 @@ class ImageBindSegmaskAudioEncoder(nn.Module):
         """bf16 GEMM operands, f32 biases / norm parameters / tables, on the module's device."""
         if self._packed is not None:
             return self._packed
-        bf = lambda t: t.detach().to(torch.bfloat16).contiguous()      # noqa: E731
+        bf = lambda t: t.detach().to(P.ACT).contiguous()      # noqa: E731
         f32 = lambda t: t.detach().to(torch.float32).contiguous()      # noqa: E731
         pre = self.preprocessor
         pk = {

@@ -14,6 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libavsd_hip.so")
+# two builds of the same sources: bfloat16 storage (default) and IEEE-half storage (-DAVSD_F16=1), asva_amd/precision.py
+VARIANTS = {"bf16": ("", LIB, []), "fp16": ("_f16", os.path.join(HERE, "libavsd_hip_f16.so"), ["-DAVSD_F16=1"])}
 SOURCES = ["lib.hip", "attention.hip", "norm.hip", "elementwise.hip", "audio.hip"]
 # gemm.hip instantiates ~270 kernels: compiled as four translation units (one per A-loader mode + the entry point)
 GEMM_UNITS = 4
@@ -35,23 +37,31 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(verbose: bool = False, force: bool = False) -> str:
-    os.makedirs(OBJ, exist_ok=True)
+def build(verbose: bool = False, force: bool = False, variants=("bf16", "fp16")) -> str:
     hipcc = _hipcc()
     jobs = []
-    objs = []
-    for src in SOURCES:
-        s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
-        objs.append(o)
-        if force or _stale(o, [s] + HEADERS):
-            jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
-    gsrc = os.path.join(CSRC, "gemm.hip")
-    for u in range(GEMM_UNITS):
-        o = os.path.join(OBJ, f"gemm_tu{u}.o")
-        objs.append(o)
-        if force or _stale(o, [gsrc] + HEADERS):
-            jobs.insert(0, [hipcc, *FLAGS, f"-DAVSD_GEMM_TU={u}", "-c", gsrc, "-o", o])     # longest jobs first
+    links = []
+    for var in variants:
+        suffix, lib, defs = VARIANTS[var]
+        objdir = OBJ + suffix
+        os.makedirs(objdir, exist_ok=True)
+        objs = []
+        stale = False
+        for src in SOURCES:
+            s = os.path.join(CSRC, src)
+            o = os.path.join(objdir, src.replace(".hip", ".o"))
+            objs.append(o)
+            if force or _stale(o, [s] + HEADERS):
+                jobs.append([hipcc, *FLAGS, *defs, "-c", s, "-o", o])
+                stale = True
+        gsrc = os.path.join(CSRC, "gemm.hip")
+        for u in range(GEMM_UNITS):
+            o = os.path.join(objdir, f"gemm_tu{u}.o")
+            objs.append(o)
+            if force or _stale(o, [gsrc] + HEADERS):
+                jobs.insert(0, [hipcc, *FLAGS, *defs, f"-DAVSD_GEMM_TU={u}", "-c", gsrc, "-o", o])     # longest jobs first
+                stale = True
+        links.append((lib, objs, stale))
 
     def run(cmd):
         if verbose:
@@ -62,10 +72,11 @@ def build(verbose: bool = False, force: bool = False) -> str:
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
 
-    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
+    with ThreadPoolExecutor(max_workers=min(7, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    for lib, objs, stale in links:
+        if force or stale or _stale(lib, objs):
+            run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
     return LIB
 
 

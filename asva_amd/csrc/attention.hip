@@ -23,7 +23,7 @@
 namespace {
 
 struct AttnArgs {
-  const bf16_t* Q; const bf16_t* K; const bf16_t* V; bf16_t* O;
+  const h16_t* Q; const h16_t* K; const h16_t* V; h16_t* O;
   int ldq, ldk, ldv, ldo;
   int Lq, Lk, kv_rows, q_per_kv, frames;
   const int32_t* key_index;
@@ -53,8 +53,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
   constexpr bool ONES = DV > D;
   constexpr int LB = D / 32, LR = ((D % 32) & 3) + 4 * ((D % 32) >> 3), LH = ((D % 32) >> 2) & 1;
 
-  __shared__ __attribute__((aligned(16))) bf16_t sK[2][32 * KS];
-  __shared__ __attribute__((aligned(16))) bf16_t sVt[2][DV * VS];
+  __shared__ __attribute__((aligned(16))) h16_t sK[2][32 * KS];
+  __shared__ __attribute__((aligned(16))) h16_t sVt[2][DV * VS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -73,17 +73,17 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
   for (int i = tid; i < (int)(sizeof(sVt) / 16); i += 256) reinterpret_cast<uint4*>(&sVt[0][0])[i] = make_uint4(0, 0, 0, 0);
 
   // ---- Q fragments (MFMA B operand: lane holds Q[q][16c + 8*half + 0..7]) ----------------------
-  bf16x8 qf[QB][NCK];
+  h16x8 qf[QB][NCK];
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
     const int q = q0 + 32 * j;
-    const bf16_t* qrow = p.Q + ((int64_t)qb * p.Lq + q) * p.ldq + head * D;
+    const h16_t* qrow = p.Q + ((int64_t)qb * p.Lq + q) * p.ldq + head * D;
 #pragma unroll
     for (int c = 0; c < NCK; ++c) {
       const int dd = c * 16 + half * 8;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (q < p.Lq && dd < D) v = *reinterpret_cast<const uint4*>(qrow + dd);
-      qf[j][c] = __builtin_bit_cast(bf16x8, v);
+      qf[j][c] = __builtin_bit_cast(h16x8, v);
     }
   }
 
@@ -99,8 +99,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
     l_run[j] = 0.f;
   }
 
-  const bf16_t* Kb = p.K + (int64_t)kb * p.kv_rows * p.ldk + head * D;
-  const bf16_t* Vb = p.V + (int64_t)kb * p.kv_rows * p.ldv + head * D;
+  const h16_t* Kb = p.K + (int64_t)kb * p.kv_rows * p.ldk + head * D;
+  const h16_t* Vb = p.V + (int64_t)kb * p.kv_rows * p.ldv + head * D;
   const int32_t* kidx = IDX ? p.key_index + (int64_t)frame * p.Lk : nullptr;   // IDX: keys gathered through a list
   const float sl2 = p.scale * 1.4426950408889634f;   // scores are kept in the log2 domain (v_exp_f32 is 2^x)
 
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
   gload(0, ra);
   __syncthreads();   // zero fill complete
   if (ONES) {
-    if (tid < 32) { sVt[0][D * VS + tid] = 0x3f80; sVt[1][D * VS + tid] = 0x3f80; }
+    if (tid < 32) { sVt[0][D * VS + tid] = AVSD_H16_ONE; sVt[1][D * VS + tid] = AVSD_H16_ONE; }
   }
   lstore(0, ra);
   // every prologue load (Q fragments, tile 0) has landed: tells the compiler's wait-count pass that the loop
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
     gload(t + 2, nxt);
     const bool tail = (t + 1 == ntiles) && (p.Lk & 31);
 
-    bf16x8 pf[QB][2];
+    h16x8 pf[QB][2];
 #pragma unroll
     for (int j = 0; j < QB; ++j) {
       // ---- S^T[key][query] = K . Q^T -------------------------------------------------------------
@@ -204,8 +204,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
       for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
       for (int c = 0; c < NCK; ++c) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&sK[st][l31 * KS + c * 16 + half * 8]);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[j][c], s, 0, 0, 0);
+        const h16x8 kf = *reinterpret_cast<const h16x8*>(&sK[st][l31 * KS + c * 16 + half * 8]);
+        s = mfma32x32x16(kf, qf[j][c], s, 0, 0, 0);
       }
 
       // ---- online softmax: lane owns query l31, keys (r&3) + 8*(r>>2) + 4*half -------------------
@@ -253,26 +253,26 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         uint4 v;
-        v.x = pack2bf(s[8 * c + 0], s[8 * c + 1]);
-        v.y = pack2bf(s[8 * c + 2], s[8 * c + 3]);
-        v.z = pack2bf(s[8 * c + 4], s[8 * c + 5]);
-        v.w = pack2bf(s[8 * c + 6], s[8 * c + 7]);
-        pf[j][c] = __builtin_bit_cast(bf16x8, v);
+        v.x = pack2h(s[8 * c + 0], s[8 * c + 1]);
+        v.y = pack2h(s[8 * c + 2], s[8 * c + 3]);
+        v.z = pack2h(s[8 * c + 4], s[8 * c + 5]);
+        v.w = pack2h(s[8 * c + 6], s[8 * c + 7]);
+        pf[j][c] = __builtin_bit_cast(h16x8, v);
       }
     }
 
     // ---- O^T[dcol][query] += V^T . P^T ; V^T k-slots follow the same key permutation -------------
 #pragma unroll
     for (int b = 0; b < NDB; ++b) {
-      const bf16_t* vrow = &sVt[st][(b * 32 + l31) * VS + 4 * half];
+      const h16_t* vrow = &sVt[st][(b * 32 + l31) * VS + 4 * half];
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const uint2 lo = *reinterpret_cast<const uint2*>(vrow + 16 * c);
         const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16 * c + 8);
-        const bf16x8 vv = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        const h16x8 vv = __builtin_bit_cast(h16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
 #pragma unroll
         for (int j = 0; j < QB; ++j)
-          acc_o[j][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vv, pf[j][c], acc_o[j][b], 0, 0, 0);
+          acc_o[j][b] = mfma32x32x16(vv, pf[j][c], acc_o[j][b], 0, 0, 0);
       }
     }
     if (t + 1 < ntiles) lstore(st ^ 1, cur);
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
     const float inv = 1.0f / l_tot;
     const int q = q0 + 32 * j;
     if (q < p.Lq) {
-      bf16_t* orow = p.O + ((int64_t)qb * p.Lq + q) * p.ldo + head * D;
+      h16_t* orow = p.O + ((int64_t)qb * p.Lq + q) * p.ldo + head * D;
 #pragma unroll
       for (int b = 0; b < NDB; ++b) {
         if (b * 32 + 32 <= D && (p.ldo & 7) == 0) {
@@ -303,14 +303,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
           unsigned x[2][2], y[2][2];
 #pragma unroll
           for (int d = 0; d < 2; ++d) {
-            const auto e = __builtin_amdgcn_permlane32_swap(pack2bf(acc_o[j][b][2 * d] * inv, acc_o[j][b][2 * d + 1] * inv),
-                                                            pack2bf(acc_o[j][b][8 + 2 * d] * inv, acc_o[j][b][8 + 2 * d + 1] * inv), false, false);
-            const auto o = __builtin_amdgcn_permlane32_swap(pack2bf(acc_o[j][b][4 + 2 * d] * inv, acc_o[j][b][4 + 2 * d + 1] * inv),
-                                                            pack2bf(acc_o[j][b][12 + 2 * d] * inv, acc_o[j][b][12 + 2 * d + 1] * inv), false, false);
+            const auto e = __builtin_amdgcn_permlane32_swap(pack2h(acc_o[j][b][2 * d] * inv, acc_o[j][b][2 * d + 1] * inv),
+                                                            pack2h(acc_o[j][b][8 + 2 * d] * inv, acc_o[j][b][8 + 2 * d + 1] * inv), false, false);
+            const auto o = __builtin_amdgcn_permlane32_swap(pack2h(acc_o[j][b][4 + 2 * d] * inv, acc_o[j][b][4 + 2 * d + 1] * inv),
+                                                            pack2h(acc_o[j][b][12 + 2 * d] * inv, acc_o[j][b][12 + 2 * d + 1] * inv), false, false);
             x[0][d] = e[0]; x[1][d] = e[1];
             y[0][d] = o[0]; y[1][d] = o[1];
           }
-          bf16_t* op = orow + b * 32 + 16 * half;
+          h16_t* op = orow + b * 32 + 16 * half;
           *reinterpret_cast<uint4*>(op) = make_uint4(x[0][0], x[0][1], x[1][0], x[1][1]);
           *reinterpret_cast<uint4*>(op + 8) = make_uint4(y[0][0], y[0][1], y[1][0], y[1][1]);
         } else {
@@ -319,8 +319,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
             const int dcol = b * 32 + 8 * qd + 4 * half;
             if (dcol < D) {
               uint2 st;
-              st.x = pack2bf(acc_o[j][b][4 * qd + 0] * inv, acc_o[j][b][4 * qd + 1] * inv);
-              st.y = pack2bf(acc_o[j][b][4 * qd + 2] * inv, acc_o[j][b][4 * qd + 3] * inv);
+              st.x = pack2h(acc_o[j][b][4 * qd + 0] * inv, acc_o[j][b][4 * qd + 1] * inv);
+              st.y = pack2h(acc_o[j][b][4 * qd + 2] * inv, acc_o[j][b][4 * qd + 3] * inv);
               *reinterpret_cast<uint2*>(orow + dcol) = st;
             }
           }
@@ -352,7 +352,7 @@ int launch_attn(const AttnArgs& a, int Bq, int heads, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------------------
 struct TAttnArgs {
-  const bf16_t* QKV; bf16_t* O;
+  const h16_t* QKV; h16_t* O;
   int ldqkv, ldo, frames, hw, heads;
   int hpb;    // heads per workgroup (blockIdx.y = head group): low-resolution layers have too few pixels to fill the chip
   float scale;
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(1024) void tattn_kernel(const TAttnArgs p) {
   constexpr int DS = D / SL;                    // 1, 2 or 4 lanes per (head, frame)
   constexpr int NV = SL / 8;                    // 16-byte vectors per slice
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_t[];
-  bf16_t* sKV = reinterpret_cast<bf16_t*>(smem_t);  // [frames][2*C] : k | v
+  h16_t* sKV = reinterpret_cast<h16_t*>(smem_t);  // [frames][2*C] : k | v
   const int C = p.heads * D;
   const int Cg = p.hpb * D;             // channels of this workgroup's head group
   const int c0g = blockIdx.y * Cg;      // first channel of the group
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(1024) void tattn_kernel(const TAttnArgs p) {
   // following the barrier
   uint4 qv[NV];
   {
-    const bf16_t* qrow = p.QKV + (row0 + (int64_t)i * p.hw) * p.ldqkv + coff;
+    const h16_t* qrow = p.QKV + (row0 + (int64_t)i * p.hw) * p.ldqkv + coff;
 #pragma unroll
     for (int d = 0; d < NV; ++d) qv[d] = *reinterpret_cast<const uint4*>(qrow + d * 8);
   }
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(1024) void tattn_kernel(const TAttnArgs p) {
   for (int j = 0; j < FMAX; ++j) {
     float dot = 0.f;
     if (j < F) {
-      const bf16_t* krow = sKV + j * 2 * Cg + loff;
+      const h16_t* krow = sKV + j * 2 * Cg + loff;
 #pragma unroll
       for (int d = 0; d < NV; ++d) {
         float a[8], k[8];
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(1024) void tattn_kernel(const TAttnArgs p) {
   const float inv = 1.0f / sum;
   if (!active) return;
 
-  bf16_t* orow = p.O + (row0 + (int64_t)i * p.hw) * p.ldo + coff;
+  h16_t* orow = p.O + (row0 + (int64_t)i * p.hw) * p.ldo + coff;
 #pragma unroll
   for (int d = 0; d < NV; ++d) {
     float o[8];
@@ -463,7 +463,7 @@ int launch_tattn(const TAttnArgs& a0, int B, hipStream_t s) {
   // one workgroup per (clip branch, pixel, head group): split the heads until ~1024 workgroups exist
   a.hpb = a.heads;
   while (a.hpb > 1 && a.hpb % 2 == 0 && (long)B * a.hw * (a.heads / a.hpb) < 1024) a.hpb /= 2;
-  const size_t lds = (size_t)a.frames * 2 * a.hpb * D * sizeof(bf16_t);
+  const size_t lds = (size_t)a.frames * 2 * a.hpb * D * sizeof(h16_t);
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tattn_kernel<D, FMAX>),
@@ -505,7 +505,7 @@ extern "C" int avsd_attention(const void* Q, int ldq, const void* K, int ldk, co
   AVSD_REQUIRE(scale > 0.f, "attention: scale must be positive");
   AVSD_REQUIRE(kv_rows >= Lk || key_index, "attention: kv_rows (%d) < Lk (%d) without a gather list", kv_rows, Lk);
   AttnArgs a;
-  a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V; a.O = (bf16_t*)O;
+  a.Q = (const h16_t*)Q; a.K = (const h16_t*)K; a.V = (const h16_t*)V; a.O = (h16_t*)O;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
   a.Lq = Lq; a.Lk = Lk; a.kv_rows = kv_rows; a.q_per_kv = q_per_kv; a.frames = frames;
   a.key_index = key_index; a.scale = scale;
@@ -528,7 +528,7 @@ extern "C" int avsd_temporal_attention(const void* QKV, int ldqkv, void* O, int 
   AVSD_REQUIRE(ldqkv % 8 == 0 && ldo % 8 == 0, "temporal attention: strides must be multiples of 8");
   AVSD_REQUIRE((size_t)frames * 2 * heads * d * 2 <= 160 * 1024, "temporal attention: K/V slab exceeds LDS");
   TAttnArgs a;
-  a.QKV = (const bf16_t*)QKV; a.O = (bf16_t*)O; a.ldqkv = ldqkv; a.ldo = ldo;
+  a.QKV = (const h16_t*)QKV; a.O = (h16_t*)O; a.ldqkv = ldqkv; a.ldo = ldo;
   a.frames = frames; a.hw = hw; a.heads = heads; a.scale = scale;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (d) {

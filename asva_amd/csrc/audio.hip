@@ -95,7 +95,7 @@ __global__ __launch_bounds__(FB_THREADS) void fbank_kernel(const FbankArgs p) {
   }
 }
 
-__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int B, int C,
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ src, h16_t* __restrict__ dst, int B, int C,
                                                        int H, int W, int kh, int kw, int stride, int ph, int pw_) {
   const int kk = C * kh * kw;
   const int64_t total = (int64_t)B * ph * pw_ * kk;
@@ -106,12 +106,12 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     const int py = (int)((r / pw_) % ph);
     const int b = (int)(r / ((int64_t)pw_ * ph));
     const int dx = e % kw, dy = (e / kw) % kh, c = e / (kw * kh);
-    dst[i] = f2bf(src[(((int64_t)b * C + c) * H + py * stride + dy) * W + px * stride + dx]);
+    dst[i] = f2h(src[(((int64_t)b * C + c) * H + py * stride + dy) * W + px * stride + dx]);
   }
 }
 
-__global__ __launch_bounds__(256) void tokens_kernel(const bf16_t* __restrict__ patches, const float* __restrict__ cls,
-                                                     const float* __restrict__ pos, bf16_t* __restrict__ out, int B, int np,
+__global__ __launch_bounds__(256) void tokens_kernel(const h16_t* __restrict__ patches, const float* __restrict__ cls,
+                                                     const float* __restrict__ pos, h16_t* __restrict__ out, int B, int np,
                                                      int C, int tail) {
   const int L = 1 + np + tail;
   const int64_t total = (int64_t)B * L * C;
@@ -121,8 +121,8 @@ __global__ __launch_bounds__(256) void tokens_kernel(const bf16_t* __restrict__ 
     const int b = (int)(i / ((int64_t)C * L));
     float v = 0.f;
     if (l == 0) v = cls[c] + pos[c];
-    else if (l <= np) v = bf2f(patches[((int64_t)b * np + (l - 1)) * C + c]) + pos[(int64_t)l * C + c];
-    out[i] = f2bf(v);
+    else if (l <= np) v = h2f(patches[((int64_t)b * np + (l - 1)) * C + c]) + pos[(int64_t)l * C + c];
+    out[i] = f2h(v);
   }
 }
 
@@ -155,7 +155,7 @@ extern "C" int avsd_patchify(const float* src, void* dst, int B, int C, int H, i
   const int64_t total = (int64_t)B * ph * pw * C * kh * kw;
   const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src,
-                     reinterpret_cast<bf16_t*>(dst), B, C, H, W, kh, kw, stride, ph, pw);
+                     reinterpret_cast<h16_t*>(dst), B, C, H, W, kh, kw, stride, ph, pw);
   AVSD_CHECK_LAUNCH("patchify launch");
   return AVSD_OK;
 }
@@ -167,7 +167,7 @@ extern "C" int avsd_vit_tokens(const void* patches, const float* cls, const floa
   const int64_t total = (int64_t)B * (1 + n_patches + tail_rows) * C;
   const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   hipLaunchKernelGGL(tokens_kernel, dim3((unsigned)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     reinterpret_cast<const bf16_t*>(patches), cls, pos, reinterpret_cast<bf16_t*>(out), B, n_patches, C, tail_rows);
+                     reinterpret_cast<const h16_t*>(patches), cls, pos, reinterpret_cast<h16_t*>(out), B, n_patches, C, tail_rows);
   AVSD_CHECK_LAUNCH("vit_tokens launch");
   return AVSD_OK;
 }

@@ -6,8 +6,21 @@
 #include <stdarg.h>
 #include "../../include/avsd.h"
 
-typedef unsigned short bf16_t;  // raw bfloat16 storage
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+// ---- 16-bit storage type of activations and matrix weights --------------------------------------------------------
+// One source tree, two builds (asva_amd/build.py): default = bfloat16 (libavsd_hip.so, BASELINE.json's dtype);
+// -DAVSD_F16=1 = IEEE half (libavsd_hip_f16.so: the higher-precision mode, same MFMA rate).  Accumulation, softmax,
+// normalisation statistics and every epilogue are f32 in both.  Only this block knows which one is compiled.
+typedef unsigned short h16_t;  // raw 16-bit storage
+#ifdef AVSD_F16
+typedef _Float16 hw_h16;
+#define AVSD_H16_ONE 0x3c00u
+#define AVSD_PRECISION_NAME "fp16"
+#else
+typedef __bf16 hw_h16;
+#define AVSD_H16_ONE 0x3f80u
+#define AVSD_PRECISION_NAME "bf16"
+#endif
+typedef __attribute__((ext_vector_type(8))) hw_h16 h16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
@@ -31,35 +44,57 @@ void avsd_set_error(const char* fmt, ...);
     }                                                                             \
   } while (0)
 
-// ---- bf16 <-> f32 (device) -----------------------------------------------------------
-__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-
-// round-to-nearest-even via the gfx950 conversion instruction (v_cvt_pk_bf16_f32)
-typedef __bf16 hw_bf16x2 __attribute__((ext_vector_type(2)));
+// ---- 16-bit <-> f32 (device) ------------------------------------------------------------
+typedef hw_h16 hw_h16x2 __attribute__((ext_vector_type(2)));
 typedef float hw_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  const hw_f32x2 v = {lo, hi};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hw_bf16x2));
+#ifdef AVSD_F16
+__device__ __forceinline__ float h2f(h16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+// low / high half of a packed pair -> f32 (v_cvt_f32_f16, the high half through SDWA)
+__device__ __forceinline__ float lo2f(uint32_t u) { return (float)__builtin_bit_cast(hw_h16x2, u)[0]; }
+__device__ __forceinline__ float hi2f(uint32_t u) { return (float)__builtin_bit_cast(hw_h16x2, u)[1]; }
+__device__ __forceinline__ f32x16 mfma32x32x16(h16x8 a, h16x8 b, f32x16 c, int, int, int) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
-__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
+#else
+__device__ __forceinline__ float h2f(h16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ float lo2f(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float hi2f(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ f32x16 mfma32x32x16(h16x8 a, h16x8 b, f32x16 c, int, int, int) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+#endif
 
-// 8 bf16 packed in a uint4 -> 8 floats
+// two f32 -> one packed pair, round-to-nearest-even in both builds (v_cvt_pk_bf16_f32 / v_cvt_f16_f32 x2)
+__device__ __forceinline__ uint32_t pack2h(float lo, float hi) {
+  const hw_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hw_h16x2));
+}
+__device__ __forceinline__ h16_t f2h(float f) { return (h16_t)(pack2h(f, 0.f) & 0xffffu); }
+
+// 8 packed 16-bit values in a uint4 -> 8 floats
 __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
-  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
-  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
-  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+  f[0] = lo2f(v.x); f[1] = hi2f(v.x);
+  f[2] = lo2f(v.y); f[3] = hi2f(v.y);
+  f[4] = lo2f(v.z); f[5] = hi2f(v.z);
+  f[6] = lo2f(v.w); f[7] = hi2f(v.w);
 }
 __device__ __forceinline__ uint4 pack8(const float* f) {
   uint4 v;
-  v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]);
-  v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+  v.x = pack2h(f[0], f[1]); v.y = pack2h(f[2], f[3]);
+  v.z = pack2h(f[4], f[5]); v.w = pack2h(f[6], f[7]);
   return v;
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// erf-GELU (torch F.gelu default; diffusers GEGLU): 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz & Stegun 7.1.26
+// (|error| <= 1.5e-7 — two orders below the 16-bit rounding of the result; libm's erff costs ~3x the instructions, and a
+// GEGLU epilogue evaluates one per output element).  1 + erf(z) is formed without cancellation on both sides of 0.
 __device__ __forceinline__ float gelu_erf_f(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  const float poly = fmaf(fmaf(fmaf(fmaf(1.061405429f, t, -1.453152027f), t, 1.421413741f), t, -0.284496736f), t, 0.254829592f) * t;
+  const float pe = poly * __expf(-z * z);          // = 1 - erf(|z|)
+  return 0.5f * x * (x >= 0.f ? 2.0f - pe : pe);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

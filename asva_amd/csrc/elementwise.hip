@@ -11,7 +11,7 @@
 
 namespace {
 
-__global__ void ncfhw_to_rows_kernel(const float* src, bf16_t* dst, int B, int C, int F, int HW, int cpad,
+__global__ void ncfhw_to_rows_kernel(const float* src, h16_t* dst, int B, int C, int F, int HW, int cpad,
                                      int rep, float scale) {
   // one thread per (rep, b, f, p); writes cpad channels
   const int64_t n = (int64_t)rep * B * F * HW;
@@ -19,11 +19,11 @@ __global__ void ncfhw_to_rows_kernel(const float* src, bf16_t* dst, int B, int C
     const int p = (int)(i % HW);
     const int f = (int)((i / HW) % F);
     const int b = (int)((i / ((int64_t)HW * F)) % B);
-    bf16_t* o = dst + i * cpad;
+    h16_t* o = dst + i * cpad;
     for (int c = 0; c < cpad; ++c) {
       float v = 0.f;
       if (c < C) v = src[(((int64_t)b * C + c) * F + f) * HW + p] * scale;
-      o[c] = f2bf(v);
+      o[c] = f2h(v);
     }
   }
 }
@@ -52,7 +52,7 @@ __global__ void timestep_embedding_kernel(const float* t, float* out, int n, int
 }
 
 // out[m, n] = act_out(sum_k act_in(x[m, k]) * W[n, k] + bias[n]); one wave per n, 8 rows per block.y
-__global__ __launch_bounds__(256) void linear_small_m_kernel(const float* x, const bf16_t* W, const float* bias,
+__global__ __launch_bounds__(256) void linear_small_m_kernel(const float* x, const h16_t* W, const float* bias,
                                                              float* out, int M, int N, int K, int ldw, int act_in,
                                                              int act_out) {
   const int lane = threadIdx.x & 63;
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void linear_small_m_kernel(const float* x, con
   float acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-  const bf16_t* wrow = W + (int64_t)n * ldw;
+  const h16_t* wrow = W + (int64_t)n * ldw;
   for (int k = lane * 8; k < K; k += 512) {
     float w[8];
     unpack8(*reinterpret_cast<const uint4*>(wrow + k), w);
@@ -128,25 +128,25 @@ __global__ void guided_step_kernel(const GuidedArgs a) {
   }
 }
 
-__global__ void vae_postprocess_kernel(const bf16_t* src, int ld, float* dst, int N, int HW) {
+__global__ void vae_postprocess_kernel(const h16_t* src, int ld, float* dst, int N, int HW) {
   const int64_t n = (int64_t)N * 3 * HW;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int p = (int)(i % HW);
     const int c = (int)((i / HW) % 3);
     const int im = (int)(i / ((int64_t)3 * HW));
-    const float v = bf2f(src[((int64_t)im * HW + p) * ld + c]) * 0.5f + 0.5f;
+    const float v = h2f(src[((int64_t)im * HW + p) * ld + c]) * 0.5f + 0.5f;
     dst[i] = fminf(fmaxf(v, 0.f), 1.f);
   }
 }
 
 // channels-last bf16 rows [N*HW][ld] -> uint8 frames (N, H, W, 3): (clamp(x/2+0.5, 0, 1) * 255) truncated, i.e. the
 // pipeline's post-processing (:212) followed by generate_videos' `(video.permute(0,2,3,1) * 255).byte()` (:448)
-__global__ void vae_postprocess_u8_kernel(const bf16_t* src, int ld, uint8_t* dst, int64_t npix) {
+__global__ void vae_postprocess_u8_kernel(const h16_t* src, int ld, uint8_t* dst, int64_t npix) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
-    const bf16_t* s = src + i * ld;
+    const h16_t* s = src + i * ld;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float v = fminf(fmaxf(bf2f(s[c]) * 0.5f + 0.5f, 0.f), 1.f);
+      const float v = fminf(fmaxf(h2f(s[c]) * 0.5f + 0.5f, 0.f), 1.f);
       dst[i * 3 + c] = (uint8_t)(v * 255.0f);
     }
   }
@@ -166,7 +166,7 @@ extern "C" int avsd_ncfhw_to_rows(const float* src, void* dst, int B, int C, int
   AVSD_REQUIRE(src && dst && B > 0 && C > 0 && F > 0 && HW > 0 && cpad >= C && rep >= 1, "ncfhw_to_rows: bad arguments");
   const int64_t n = (int64_t)rep * B * F * HW;
   hipLaunchKernelGGL(ncfhw_to_rows_kernel, dim3(grid_for(n, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     src, (bf16_t*)dst, B, C, F, HW, cpad, rep, scale);
+                     src, (h16_t*)dst, B, C, F, HW, cpad, rep, scale);
   AVSD_CHECK_LAUNCH("ncfhw_to_rows launch");
   return AVSD_OK;
 }
@@ -195,7 +195,7 @@ extern "C" int avsd_linear_small_m(const float* x, const void* W, const float* b
                "linear_small_m: need 0 < M <= 64, K %% 8 == 0, ldw %% 8 == 0 (M=%d N=%d K=%d ldw=%d)", M, N, K, ldw);
   dim3 grid((unsigned)((N + 3) / 4), (unsigned)((M + 7) / 8));
   hipLaunchKernelGGL(linear_small_m_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
-                     (const bf16_t*)W, bias, out, M, N, K, ldw, act_in, act_out);
+                     (const h16_t*)W, bias, out, M, N, K, ldw, act_in, act_out);
   AVSD_CHECK_LAUNCH("linear_small_m launch");
   return AVSD_OK;
 }
@@ -225,7 +225,7 @@ extern "C" int avsd_vae_postprocess(const void* src, int ld, float* dst, int N, 
   AVSD_REQUIRE(src && dst && N > 0 && HW > 0 && ld >= 3, "vae_postprocess: bad arguments");
   const int64_t n = (int64_t)N * 3 * HW;
   hipLaunchKernelGGL(vae_postprocess_kernel, dim3(grid_for(n, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     (const bf16_t*)src, ld, dst, N, HW);
+                     (const h16_t*)src, ld, dst, N, HW);
   AVSD_CHECK_LAUNCH("vae_postprocess launch");
   return AVSD_OK;
 }
@@ -234,7 +234,7 @@ extern "C" int avsd_vae_postprocess_u8(const void* src, int ld, void* dst, int N
   AVSD_REQUIRE(src && dst && N > 0 && HW > 0 && ld >= 3, "vae_postprocess_u8: bad arguments");
   const int64_t n = (int64_t)N * HW;
   hipLaunchKernelGGL(vae_postprocess_u8_kernel, dim3(grid_for(n, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     (const bf16_t*)src, ld, (uint8_t*)dst, n);
+                     (const h16_t*)src, ld, (uint8_t*)dst, n);
   AVSD_CHECK_LAUNCH("vae_postprocess_u8 launch");
   return AVSD_OK;
 }

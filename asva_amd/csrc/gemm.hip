@@ -56,11 +56,11 @@ __device__ __forceinline__ RowInfo make_row(const avsd_gemm_desc& p, int m) {
 }
 
 template <int MODE>
-__device__ __forceinline__ uint4 load_a(const avsd_gemm_desc& p, const bf16_t* A, const bf16_t* A2,
+__device__ __forceinline__ uint4 load_a(const avsd_gemm_desc& p, const h16_t* A, const h16_t* A2,
                                         const RowInfo& r, int k0) {
   uint4 z = make_uint4(0, 0, 0, 0);
   if (!r.valid || k0 >= p.K) return z;
-  const bf16_t* ptr;
+  const h16_t* ptr;
   if (MODE == AVSD_GEMM_PLAIN) {
     ptr = (k0 < p.k_split) ? (A + r.o0 + k0) : (A2 + r.o1 + (k0 - p.k_split));
   } else if (MODE == AVSD_GEMM_TMIX) {
@@ -110,6 +110,8 @@ __device__ __forceinline__ void ln_row_stats(const avsd_gemm_desc& p, int m, int
 
 // ---- shared f32 epilogue: lane holds row m = m_base + (lane&31) of fragment b, and columns
 // n = n_base + 32*a + 8q + 4*(lane>>5) + {0..3} of fragment a (see header of this file) ----------------
+// Residuals are 16-bit, or f32 under AVSD_GEMM_RES1_F32 / RES2_F32 (the f32 residual stream); with `out_master` the
+// un-rounded f32 result is stored next to the 16-bit one.
 template <int FN, int FM>
 __device__ __forceinline__ void epilogue(const avsd_gemm_desc& p, f32x16 (&acc)[FN][FM], int m_base, int n_base,
                                          int lane, int64_t bz, const float (&pre_ln)[2 * FM], bool have_pre) {
@@ -119,8 +121,11 @@ __device__ __forceinline__ void epilogue(const avsd_gemm_desc& p, f32x16 (&acc)[
   const bool gelu = (p.flags & AVSD_GEMM_GELU) != 0;
   const bool lnfuse = (p.flags & AVSD_GEMM_LNFUSE) != 0;
   const bool rowstats = (p.flags & AVSD_GEMM_ROWSTATS) != 0;
-  const bf16_t* R1 = reinterpret_cast<const bf16_t*>(p.res1);
-  const bf16_t* R2 = reinterpret_cast<const bf16_t*>(p.res2);
+  const bool r1f = (p.flags & AVSD_GEMM_RES1_F32) != 0, r2f = (p.flags & AVSD_GEMM_RES2_F32) != 0;
+  const h16_t* R1 = reinterpret_cast<const h16_t*>(p.res1);
+  const h16_t* R2 = reinterpret_cast<const h16_t*>(p.res2);
+  const float* R1f = reinterpret_cast<const float*>(p.res1);
+  const float* R2f = reinterpret_cast<const float*>(p.res2);
   const int hsel = (lane >> 5) * 4;
 #pragma unroll
   for (int b = 0; b < FM; ++b) {
@@ -134,43 +139,52 @@ __device__ __forceinline__ void epilogue(const avsd_gemm_desc& p, f32x16 (&acc)[
       else ln_row_stats(p, m, bz, ln_rstd, ln_mr);
     }
     float2* rs_out = rowstats ? reinterpret_cast<float2*>(p.rowstats) + ((int64_t)bz * p.M + m) * (p.N >> 5) : nullptr;
+    const int64_t orow = bz * p.batch_stride_out + (int64_t)m * p.ldc;
+    float* mrow = p.out_master ? p.out_master + bz * p.batch_stride_out + (int64_t)m * p.ldm : nullptr;
+    // alpha * acc (+ LayerNorm fold) + bias + rowvec (+ GELU) for quad q of fragment (a, b) -> v[0..3]
+    auto head = [&](int a, int q, int n, float (&v)[4]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = p.alpha * acc[a][b][4 * q + i];
+      if (lnfuse) {
+        const float4 cs = *reinterpret_cast<const float4*>(p.ln_colsum + n);
+        v[0] = fmaf(v[0], ln_rstd, -ln_mr * cs.x); v[1] = fmaf(v[1], ln_rstd, -ln_mr * cs.y);
+        v[2] = fmaf(v[2], ln_rstd, -ln_mr * cs.z); v[3] = fmaf(v[3], ln_rstd, -ln_mr * cs.w);
+      }
+      if (p.bias) {
+        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+      }
+      if (rv) {
+        const float4 bb = *reinterpret_cast<const float4*>(rv + n);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+      }
+    };
+    auto add_f32 = [&](const float* R, int ldr, int n, float (&v)[4]) {
+      const float4 rr = *reinterpret_cast<const float4*>(R + bz * p.batch_stride_out + (int64_t)m * ldr + n);
+      v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+    };
 #pragma unroll
     for (int a = 0; a < FN; ++a) {
       const int nb = n_base + a * 32;  // first packed column of this fragment
       if (nb >= p.N) continue;
-      // bf16 output, fragment fully inside N, 16-byte-aligned rows: the two lanes that share a row (l, l ^ 32) trade
-      // halves with v_permlane32_swap so each stores (and reads the residuals as) 32 contiguous bytes — two dwordx4
+      // 16-bit output, fragment fully inside N, 16-byte-aligned rows: the two lanes that share a row (l, l ^ 32) trade
+      // halves with v_permlane32_swap so each stores (and reads 16-bit residuals as) 32 contiguous bytes — two dwordx4
       // per fragment instead of four dwordx2 scattered 8 bytes apart (store issue, not bandwidth, bounds this tail).
-      const bool wide = !geglu && !out_f32 && nb + 32 <= p.N && (p.ldc & 7) == 0 && (!R1 || (p.ldr1 & 7) == 0) &&
-                        (!R2 || (p.ldr2 & 7) == 0);
+      const bool wide = !geglu && !out_f32 && nb + 32 <= p.N && (p.ldc & 7) == 0 && (!R1 || r1f || (p.ldr1 & 7) == 0) &&
+                        (!R2 || r2f || (p.ldr2 & 7) == 0);
       if (wide) {
         float v[4][4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int n = nb + 8 * q + hsel;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[q][i] = p.alpha * acc[a][b][4 * q + i];
-          if (lnfuse) {
-            const float4 cs = *reinterpret_cast<const float4*>(p.ln_colsum + n);
-            v[q][0] = fmaf(v[q][0], ln_rstd, -ln_mr * cs.x); v[q][1] = fmaf(v[q][1], ln_rstd, -ln_mr * cs.y);
-            v[q][2] = fmaf(v[q][2], ln_rstd, -ln_mr * cs.z); v[q][3] = fmaf(v[q][3], ln_rstd, -ln_mr * cs.w);
-          }
-          if (p.bias) {
-            const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-            v[q][0] += bb.x; v[q][1] += bb.y; v[q][2] += bb.z; v[q][3] += bb.w;
-          }
-          if (rv) {
-            const float4 bb = *reinterpret_cast<const float4*>(rv + n);
-            v[q][0] += bb.x; v[q][1] += bb.y; v[q][2] += bb.z; v[q][3] += bb.w;
-          }
+          head(a, q, nb + 8 * q + hsel, v[q]);
           if (gelu) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[q][i] = gelu_erf_f(v[q][i]);
           }
         }
         const int ncol = nb + 4 * hsel;   // this lane's 16 columns after the swap: nb (lanes 0-31) or nb + 16
-        auto add_res = [&](const bf16_t* R, int ldr) {
-          const bf16_t* rp = R + bz * p.batch_stride_out + (int64_t)m * ldr + ncol;
+        auto add_res = [&](const h16_t* R, int ldr) {
+          const h16_t* rp = R + bz * p.batch_stride_out + (int64_t)m * ldr + ncol;
           const uint4 lo = *reinterpret_cast<const uint4*>(rp);
           const uint4 hi = *reinterpret_cast<const uint4*>(rp + 8);
           const unsigned s0[2] = {lo.x, lo.y}, s1[2] = {lo.z, lo.w}, s2[2] = {hi.x, hi.y}, s3[2] = {hi.z, hi.w};
@@ -178,23 +192,38 @@ __device__ __forceinline__ void epilogue(const avsd_gemm_desc& p, f32x16 (&acc)[
           for (int d = 0; d < 2; ++d) {
             const auto e = __builtin_amdgcn_permlane32_swap(s0[d], s1[d], false, false);   // -> quads 0 and 2
             const auto o = __builtin_amdgcn_permlane32_swap(s2[d], s3[d], false, false);   // -> quads 1 and 3
-            v[0][2 * d] += __uint_as_float(e[0] << 16); v[0][2 * d + 1] += __uint_as_float(e[0] & 0xffff0000u);
-            v[2][2 * d] += __uint_as_float(e[1] << 16); v[2][2 * d + 1] += __uint_as_float(e[1] & 0xffff0000u);
-            v[1][2 * d] += __uint_as_float(o[0] << 16); v[1][2 * d + 1] += __uint_as_float(o[0] & 0xffff0000u);
-            v[3][2 * d] += __uint_as_float(o[1] << 16); v[3][2 * d + 1] += __uint_as_float(o[1] & 0xffff0000u);
+            v[0][2 * d] += lo2f(e[0]); v[0][2 * d + 1] += hi2f(e[0]);
+            v[2][2 * d] += lo2f(e[1]); v[2][2 * d + 1] += hi2f(e[1]);
+            v[1][2 * d] += lo2f(o[0]); v[1][2 * d + 1] += hi2f(o[0]);
+            v[3][2 * d] += lo2f(o[1]); v[3][2 * d + 1] += hi2f(o[1]);
           }
         };
-        if (R1) add_res(R1, p.ldr1);
-        if (R2) add_res(R2, p.ldr2);
+        if (R1) {
+          if (r1f) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) add_f32(R1f, p.ldr1, nb + 8 * q + hsel, v[q]);
+          } else add_res(R1, p.ldr1);
+        }
+        if (R2) {
+          if (r2f) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) add_f32(R2f, p.ldr2, nb + 8 * q + hsel, v[q]);
+          } else add_res(R2, p.ldr2);
+        }
+        if (mrow) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(mrow + nb + 8 * q + hsel) = make_float4(v[q][0], v[q][1], v[q][2], v[q][3]);
+        }
         unsigned x[2][2], y[2][2];
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
-          const auto e = __builtin_amdgcn_permlane32_swap(pack2bf(v[0][2 * d], v[0][2 * d + 1]), pack2bf(v[2][2 * d], v[2][2 * d + 1]), false, false);
-          const auto o = __builtin_amdgcn_permlane32_swap(pack2bf(v[1][2 * d], v[1][2 * d + 1]), pack2bf(v[3][2 * d], v[3][2 * d + 1]), false, false);
+          const auto e = __builtin_amdgcn_permlane32_swap(pack2h(v[0][2 * d], v[0][2 * d + 1]), pack2h(v[2][2 * d], v[2][2 * d + 1]), false, false);
+          const auto o = __builtin_amdgcn_permlane32_swap(pack2h(v[1][2 * d], v[1][2 * d + 1]), pack2h(v[3][2 * d], v[3][2 * d + 1]), false, false);
           x[0][d] = e[0]; x[1][d] = e[1];
           y[0][d] = o[0]; y[1][d] = o[1];
         }
-        bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + bz * p.batch_stride_out + (int64_t)m * p.ldc + ncol;
+        h16_t* op = reinterpret_cast<h16_t*>(p.out) + orow + ncol;
         *reinterpret_cast<uint4*>(op) = make_uint4(x[0][0], x[0][1], x[1][0], x[1][1]);
         *reinterpret_cast<uint4*>(op + 8) = make_uint4(y[0][0], y[0][1], y[1][0], y[1][1]);
         if (rs_out) {
@@ -203,7 +232,7 @@ __device__ __forceinline__ void epilogue(const avsd_gemm_desc& p, f32x16 (&acc)[
           const unsigned w8[8] = {x[0][0], x[0][1], x[1][0], x[1][1], y[0][0], y[0][1], y[1][0], y[1][1]};
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            const float lo = __uint_as_float(w8[i] << 16), hi = __uint_as_float(w8[i] & 0xffff0000u);
+            const float lo = lo2f(w8[i]), hi = hi2f(w8[i]);
             sm += lo + hi;
             sq = fmaf(lo, lo, fmaf(hi, hi, sq));
           }
@@ -219,75 +248,69 @@ __device__ __forceinline__ void epilogue(const avsd_gemm_desc& p, f32x16 (&acc)[
           const int n = nb + 8 * q + hsel;
           if (n >= p.N) continue;
           float v[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = p.alpha * acc[a][b][4 * q + i];
-          if (lnfuse) {
-            const float4 cs = *reinterpret_cast<const float4*>(p.ln_colsum + n);
-            v[0] = fmaf(v[0], ln_rstd, -ln_mr * cs.x); v[1] = fmaf(v[1], ln_rstd, -ln_mr * cs.y);
-            v[2] = fmaf(v[2], ln_rstd, -ln_mr * cs.z); v[3] = fmaf(v[3], ln_rstd, -ln_mr * cs.w);
-          }
-          if (p.bias) {
-            const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-            v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-          }
-          if (rv) {
-            const float4 bb = *reinterpret_cast<const float4*>(rv + n);
-            v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-          }
+          head(a, q, n, v);
           if (gelu) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = gelu_erf_f(v[i]);
           }
           if (R1) {
-            const uint2 rr = *reinterpret_cast<const uint2*>(R1 + bz * p.batch_stride_out + (int64_t)m * p.ldr1 + n);
-            v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-            v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+            if (r1f) add_f32(R1f, p.ldr1, n, v);
+            else {
+              const uint2 rr = *reinterpret_cast<const uint2*>(R1 + bz * p.batch_stride_out + (int64_t)m * p.ldr1 + n);
+              v[0] += lo2f(rr.x); v[1] += hi2f(rr.x); v[2] += lo2f(rr.y); v[3] += hi2f(rr.y);
+            }
           }
           if (R2) {
-            const uint2 rr = *reinterpret_cast<const uint2*>(R2 + bz * p.batch_stride_out + (int64_t)m * p.ldr2 + n);
-            v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-            v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+            if (r2f) add_f32(R2f, p.ldr2, n, v);
+            else {
+              const uint2 rr = *reinterpret_cast<const uint2*>(R2 + bz * p.batch_stride_out + (int64_t)m * p.ldr2 + n);
+              v[0] += lo2f(rr.x); v[1] += hi2f(rr.x); v[2] += lo2f(rr.y); v[3] += hi2f(rr.y);
+            }
           }
-          const int64_t o = bz * p.batch_stride_out + (int64_t)m * p.ldc + n;
+          if (mrow) *reinterpret_cast<float4*>(mrow + n) = make_float4(v[0], v[1], v[2], v[3]);
           if (out_f32) {
-            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow + n) = make_float4(v[0], v[1], v[2], v[3]);
           } else {
             uint2 st;
-            st.x = pack2bf(v[0], v[1]);
-            st.y = pack2bf(v[2], v[3]);
-            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + o) = st;
+            st.x = pack2h(v[0], v[1]);
+            st.y = pack2h(v[2], v[3]);
+            *reinterpret_cast<uint2*>(reinterpret_cast<h16_t*>(p.out) + orow + n) = st;
           }
         }
       } else {
-        // packed 32-row block = [16 value rows | 16 gate rows]; quads 0,1 hold values, 2,3 gates
+        // GEGLU: packed 32-row block = [16 value rows | 16 gate rows]; quads 0,1 hold values, 2,3 their gates.
+        float v[2][4];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          const int nval = nb + 8 * q + hsel;   // packed column of the value
-          const int ngate = nval + 16;
-          float v[4];
+          float gate[4];
+          head(a, q, nb + 8 * q + hsel, v[q]);
+          head(a, q + 2, nb + 8 * q + hsel + 16, gate);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            float val = p.alpha * acc[a][b][4 * q + i];
-            float gate = p.alpha * acc[a][b][4 * (q + 2) + i];
-            if (lnfuse) {
-              val = fmaf(val, ln_rstd, -ln_mr * p.ln_colsum[nval + i]);
-              gate = fmaf(gate, ln_rstd, -ln_mr * p.ln_colsum[ngate + i]);
-            }
-            if (p.bias) {
-              val += p.bias[nval + i];
-              gate += p.bias[ngate + i];
-            }
-            v[i] = val * gelu_erf_f(gate);
+          for (int i = 0; i < 4; ++i) v[q][i] *= gelu_erf_f(gate[i]);
+        }
+        const int no = (nb >> 1) + hsel;   // output feature of quad 0; quad 1 sits 8 further
+        if (!out_f32 && (p.ldc & 7) == 0) {
+          // lanes l / l ^ 32 hold output columns {0-3, 8-11} / {4-7, 12-15} of the 16-column block: swap so that each stores
+          // 8 contiguous columns (one dwordx4 instead of two dwordx2)
+          unsigned e0[2], e1[2];
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            const auto e = __builtin_amdgcn_permlane32_swap(pack2h(v[0][2 * d], v[0][2 * d + 1]), pack2h(v[1][2 * d], v[1][2 * d + 1]), false, false);
+            e0[d] = e[0]; e1[d] = e[1];
           }
-          const int no = (nb >> 1) + 8 * q + hsel;  // output feature
-          const int64_t o = bz * p.batch_stride_out + (int64_t)m * p.ldc + no;
-          if (out_f32) {
-            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-            uint2 st;
-            st.x = pack2bf(v[0], v[1]);
-            st.y = pack2bf(v[2], v[3]);
-            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + o) = st;
+          *reinterpret_cast<uint4*>(reinterpret_cast<h16_t*>(p.out) + orow + (nb >> 1) + 2 * hsel) = make_uint4(e0[0], e0[1], e1[0], e1[1]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int64_t o = orow + no + 8 * q;
+            if (out_f32) {
+              *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) = make_float4(v[q][0], v[q][1], v[q][2], v[q][3]);
+            } else {
+              uint2 st;
+              st.x = pack2h(v[q][0], v[q][1]);
+              st.y = pack2h(v[q][2], v[q][3]);
+              *reinterpret_cast<uint2*>(reinterpret_cast<h16_t*>(p.out) + o) = st;
+            }
           }
         }
       }
@@ -298,8 +321,8 @@ __device__ __forceinline__ void epilogue(const avsd_gemm_desc& p, f32x16 (&acc)[
 template <int BM, int BN, int MODE>
 __global__ __launch_bounds__(256) void gemm_kernel(const avsd_gemm_desc p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16_t* sA = reinterpret_cast<bf16_t*>(smem);      // [2][BM][LDS_STRIDE]
-  bf16_t* sW = sA + 2 * BM * LDS_STRIDE;             // [2][BN][LDS_STRIDE]
+  h16_t* sA = reinterpret_cast<h16_t*>(smem);      // [2][BM][LDS_STRIDE]
+  h16_t* sW = sA + 2 * BM * LDS_STRIDE;             // [2][BN][LDS_STRIDE]
 
   constexpr int NA = BM / 32;  // 16-byte vectors per thread per A tile
   constexpr int NW = BN / 32;
@@ -331,9 +354,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const avsd_gemm_desc p) {
   const int tm = nmaj ? wg % ntm : wg / ntn;
 
   const int64_t bz = blockIdx.z;
-  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + bz * p.batch_stride_a;
-  const bf16_t* A2 = p.A2 ? reinterpret_cast<const bf16_t*>(p.A2) + bz * p.batch_stride_a : nullptr;
-  const bf16_t* W = reinterpret_cast<const bf16_t*>(p.W) + bz * p.batch_stride_w;
+  const h16_t* A = reinterpret_cast<const h16_t*>(p.A) + bz * p.batch_stride_a;
+  const h16_t* A2 = p.A2 ? reinterpret_cast<const h16_t*>(p.A2) + bz * p.batch_stride_a : nullptr;
+  const h16_t* W = reinterpret_cast<const h16_t*>(p.W) + bz * p.batch_stride_w;
 
   // ---- per-thread staging rows -----------------------------------------------------------------
   const int kv = (tid & 7) * 8;   // k offset of this thread's vector inside a K tile
@@ -387,20 +410,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const avsd_gemm_desc p) {
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) gload(kt + 1);
-    const bf16_t* bA = sA + (buf * BM + wm * (BM / 2) + frow) * LDS_STRIDE + fk;
-    const bf16_t* bW = sW + (buf * BN + wn * (BN / 2) + frow) * LDS_STRIDE + fk;
+    const h16_t* bA = sA + (buf * BM + wm * (BM / 2) + frow) * LDS_STRIDE + fk;
+    const h16_t* bW = sW + (buf * BN + wn * (BN / 2) + frow) * LDS_STRIDE + fk;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      bf16x8 xf[FM], wf[FN];
+      h16x8 xf[FM], wf[FN];
 #pragma unroll
-      for (int b = 0; b < FM; ++b) xf[b] = *reinterpret_cast<const bf16x8*>(bA + b * 32 * LDS_STRIDE + ks * 16);
+      for (int b = 0; b < FM; ++b) xf[b] = *reinterpret_cast<const h16x8*>(bA + b * 32 * LDS_STRIDE + ks * 16);
 #pragma unroll
-      for (int a = 0; a < FN; ++a) wf[a] = *reinterpret_cast<const bf16x8*>(bW + a * 32 * LDS_STRIDE + ks * 16);
+      for (int a = 0; a < FN; ++a) wf[a] = *reinterpret_cast<const h16x8*>(bW + a * 32 * LDS_STRIDE + ks * 16);
 #pragma unroll
       for (int a = 0; a < FN; ++a)
 #pragma unroll
         for (int b = 0; b < FM; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = mfma32x32x16(wf[a], xf[b], acc[a][b], 0, 0, 0);
     }
     if (kt + 1 < nk) lstore(buf ^ 1);
     __syncthreads();
@@ -412,7 +435,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const avsd_gemm_desc p) {
 
 template <int BM, int BN, int MODE>
 int launch(const avsd_gemm_desc& d, hipStream_t s) {
-  constexpr size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(bf16_t);
+  constexpr size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(h16_t);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, MODE>),
@@ -570,9 +593,9 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm2_kernel(const avsd_g
   const int kt0 = ksplit * per_split;
   const int kt1 = min(nk_all, kt0 + per_split);
 
-  const bf16_t* Ab = reinterpret_cast<const bf16_t*>(p.A) + bz * p.batch_stride_a;
-  const bf16_t* A2b = p.A2 ? reinterpret_cast<const bf16_t*>(p.A2) + bz * p.batch_stride_a : Ab;
-  const bf16_t* Wb = reinterpret_cast<const bf16_t*>(p.W) + bz * p.batch_stride_w;
+  const h16_t* Ab = reinterpret_cast<const h16_t*>(p.A) + bz * p.batch_stride_a;
+  const h16_t* A2b = p.A2 ? reinterpret_cast<const h16_t*>(p.A2) + bz * p.batch_stride_a : Ab;
+  const h16_t* Wb = reinterpret_cast<const h16_t*>(p.W) + bz * p.batch_stride_w;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)A2b, 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, 0x7fffffff, 0x00020000);
@@ -763,19 +786,19 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm2_kernel(const avsd_g
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       const int c = ks * 2 + chalf;
-      bf16x8 xf[FM], wf[FN];
+      h16x8 xf[FM], wf[FN];
 #pragma unroll
       for (int b = 0; b < FM; ++b)
-        xf[b] = *reinterpret_cast<const bf16x8*>(sA + a_line[b] + (((a_hi[b] | c) ^ a_sw[b]) << 4));
+        xf[b] = *reinterpret_cast<const h16x8*>(sA + a_line[b] + (((a_hi[b] | c) ^ a_sw[b]) << 4));
 #pragma unroll
       for (int a = 0; a < FN; ++a)
-        wf[a] = *reinterpret_cast<const bf16x8*>(sW + w_line[a] + (((w_hi[a] | c) ^ w_sw[a]) << 4));
+        wf[a] = *reinterpret_cast<const h16x8*>(sW + w_line[a] + (((w_hi[a] | c) ^ w_sw[a]) << 4));
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int a = 0; a < FN; ++a)
 #pragma unroll
         for (int b = 0; b < FM; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = mfma32x32x16(wf[a], xf[b], acc[a][b], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     }
   }
@@ -807,8 +830,8 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm2_kernel(const avsd_g
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const avsd_gemm_desc p) {
   const int nq = p.N / 4;
   const int64_t total = (int64_t)p.M * nq;
-  const bf16_t* R1 = reinterpret_cast<const bf16_t*>(p.res1);
-  const bf16_t* R2 = reinterpret_cast<const bf16_t*>(p.res2);
+  const h16_t* R1 = reinterpret_cast<const h16_t*>(p.res1);
+  const h16_t* R2 = reinterpret_cast<const h16_t*>(p.res2);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int m = (int)(i / nq);
     const int n = (int)(i - (int64_t)m * nq) * 4;
@@ -841,27 +864,36 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const avsd_gemm_desc
       for (int i = 0; i < 4; ++i) v[i] = gelu_erf_f(v[i]);
     }
     if (R1) {
-      const uint2 rr = *reinterpret_cast<const uint2*>(R1 + (int64_t)m * p.ldr1 + n);
-      v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-      v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+      if (p.flags & AVSD_GEMM_RES1_F32) {
+        const float4 rr = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res1) + (int64_t)m * p.ldr1 + n);
+        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+      } else {
+        const uint2 rr = *reinterpret_cast<const uint2*>(R1 + (int64_t)m * p.ldr1 + n);
+        v[0] += lo2f(rr.x); v[1] += hi2f(rr.x); v[2] += lo2f(rr.y); v[3] += hi2f(rr.y);
+      }
     }
     if (R2) {
-      const uint2 rr = *reinterpret_cast<const uint2*>(R2 + (int64_t)m * p.ldr2 + n);
-      v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-      v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+      if (p.flags & AVSD_GEMM_RES2_F32) {
+        const float4 rr = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res2) + (int64_t)m * p.ldr2 + n);
+        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+      } else {
+        const uint2 rr = *reinterpret_cast<const uint2*>(R2 + (int64_t)m * p.ldr2 + n);
+        v[0] += lo2f(rr.x); v[1] += hi2f(rr.x); v[2] += lo2f(rr.y); v[3] += hi2f(rr.y);
+      }
     }
+    if (p.out_master) *reinterpret_cast<float4*>(p.out_master + (int64_t)m * p.ldm + n) = make_float4(v[0], v[1], v[2], v[3]);
     const int64_t o = (int64_t)m * p.ldc + n;
     if (p.flags & AVSD_GEMM_OUT_F32) {
       *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) = make_float4(v[0], v[1], v[2], v[3]);
     } else {
       uint2 st;
-      st.x = pack2bf(v[0], v[1]);
-      st.y = pack2bf(v[2], v[3]);
-      *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + o) = st;
+      st.x = pack2h(v[0], v[1]);
+      st.y = pack2h(v[2], v[3]);
+      *reinterpret_cast<uint2*>(reinterpret_cast<h16_t*>(p.out) + o) = st;
       if (p.flags & AVSD_GEMM_ROWSTATS) {
         // 8 consecutive threads hold one 32-column block of row m (N % 32 == 0, 256 % 8 == 0): fold in a fixed order
-        const float a0 = __uint_as_float(st.x << 16), a1 = __uint_as_float(st.x & 0xffff0000u);
-        const float a2 = __uint_as_float(st.y << 16), a3 = __uint_as_float(st.y & 0xffff0000u);
+        const float a0 = lo2f(st.x), a1 = hi2f(st.x);
+        const float a2 = lo2f(st.y), a3 = hi2f(st.y);
         float sm = (a0 + a1) + (a2 + a3);
         float sq = fmaf(a0, a0, fmaf(a1, a1, fmaf(a2, a2, a3 * a3)));
 #pragma unroll
@@ -1012,6 +1044,8 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
   }
   if (d.res1) AVSD_REQUIRE(d.ldr1 % 4 == 0, "gemm: ldr1 must be a multiple of 4");
   if (d.res2) AVSD_REQUIRE(d.ldr2 % 4 == 0, "gemm: ldr2 must be a multiple of 4");
+  if (d.out_master) AVSD_REQUIRE(d.ldm % 4 == 0 && d.ldm >= d.N && !(d.flags & AVSD_GEMM_GEGLU),
+                                 "gemm: out_master needs ldm %% 4 == 0, ldm >= N and no GEGLU");
   if (d.rowvec) AVSD_REQUIRE(d.rows_per_vec > 0 && d.ldv % 4 == 0, "gemm: rowvec needs rows_per_vec > 0 and ldv %% 4 == 0");
   if (d.mode == AVSD_GEMM_PLAIN) {
     if (!d.A2) d.k_split = d.K;

@@ -16,7 +16,7 @@ namespace {
 //                      first `groups` threads fold (positions x channels-of-group) -> partial[nb][nchunks][g][2]
 //   gn_apply_kernel    every block folds the chunk partials of its batch in double -> (mean, rstd) per group ->
 //                      scale/shift per channel in LDS, then streams its rows: y = act(x * scale[c] + shift[c])
-__global__ void gn_stats_kernel(const bf16_t* x1, int ld1, int c1, const bf16_t* x2, int ld2, int c2,
+__global__ void gn_stats_kernel(const h16_t* x1, int ld1, int c1, const h16_t* x2, int ld2, int c2,
                                 int rows_per_batch, int groups, float* partial, int nchunks, int nvec,
                                 int ppb) {
   extern __shared__ float sgn[];  // [ppb][2*C]: sums | sums of squares
@@ -35,7 +35,7 @@ __global__ void gn_stats_kernel(const bf16_t* x1, int ld1, int c1, const bf16_t*
     float s[8], ss[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
-    const bf16_t* base;
+    const h16_t* base;
     int ld;
     if (c0 < c1) { base = x1 + c0; ld = ld1; } else { base = x2 + (c0 - c1); ld = ld2; }
     base += (int64_t)b * rows_per_batch * ld;
@@ -81,10 +81,10 @@ __global__ void gn_stats_kernel(const bf16_t* x1, int ld1, int c1, const bf16_t*
 // up to 64 lanes per group, double accumulation, fixed order — and builds scale[c] = rstd * gamma, shift[c] =
 // beta - mean * scale in LDS (a separate finalize launch cost a full ~5 us kernel boundary for a few KB of work), then
 // streams its share of the batch's rows: y = act(x * scale + shift), 2 vectors in flight per thread.
-__global__ __launch_bounds__(1024) void gn_apply_kernel(const bf16_t* x1, int ld1, int c1, const bf16_t* x2, int ld2, int c2,
+__global__ __launch_bounds__(1024) void gn_apply_kernel(const h16_t* x1, int ld1, int c1, const h16_t* x2, int ld2, int c2,
                                                        int rows_per_batch, const float* partial, int nchunks, int groups,
                                                        float eps, const float* gamma, const float* beta, int act,
-                                                       bf16_t* y, int ldy) {
+                                                       h16_t* y, int ldy) {
   extern __shared__ float gn_ss[];   // [C] scale | [C] shift
   __shared__ float smean[64], srstd[64];
   const int C = c1 + c2;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(1024) void gn_apply_kernel(const bf16_t* x1, int ld
       const int r = ok[u] ? i / nvec : 0;
       gr[u] = row_base + r0 + r;
       cc[u] = ok[u] ? (i - r * nvec) * 8 : 0;
-      const bf16_t* src = (cc[u] < c1) ? x1 + gr[u] * ld1 + cc[u] : x2 + gr[u] * ld2 + (cc[u] - c1);
+      const h16_t* src = (cc[u] < c1) ? x1 + gr[u] * ld1 + cc[u] : x2 + gr[u] * ld2 + (cc[u] - c1);
       v[u] = ok[u] ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(1024) void gn_apply_kernel(const bf16_t* x1, int ld
 // ---- LayerNorm: LPR lanes per row (power of two), 64/LPR rows per wave, up to 8 vectors per lane in registers.
 // C = 320/640/1280 -> LPR = 8/16/32 with exactly 5 vectors per lane: every lane busy, 5 loads in flight per lane.
 template <int LPR>
-__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* x, int ldx, bf16_t* y, int ldy, int M,
+__global__ __launch_bounds__(256) void layernorm_kernel(const h16_t* x, int ldx, h16_t* y, int ldy, int M,
                                                         int C, const float* gamma, const float* beta,
                                                         float eps, const float* pos, int hw, int frames) {
   constexpr int RPW = 64 / LPR;                 // rows per wave
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* x, int ldx
 }
 
 template <int LPR>
-void launch_layernorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, int M, int C, const float* gamma, const float* beta,
+void launch_layernorm(const h16_t* x, int ldx, h16_t* y, int ldy, int M, int C, const float* gamma, const float* beta,
                       float eps, const float* pos, int hw, int frames, hipStream_t s) {
   const int rows_per_block = 4 * (64 / LPR);
   hipLaunchKernelGGL(layernorm_kernel<LPR>, dim3((unsigned)((M + rows_per_block - 1) / rows_per_block)), dim3(256), 0, s, x, ldx,
@@ -253,7 +253,7 @@ void launch_layernorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, int M, int C
 }
 
 // ---- row softmax: S f32 -> P bf16, one wave per row ---------------------------------------------
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* S, int lds, bf16_t* P, int ldp, int rows,
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* S, int lds, h16_t* P, int ldp, int rows,
                                                            int L) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -271,12 +271,12 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* S, int l
     sum += __expf(v.x - mx) + __expf(v.y - mx) + __expf(v.z - mx) + __expf(v.w - mx);
   }
   const float inv = 1.0f / wave_sum(sum);
-  bf16_t* o = P + (int64_t)row * ldp;
+  h16_t* o = P + (int64_t)row * ldp;
   for (int j = lane * 4; j < L; j += 256) {
     const float4 v = *reinterpret_cast<const float4*>(s + j);
     uint2 st;
-    st.x = pack2bf(__expf(v.x - mx) * inv, __expf(v.y - mx) * inv);
-    st.y = pack2bf(__expf(v.z - mx) * inv, __expf(v.w - mx) * inv);
+    st.x = pack2h(__expf(v.x - mx) * inv, __expf(v.y - mx) * inv);
+    st.y = pack2h(__expf(v.z - mx) * inv, __expf(v.w - mx) * inv);
     *reinterpret_cast<uint2*>(o + j) = st;
   }
 }
@@ -332,7 +332,7 @@ extern "C" int avsd_groupnorm_stats(const void* x1, int ld1, int c1, const void*
   const size_t lds = (size_t)ppb * 2 * C * sizeof(float);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)nchunks, (unsigned)nb), dim3((unsigned)threads), lds, s,
-                     (const bf16_t*)x1, ld1, c1, (const bf16_t*)x2, ld2, c2, rows_per_batch, groups, scratch, nchunks, nvec, ppb);
+                     (const h16_t*)x1, ld1, c1, (const h16_t*)x2, ld2, c2, rows_per_batch, groups, scratch, nchunks, nvec, ppb);
   AVSD_CHECK_LAUNCH("groupnorm_stats launch");
   return AVSD_OK;
 }
@@ -354,8 +354,8 @@ extern "C" int avsd_groupnorm_apply(const void* x1, int ld1, int c1, const void*
   if (bpb > cap) bpb = (int)cap;
   if (bpb > rows_per_batch) bpb = rows_per_batch;
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)bpb, (unsigned)nb), dim3(1024), (size_t)2 * C * sizeof(float),
-                     reinterpret_cast<hipStream_t>(stream), (const bf16_t*)x1, ld1, c1, (const bf16_t*)x2, ld2, c2,
-                     rows_per_batch, scratch, nchunks, groups, eps, gamma, beta, act, (bf16_t*)y, ldy);
+                     reinterpret_cast<hipStream_t>(stream), (const h16_t*)x1, ld1, c1, (const h16_t*)x2, ld2, c2,
+                     rows_per_batch, scratch, nchunks, groups, eps, gamma, beta, act, (h16_t*)y, ldy);
   AVSD_CHECK_LAUNCH("groupnorm_apply launch");
   return AVSD_OK;
 }
@@ -369,8 +369,8 @@ extern "C" int avsd_layernorm(const void* x, int ldx, void* y, int ldy, int M, i
   if (!pos) { hw = 1; frames = 1; }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int nvec = C / 8;
-  const bf16_t* xi = (const bf16_t*)x;
-  bf16_t* yo = (bf16_t*)y;
+  const h16_t* xi = (const h16_t*)x;
+  h16_t* yo = (h16_t*)y;
   if (nvec <= 8) launch_layernorm<1>(xi, ldx, yo, ldy, M, C, gamma, beta, eps, pos, hw, frames, s);
   else if (nvec <= 16) launch_layernorm<2>(xi, ldx, yo, ldy, M, C, gamma, beta, eps, pos, hw, frames, s);
   else if (nvec <= 32) launch_layernorm<4>(xi, ldx, yo, ldy, M, C, gamma, beta, eps, pos, hw, frames, s);
@@ -386,7 +386,7 @@ extern "C" int avsd_softmax_rows(const float* S, int lds, void* P, int ldp, int 
   AVSD_REQUIRE(S && P && rows > 0 && L > 0, "softmax_rows: bad arguments");
   AVSD_REQUIRE(L % 4 == 0 && lds % 4 == 0 && ldp % 4 == 0, "softmax_rows: L, lds, ldp must be multiples of 4");
   hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), S, lds, (bf16_t*)P, ldp, rows, L);
+                     reinterpret_cast<hipStream_t>(stream), S, lds, (h16_t*)P, ldp, rows, L);
   AVSD_CHECK_LAUNCH("softmax_rows launch");
   return AVSD_OK;
 }

@@ -13,12 +13,13 @@ from typing import Optional
 import torch
 
 from . import _lib
+from . import precision as P
 from ._lib import GemmDesc, check
 
 PLAIN, TMIX, CONV3 = 0, 1, 2
-GEGLU, OUT_F32, GELU, XCD_N, ROWSTATS, LNFUSE = 1, 2, 4, 8, 16, 32
+GEGLU, OUT_F32, GELU, XCD_N, ROWSTATS, LNFUSE, RES1_F32, RES2_F32 = 1, 2, 4, 8, 16, 32, 64, 128
 _XCD_MODE = os.environ.get("AVSD_XCD_MODE", "auto")     # auto | m | n  (which operand each XCD's L2 fetches once)
-BF16, F32 = torch.bfloat16, torch.float32
+F32 = torch.float32      # (16-bit storage dtype: P.ACT, asva_amd/precision.py)
 
 
 class KernelTimer:
@@ -88,19 +89,24 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-# ---- per-shape tile autotuning -------------------------------------------------------------------------
+# ---- per-shape tile selection ---------------------------------------------------------------------------
 # The GEMM kernel exists in several tile/wave/stage configurations (gemm.hip: dispatch_tile).  Which one is
-# fastest depends on (mode, M, N, K): the first time a shape is seen OUTSIDE a graph capture, every candidate is
-# timed with HIP events on the caller's real buffers and the winner is cached for the life of the process
-# (measure, don't guess).  During capture, or with autotuning off, an uncached shape falls back to the
-# library's static heuristic (tile 0).
+# fastest depends on (mode, M, N, K, epilogue).  Selection is DETERMINISTIC by default, so two processes produce
+# bit-identical results (the f32 summation order depends on the tile):
+#   1. the committed table asva_amd/tiles_gfx950.json (tuned on MI355X for the BASELINE.json shapes by
+#      tools/tune_tiles.py; AVSD_TILE_CACHE=<file> replaces it),
+#   2. else a static rule of thumb (_heuristic_tile): the largest tile that still yields >= ~1 workgroup per CU, split-K
+#      for the low-resolution layers.
+# AVSD_AUTOTUNE=1 / set_autotune(True) switches on the measuring tuner for shapes missing from the table: every
+# candidate is timed with HIP events on the caller's real buffers and the winner is cached for the life of the
+# process (measure, don't guess) — that is how the table is produced; results then depend on timing noise.
 TILE_CANDIDATES = ((4, 1), (6, 1), (7, 1), (8, 1), (9, 1), (3, 1), (11, 1), (12, 1), (13, 1), (14, 1), (15, 1), (16, 1), (17, 1), (18, 1), (19, 1),
                    (20, 1), (21, 1), (22, 1), (23, 1), (24, 1), (25, 1), (26, 1), (27, 1), (28, 1))
 # extra (tile, split_k) candidates for GEMMs whose output is too small to fill 256 CUs with big tiles
 SPLITK_CANDIDATES = ((6, 2), (6, 4), (6, 8), (9, 2), (9, 4), (4, 2), (4, 4), (4, 8), (7, 2), (7, 4),
                      (20, 2), (20, 4), (24, 2), (24, 4), (24, 8), (25, 2), (25, 4), (26, 2), (26, 4), (26, 8))
 _TILE_CACHE: dict = {}
-_AUTOTUNE = True
+_AUTOTUNE = os.environ.get("AVSD_AUTOTUNE", "0") == "1"
 
 
 def set_autotune(on: bool) -> None:
@@ -130,8 +136,31 @@ def load_tile_cache(path: str) -> int:
     return len(_TILE_CACHE)
 
 
-if os.environ.get("AVSD_TILE_CACHE") and os.path.isfile(os.environ["AVSD_TILE_CACHE"]):
-    load_tile_cache(os.environ["AVSD_TILE_CACHE"])
+DEFAULT_TILE_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tiles_gfx950.json")
+if os.environ.get("AVSD_TILE_CACHE"):
+    if os.path.isfile(os.environ["AVSD_TILE_CACHE"]):
+        load_tile_cache(os.environ["AVSD_TILE_CACHE"])
+elif os.path.isfile(DEFAULT_TILE_TABLE):
+    load_tile_cache(DEFAULT_TILE_TABLE)
+
+
+def _heuristic_tile(M: int, N: int, K: int, geglu: bool, splitk_ok: bool):
+    """Static (tile, split_k) for shapes the table does not hold.  Per-tile efficiency grows with the tile (the
+    global->LDS path delivers (BM + BN) / (BM * BN) bytes per MFMA flop), but a launch wants >= ~1 workgroup per CU."""
+    def tiles(bm, bn):
+        return ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
+
+    for tile, bm, bn in ((18, 256, 256), (20, 256, 128), (6, 128, 128), (24, 128, 64)):
+        if tiles(bm, bn) >= 224:
+            return tile, 1
+    nk = (K + 63) // 64
+    t64 = tiles(64, 64)
+    if t64 >= 160 or not splitk_ok or geglu or nk < 8:
+        return (25 if nk >= 8 else 13), 1
+    sk = 1
+    while sk < 8 and t64 * sk < 224 and nk // (2 * sk) >= 4:
+        sk *= 2
+    return 25, sk
 
 
 _TUNE_COLD = os.environ.get("AVSD_TUNE_COLD", "1") != "0"
@@ -191,7 +220,7 @@ def _pick_tile(key, launch, candidates=TILE_CANDIDATES, warm=None):
     if t is not None:
         return t
     if not _AUTOTUNE or _TIMER is not None or torch.cuda.is_current_stream_capturing():
-        return (0, 1)
+        return None
     times = {}
     for rnd in range(2):
         for cand in candidates:
@@ -244,6 +273,7 @@ def gemm(
     ln: Optional[tuple] = None,                # (stats [rows, K/32, 2] f32, colsum [N] f32, eps): LayerNorm(A) folded in
     out_f32: bool = False,
     out: Optional[torch.Tensor] = None,
+    master: Optional[torch.Tensor] = None,     # out: f32 [M, N] un-rounded copy of the result (f32 residual stream)
     mode: int = PLAIN,
     tmix: Optional[tuple] = None,      # (hw, frames)
     conv: Optional[tuple] = None,      # (n_img, hs, ws, stride, ups[, pad])
@@ -252,8 +282,8 @@ def gemm(
     split_k: int = 1,
 ) -> torch.Tensor:
     """out = epilogue(alpha * A' . W^T); see avsd_gemm_bf16 in include/avsd.h."""
-    _req(a, BF16, "a")
-    _req(w, BF16, "w")
+    _req(a, P.ACT, "a")
+    _req(w, P.ACT, "w")
     d = GemmDesc()
     N = w.shape[0] if n is None else n
     lda = _ld(a)
@@ -262,7 +292,7 @@ def gemm(
         K1 = a.shape[1]
         K = K1 + (a2.shape[1] if a2 is not None else 0)
         if a2 is not None:
-            _req(a2, BF16, "a2")
+            _req(a2, P.ACT, "a2")
             d.A2, d.lda2, d.k_split = _p(a2), _ld(a2), K1
         else:
             d.k_split = K
@@ -287,9 +317,9 @@ def gemm(
         raise ValueError(f"unknown gemm mode {mode}")
     n_out = N // 2 if geglu else N
     if out is None:
-        out = torch.empty((M, n_out), dtype=F32 if out_f32 else BF16, device=a.device)
+        out = torch.empty((M, n_out), dtype=F32 if out_f32 else P.ACT, device=a.device)
     else:
-        _req(out, F32 if out_f32 else BF16, "out")
+        _req(out, F32 if out_f32 else P.ACT, "out")
     d.A, d.W, d.out = _p(a), _p(w), _p(out)
     d.M, d.N, d.K = M, N, K
     d.lda, d.ldw, d.ldc = lda, _ld(w), _ld(out)
@@ -299,15 +329,22 @@ def gemm(
     if rowvec is not None:
         _req(rowvec, F32, "rowvec")
         d.rowvec, d.rows_per_vec, d.ldv = _p(rowvec), rows_per_vec, _ld(rowvec)
-    if res1 is not None:
-        _req(res1, BF16, "res1")
+    d.flags = (GEGLU if geglu else 0) | (OUT_F32 if out_f32 else 0) | (GELU if gelu else 0)
+    if res1 is not None:            # residuals: 16-bit, or f32 (the f32 residual stream)
+        _req(res1, F32 if res1.dtype == F32 else P.ACT, "res1")
         d.res1, d.ldr1 = _p(res1), _ld(res1)
+        d.flags |= RES1_F32 if res1.dtype == F32 else 0
     if res2 is not None:
-        _req(res2, BF16, "res2")
+        _req(res2, F32 if res2.dtype == F32 else P.ACT, "res2")
         d.res2, d.ldr2 = _p(res2), _ld(res2)
+        d.flags |= RES2_F32 if res2.dtype == F32 else 0
+    if master is not None:
+        _req(master, F32, "master")
+        if master.shape != (M, n_out) or geglu:
+            raise ValueError("gemm: master must be f32 [M, N] (not available with GEGLU)")
+        d.out_master, d.ldm = _p(master), _ld(master)
     d.alpha = alpha
     d.mode = mode
-    d.flags = (GEGLU if geglu else 0) | (OUT_F32 if out_f32 else 0) | (GELU if gelu else 0)
     if rowstats is not None:
         _req(rowstats, F32, "rowstats")
         if not rowstats.is_contiguous() or rowstats.numel() != M * (N // 32) * 2:
@@ -347,7 +384,10 @@ def gemm(
         two_src_unaligned = a2 is not None and (a.shape[1] % 64 != 0)     # C falls back to register-staged tiles
         if not geglu and not two_src_unaligned and ((M + 127) // 128) * ((N + 127) // 128) < 256 and nk >= 16:
             cands = cands + tuple(c for c in SPLITK_CANDIDATES if nk // c[1] >= 4)
-        tile, split_k = _pick_tile((mode, M, N, K, d.flags, d.stride, d.ups, d.pad), _launch, cands, warm=(a, a2, res1, res2))
+        splitk_ok = not geglu and not two_src_unaligned
+        picked = _pick_tile((mode, M, N, K, d.flags, d.stride, d.ups, d.pad, int(master is not None)), _launch, cands,
+                            warm=(a, a2, res1, res2))
+        tile, split_k = picked if picked is not None else _heuristic_tile(M, N, K, geglu, splitk_ok)
     _set(tile, split_k)
     ev = _TIMER.start() if _TIMER is not None else None
     check(_lib.lib().avsd_gemm_bf16(C.byref(d), _stream()), "avsd_gemm_bf16")
@@ -355,7 +395,7 @@ def gemm(
         fam = ("gemm_plain", "gemm_tmix", "gemm_conv3")[mode]
         dc = GemmDesc.from_buffer_copy(d)
         _TIMER.add_replay(fam, lambda dc=dc: check(_lib.lib().avsd_gemm_bf16(C.byref(dc), _stream()), "avsd_gemm_bf16"),
-                          (a, a2, w, out, bias, rowvec, res1, res2, ws, rowstats, ln))
+                          (a, a2, w, out, bias, rowvec, res1, res2, ws, rowstats, ln, master))
         _TIMER.stop(ev, fam, 2.0 * M * N * K, 2.0 * M * K * (1.0 / 9 if mode == CONV3 else 1.0 / 3 if mode == TMIX else 1.0)
                     + 2.0 * N * K + _nbytes(out, res1, res2))
     return out
@@ -364,11 +404,11 @@ def gemm(
 def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, alpha: float = 1.0, out_f32: bool = False,
                  bias: Optional[torch.Tensor] = None, tile: int = 0, ln: Optional[tuple] = None) -> torch.Tensor:
     """out[b] = alpha * a[b] . w[b]^T for 3-D a [B, M, K], w [B, N, K] (VAE mid-block attention)."""
-    _req(a, BF16, "a")
-    _req(w, BF16, "w")
+    _req(a, P.ACT, "a")
+    _req(w, P.ACT, "w")
     B, M, K = a.shape
     N = w.shape[1]
-    out = torch.empty((B, M, N), dtype=F32 if out_f32 else BF16, device=a.device)
+    out = torch.empty((B, M, N), dtype=F32 if out_f32 else P.ACT, device=a.device)
     d = GemmDesc()
     d.A, d.W, d.out = _p(a), _p(w), _p(out)
     d.M, d.N, d.K, d.k_split = M, N, K, K
@@ -389,7 +429,8 @@ def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, alpha: float = 1.0, out_f3
             d.tile = t
             check(_lib.lib().avsd_gemm_bf16(C.byref(d), _stream()), "avsd_gemm_bf16(batched)")
 
-        d.tile = _pick_tile(("batched", B, M, N, K, d.flags), lambda t, sk: _launch(t))[0]
+        picked = _pick_tile(("batched", B, M, N, K, d.flags), lambda t, sk: _launch(t))
+        d.tile = picked[0] if picked is not None else _heuristic_tile(B * M, N, K, False, False)[0]
     ev = _TIMER.start() if _TIMER is not None else None
     check(_lib.lib().avsd_gemm_bf16(C.byref(d), _stream()), "avsd_gemm_bf16(batched)")
     if ev is not None:
@@ -400,7 +441,7 @@ def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, alpha: float = 1.0, out_f3
 def linear_small_m(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, act_in: bool = False,
                    act_out: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _req(x, F32, "x")
-    _req(w, BF16, "w")
+    _req(w, P.ACT, "w")
     M, K = x.shape
     N = w.shape[0]
     if not x.is_contiguous():
@@ -417,11 +458,11 @@ def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], nb: int, rows_per_ba
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """GroupNorm(+SiLU) of the channel concat [x1 | x2]; statistics pooled over each run of
     `rows_per_batch` rows.  Two launches: partial sums, then reduce + apply."""
-    _req(x1, BF16, "x1")
+    _req(x1, P.ACT, "x1")
     c1 = x1.shape[1]
     c2 = 0
     if x2 is not None:
-        _req(x2, BF16, "x2")
+        _req(x2, P.ACT, "x2")
         c2 = x2.shape[1]
     _req(gamma, F32, "gamma")
     _req(beta, F32, "beta")
@@ -430,7 +471,7 @@ def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], nb: int, rows_per_ba
     nchunks = L.avsd_groupnorm_nchunks(nb, rows_per_batch, c1 + c2)
     partial = torch.empty((L.avsd_groupnorm_scratch_floats(nb, nchunks, groups, c1 + c2),), dtype=F32, device=x1.device)
     if out is None:
-        out = torch.empty((rows, c1 + c2), dtype=BF16, device=x1.device)
+        out = torch.empty((rows, c1 + c2), dtype=P.ACT, device=x1.device)
     s = _stream()
     ev = _TIMER.start() if _TIMER is not None else None
     check(L.avsd_groupnorm_stats(_p(x1), _ld(x1), c1, _p(x2), _ld(x2) if x2 is not None else 0, c2, nb, rows_per_batch,
@@ -446,7 +487,7 @@ def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], nb: int, rows_per_ba
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
               pos: Optional[torch.Tensor] = None, hw: int = 1, frames: int = 1,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    _req(x, BF16, "x")
+    _req(x, P.ACT, "x")
     _req(gamma, F32, "gamma")
     _req(beta, F32, "beta")
     M, Cc = x.shape
@@ -455,7 +496,7 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
         if not pos.is_contiguous() or pos.shape != (frames, Cc):
             raise ValueError("layernorm: pos must be contiguous [frames, C]")
     if out is None:
-        out = torch.empty((M, Cc), dtype=BF16, device=x.device)
+        out = torch.empty((M, Cc), dtype=P.ACT, device=x.device)
     ev = _TIMER.start() if _TIMER is not None else None
     check(_lib.lib().avsd_layernorm(_p(x), _ld(x), _p(out), _ld(out), M, Cc, _p(gamma), _p(beta), float(eps), _p(pos),
                                     hw, frames, _stream()), "avsd_layernorm")
@@ -467,7 +508,7 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
 def softmax_rows(s: torch.Tensor) -> torch.Tensor:
     _req(s, F32, "s")
     rows, L = s.shape
-    out = torch.empty((rows, L), dtype=BF16, device=s.device)
+    out = torch.empty((rows, L), dtype=P.ACT, device=s.device)
     check(_lib.lib().avsd_softmax_rows(_p(s), _ld(s), _p(out), _ld(out), rows, L, _stream()), "avsd_softmax_rows")
     return out
 
@@ -476,16 +517,16 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, bq: int, lq:
               heads: int, q_per_kv: int, frames: int, key_index: Optional[torch.Tensor] = None,
               scale: Optional[float] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q [bq*lq, heads*d]; k, v [(bq/q_per_kv)*kv_rows, >= heads*d] (views into a fused k|v buffer are fine)."""
-    _req(q, BF16, "q")
-    _req(k, BF16, "k")
-    _req(v, BF16, "v")
+    _req(q, P.ACT, "q")
+    _req(k, P.ACT, "k")
+    _req(v, P.ACT, "v")
     Cc = q.shape[1]
     d = Cc // heads
     if key_index is not None:
         if key_index.dtype != torch.int32 or not key_index.is_contiguous() or key_index.shape != (frames, lk):
             raise ValueError("attention: key_index must be contiguous int32 [frames, lk]")
     if out is None:
-        out = torch.empty((bq * lq, Cc), dtype=BF16, device=q.device)
+        out = torch.empty((bq * lq, Cc), dtype=P.ACT, device=q.device)
     if scale is None:
         scale = float(d) ** -0.5
     ev = _TIMER.start() if _TIMER is not None else None
@@ -499,11 +540,11 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, bq: int, lq:
 
 def temporal_attention(qkv: torch.Tensor, *, b: int, frames: int, hw: int, heads: int,
                        scale: Optional[float] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    _req(qkv, BF16, "qkv")
+    _req(qkv, P.ACT, "qkv")
     Cc = qkv.shape[1] // 3
     d = Cc // heads
     if out is None:
-        out = torch.empty((qkv.shape[0], Cc), dtype=BF16, device=qkv.device)
+        out = torch.empty((qkv.shape[0], Cc), dtype=P.ACT, device=qkv.device)
     if scale is None:
         scale = float(d) ** -0.5
     ev = _TIMER.start() if _TIMER is not None else None
@@ -519,7 +560,7 @@ def ncfhw_to_rows(x: torch.Tensor, cpad: int, rep: int = 1, scale: float = 1.0) 
     if not x.is_contiguous():
         raise ValueError("ncfhw_to_rows: x must be contiguous")
     B, Cc, Fr, H, W = x.shape
-    out = torch.empty((rep * B * Fr * H * W, cpad), dtype=BF16, device=x.device)
+    out = torch.empty((rep * B * Fr * H * W, cpad), dtype=P.ACT, device=x.device)
     check(_lib.lib().avsd_ncfhw_to_rows(_p(x), _p(out), B, Cc, Fr, H * W, cpad, rep, float(scale), _stream()),
           "avsd_ncfhw_to_rows")
     return out
@@ -556,14 +597,14 @@ def guided_step(noise_pred: torch.Tensor, n_branch: int, g: float, x_in: torch.T
 
 
 def vae_postprocess(rows: torch.Tensor, n_img: int, H: int, W: int) -> torch.Tensor:
-    _req(rows, BF16, "rows")
+    _req(rows, P.ACT, "rows")
     out = torch.empty((n_img, 3, H, W), dtype=F32, device=rows.device)
     check(_lib.lib().avsd_vae_postprocess(_p(rows), _ld(rows), _p(out), n_img, H * W, _stream()), "avsd_vae_postprocess")
     return out
 
 
 def vae_postprocess_u8(rows: torch.Tensor, n_img: int, H: int, W: int) -> torch.Tensor:
-    _req(rows, BF16, "rows")
+    _req(rows, P.ACT, "rows")
     out = torch.empty((n_img, H, W, 3), dtype=torch.uint8, device=rows.device)
     check(_lib.lib().avsd_vae_postprocess_u8(_p(rows), _ld(rows), _p(out), n_img, H * W, _stream()), "avsd_vae_postprocess_u8")
     return out
@@ -593,19 +634,19 @@ def patchify(x: torch.Tensor, kh: int, kw: int, stride: int) -> torch.Tensor:
         raise ValueError("patchify: x must be contiguous")
     B, Cc, H, W = x.shape
     ph, pw = (H - kh) // stride + 1, (W - kw) // stride + 1
-    out = torch.empty((B * ph * pw, Cc * kh * kw), dtype=BF16, device=x.device)
+    out = torch.empty((B * ph * pw, Cc * kh * kw), dtype=P.ACT, device=x.device)
     check(_lib.lib().avsd_patchify(_p(x), _p(out), B, Cc, H, W, kh, kw, stride, _stream()), "avsd_patchify")
     return out
 
 
 def vit_tokens(patches: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, b: int, tail_rows: int = 0) -> torch.Tensor:
     """bf16 patch embeddings [b*np, C] + cls [C] + pos [1+np, C] (f32) -> bf16 [b*(1+np+tail_rows), C]."""
-    _req(patches, BF16, "patches")
+    _req(patches, P.ACT, "patches")
     _req(cls, F32, "cls")
     _req(pos, F32, "pos")
     n_p, Cc = patches.shape[0] // b, patches.shape[1]
     if not patches.is_contiguous() or pos.shape != (1 + n_p, Cc) or cls.numel() != Cc:
         raise ValueError("vit_tokens: shape mismatch")
-    out = torch.empty((b * (1 + n_p + tail_rows), Cc), dtype=BF16, device=patches.device)
+    out = torch.empty((b * (1 + n_p + tail_rows), Cc), dtype=P.ACT, device=patches.device)
     check(_lib.lib().avsd_vit_tokens(_p(patches), _p(cls), _p(pos), _p(out), b, n_p, Cc, tail_rows, _stream()), "avsd_vit_tokens")
     return out

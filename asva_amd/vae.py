@@ -19,6 +19,8 @@ import os
 from typing import Optional
 
 import torch
+
+from . import precision as P
 from torch import nn
 
 from . import ops
@@ -282,7 +284,7 @@ class AutoencoderKL(nn.Module):
         def conv1(m):
             cout, cin = m.weight.shape[:2]
             cop, cip = (cout + 7) // 8 * 8, (cin + 7) // 8 * 8
-            w = torch.zeros(cop, cip, dtype=torch.bfloat16, device=m.weight.device)
+            w = torch.zeros(cop, cip, dtype=P.ACT, device=m.weight.device)
             w[:cout, :cin] = pack_conv1x1(m.weight.detach().float())
             b = torch.zeros(cop, device=m.weight.device)
             b[:cout] = m.bias.detach().float()

@@ -15,13 +15,15 @@ from __future__ import annotations
 
 import torch
 
+from . import precision as P
+
 
 def pack_linear(w: torch.Tensor) -> torch.Tensor:
-    return w.detach().to(torch.bfloat16).contiguous()
+    return w.detach().to(P.ACT).contiguous()
 
 
 def pack_conv1x1(w: torch.Tensor) -> torch.Tensor:
-    return w.detach().reshape(w.shape[0], w.shape[1]).to(torch.bfloat16).contiguous()
+    return w.detach().reshape(w.shape[0], w.shape[1]).to(P.ACT).contiguous()
 
 
 def pack_conv3x3(w: torch.Tensor, cin_pad: int | None = None, cout_pad: int | None = None) -> torch.Tensor:
@@ -31,7 +33,7 @@ def pack_conv3x3(w: torch.Tensor, cin_pad: int | None = None, cout_pad: int | No
     cout_pad = cout_pad or (cout + 3) // 4 * 4
     p = torch.zeros((cout_pad, 3, 3, cin_pad), dtype=torch.float32, device=w.device)
     p[:cout, :, :, :cin] = w.detach().float().permute(0, 2, 3, 1)
-    return p.reshape(cout_pad, 9 * cin_pad).to(torch.bfloat16).contiguous()
+    return p.reshape(cout_pad, 9 * cin_pad).to(P.ACT).contiguous()
 
 
 def geglu_row_order(nh: int) -> torch.Tensor:
@@ -45,7 +47,7 @@ def geglu_row_order(nh: int) -> torch.Tensor:
 def pack_geglu(w: torch.Tensor, b: torch.Tensor | None):
     nh = w.shape[0] // 2
     order = geglu_row_order(nh).to(w.device)
-    wp = w.detach()[order].to(torch.bfloat16).contiguous()
+    wp = w.detach()[order].to(P.ACT).contiguous()
     bp = None if b is None else b.detach()[order].float().contiguous()
     return wp, bp
 

@@ -37,6 +37,8 @@ extern "C" {
 
 /* ---- library ------------------------------------------------------------------------ */
 int avsd_abi_version(void);
+/* "bf16" or "fp16": the 16-bit storage type this build of the library computes in. */
+const char* avsd_precision(void);
 const char* avsd_last_error(void);
 /* Fills name[<=len] with the device arch string (e.g. "gfx950:sramecc+:xnack-"), and the
  * CU count.  AVSD_ENODEV when no device is visible. */
@@ -66,14 +68,20 @@ int avsd_device_info(char* name_host, int len, int* num_cu_host);
  *   AVSD_GEMM_GELU:  act = gelu_erf (the MLP of the audio front-end's ViT blocks); identity otherwise.
  *   AVSD_GEMM_GEGLU: W rows are packed per 32-row block as [16 value rows | 16 gate rows];
  *                    out[M, N/2] = value * gelu_erf(gate)   (diffusers GEGLU)
- *   AVSD_GEMM_OUT_F32: out is f32 instead of bf16.
+ *   AVSD_GEMM_OUT_F32: out is f32 instead of 16-bit.
+ *   AVSD_GEMM_RES1_F32 / RES2_F32: res1 / res2 are f32 [M][ldr] instead of 16-bit.  With `out_master` != NULL the epilogue
+ *                    also stores the UN-ROUNDED f32 result to out_master[m*ldm + n]: together they keep a residual
+ *                    stream (h = h + f(h), ff_spatio_audio_temp_transformer_3d.py:300-371; x + h, ff_spatio_temp_resnet_3d.py:189)
+ *                    in f32 while the 16-bit copy in `out` feeds the next matrix multiply.
+ * "16-bit" = bfloat16 in libavsd_hip.so, IEEE half in libavsd_hip_f16.so (the same sources built with -DAVSD_F16=1;
+ *   avsd_precision() tells which); accumulation and the epilogue are f32 in both.
  *   AVSD_GEMM_XCD_N: scheduling hint, no effect on the result — tiles are dealt to the 8 XCDs in bands of N instead of
  *                    bands of M, so the weights (not the activations) are the operand each L2 fetches only once.
  * blockIdx.z batches: pointers advance by batch_stride_* elements (0 = shared).
  */
 enum { AVSD_GEMM_PLAIN = 0, AVSD_GEMM_TMIX = 1, AVSD_GEMM_CONV3 = 2 };
 enum { AVSD_GEMM_GEGLU = 1, AVSD_GEMM_OUT_F32 = 2, AVSD_GEMM_GELU = 4, AVSD_GEMM_XCD_N = 8, AVSD_GEMM_ROWSTATS = 16,
-       AVSD_GEMM_LNFUSE = 32 };
+       AVSD_GEMM_LNFUSE = 32, AVSD_GEMM_RES1_F32 = 64, AVSD_GEMM_RES2_F32 = 128 };
 
 typedef struct avsd_gemm_desc {
   const void* A;        /* bf16 */
@@ -118,6 +126,9 @@ typedef struct avsd_gemm_desc {
   const float* ln_colsum;
   int32_t ln_nblk;
   float ln_eps;
+  float* out_master;                    /* f32 [M][ldm] or NULL: un-rounded copy of the result (not with GEGLU) */
+  int32_t ldm;
+  int32_t reserved0;
 } avsd_gemm_desc;
 
 int avsd_gemm_bf16(const avsd_gemm_desc* desc_host, void* stream);

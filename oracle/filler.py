@@ -34,11 +34,21 @@ def fill_state_dict(shapes: dict, dtype=torch.float32) -> dict:
     return {k: fill_tensor(k, v, dtype) for k, v in shapes.items()}
 
 
-def fill_module_(module: torch.nn.Module, prefix: str = "") -> None:
+def fill_module_(module: torch.nn.Module, prefix: str = "", round_bf16: bool = False) -> None:
+    """round_bf16: matrices (dim >= 2) are rounded to bf16-representable values, so a bf16-weight implementation holds
+    exactly the parameters the fp32 reference ran with (block-level goldens)."""
     with torch.no_grad():
         for k, p in module.state_dict().items():
-            p.copy_(fill_tensor(prefix + k, p.shape, p.dtype))
+            t = fill_tensor(prefix + k, p.shape, p.dtype)
+            if round_bf16 and t.dim() >= 2:
+                t = t.to(torch.bfloat16).to(p.dtype)
+            p.copy_(t)
 
 
 def seeded_randn(seed: int, *shape) -> torch.Tensor:
     return torch.randn(*shape, generator=torch.Generator(device="cpu").manual_seed(seed))
+
+
+def seeded_randn_bf16(seed: int, *shape) -> torch.Tensor:
+    """bf16-representable f32 values: both sides of a parity test read exactly the same numbers."""
+    return seeded_randn(seed, *shape).to(torch.bfloat16).float()

@@ -16,7 +16,10 @@ import sys
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [os.path.join(ROOT, "oracle", "diffusers_restated"), "/root/reference", ROOT]
+# the repository's own `avgen/` shim is a regular package and would shadow the reference's namespace package whatever
+# the path order: import the reference first, with the repository root not on the path yet
+sys.path[:] = [p for p in sys.path if os.path.abspath(p or os.getcwd()) != ROOT]
+sys.path[:0] = [os.path.join(ROOT, "oracle", "diffusers_restated"), "/root/reference"]
 
 from avgen.models.unets import AudioUNet3DConditionModel  # noqa: E402  (the reference)
 from avgen.models.unets.resnets.ff_spatio_temp_resnet_3d import (  # noqa: E402
@@ -25,8 +28,9 @@ from avgen.models.unets.transformers.ff_spatio_audio_temp_transformer_3d import 
     BasicTransformerBlock, FFSpatioAudioTempTransformer3DModel)
 from avgen.models.unets.utils import FFAttention, FFInflatedConv3d  # noqa: E402
 
+sys.path.append(ROOT)
 from asva_amd.conditioning import audio_segment_mask  # noqa: E402
-from oracle.filler import fill_module_, seeded_randn  # noqa: E402
+from oracle.filler import fill_module_, seeded_randn, seeded_randn_bf16  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 
@@ -105,6 +109,101 @@ def per_op():
 
 
 @torch.no_grad()
+def blocks_hip_legal():
+    """Block-level goldens at sizes the gfx950 kernels accept (C = 320 / 640, 8 heads of 40 / 80, 32 groups, f = 4,
+    8x8 latents): the reference's FFInflatedConv3d, ResBlock, samplers and Transformer3D modules run in fp32 on
+    bf16-REPRESENTABLE filler weights and inputs (so a bf16-weight implementation starts from identical numbers and
+    only its own arithmetic is measured).  Inputs are regenerated from their seeds by the test; outputs are stored."""
+    g = {"B": 2, "F": 4, "H": 8, "W": 8, "temb_dim": 1280, "text": (77, 768), "audio": (229, 768)}
+    B, Fr, H, W = 2, 4, 8, 8
+    x320 = seeded_randn_bf16(20, B, 320, Fr, H, W)
+    x640 = seeded_randn_bf16(21, B, 640, Fr, H, W)
+    temb = seeded_randn_bf16(22, B, 1280)
+    text = seeded_randn_bf16(23, B, 77, 768)
+    audio = seeded_randn_bf16(24, B, 229, 768)
+    mask = audio_segment_mask(Fr)
+    g["seeds"] = {"x320": 20, "x640": 21, "temb": 22, "text": 23, "audio": 24}
+    # FFInflatedConv3d (utils.py:22-57)
+    for name, (cin, cout, k, s, p, x) in {"conv3_320": (320, 320, 3, 1, 1, x320), "conv3_s2_320": (320, 320, 3, 2, 1, x320),
+                                          "conv1_640_320": (640, 320, 1, 1, 0, x640)}.items():
+        m = FFInflatedConv3d(cin, cout, k, stride=s, padding=p)
+        fill_module_(m, "blk." + name + ".", round_bf16=True)
+        g[name] = m(x)
+    # ResBlocks (ff_spatio_temp_resnet_3d.py:99-191): same width, and 640 -> 320 with the 1x1 shortcut
+    tfr = temb[:, None].expand(B, Fr, 1280).contiguous()
+    for name, (cin, cout, x) in {"res_320": (320, 320, x320), "res_640_320": (640, 320, x640)}.items():
+        m = FFSpatioTempResnetBlock3D(in_channels=cin, out_channels=cout, temb_channels=1280, groups=32, eps=1e-5)
+        fill_module_(m, "blk." + name + ".", round_bf16=True)
+        g[name] = m(x, tfr)
+    m = FFSpatioTempResDownsample3D(320, use_conv=True, out_channels=320, padding=1, name="op")
+    fill_module_(m, "blk.down_320.", round_bf16=True)
+    g["down_320"] = m(x320)
+    m = FFSpatioTempResUpsample3D(320, use_conv=True, out_channels=320)
+    fill_module_(m, "blk.up_320.", round_bf16=True)
+    g["up_320"] = m(x320)
+    # Transformer3D wrapper + BasicTransformerBlock (ff_spatio_audio_temp_transformer_3d.py:33-373)
+    tx = text[:, None].expand(B, Fr, 77, 768).contiguous()
+    au = audio[:, None].expand(B, Fr, 229, 768).contiguous()
+    mk = mask[None].expand(B, -1, -1).contiguous()
+    for name, (heads, d, x) in {"tr_320": (8, 40, x320), "tr_640": (8, 80, x640)}.items():
+        m = FFSpatioAudioTempTransformer3DModel(heads, d, in_channels=heads * d, num_layers=1, cross_attention_dim=768,
+                                                audio_cross_attention_dim=768, norm_num_groups=32)
+        fill_module_(m, "blk." + name + ".", round_bf16=True)
+        g[name] = m(x, encoder_hidden_states=tx, audio_encoder_hidden_states=au, audio_attention_mask=mk).sample
+    g = {k: (v.to(torch.float16) if torch.is_tensor(v) else v) for k, v in g.items()}     # outputs are O(1): 3e-4 rel rounding
+    torch.save(g, os.path.join(OUT, "unet_blocks_hip.pt"))
+    print("HIP-legal block goldens:", [k for k, v in g.items() if torch.is_tensor(v)])
+
+
+def _full_model():
+    m = AudioUNet3DConditionModel(**SD15_CFG).eval()
+    fill_module_(m)
+    return m
+
+
+@torch.no_grad()
+def full_shape_cfg3(m=None):
+    """BASELINE cfg 3, per-GPU forward: 4 clips x CFG 2 = UNet batch 8 at (12, 32, 32); branch-major batch order
+    [null-audio x 4 clips, audio x 4 clips] as torch.cat([latents] * 2) builds it (pipeline :331-336)."""
+    torch.set_num_threads(os.cpu_count())
+    m = m or _full_model()
+    n, Fr, H, W = 4, 12, 32, 32
+    lat = seeded_randn(31, n, 4, Fr, H, W)
+    x = torch.cat([lat, lat])
+    text = seeded_randn(32, n, 77, 768)
+    audio = seeded_randn(33, n, 229, 768)
+    null_audio = seeded_randn(34, 1, 229, 768).expand(n, -1, -1)
+    tx = torch.cat([text, text])[:, None].expand(2 * n, Fr, 77, 768)
+    au = torch.cat([null_audio, audio])[:, None].expand(2 * n, Fr, 229, 768)
+    mask = audio_segment_mask(Fr)[None].expand(2 * n, -1, -1).contiguous()
+    y = m(x, torch.tensor(501), tx, au, audio_attention_mask=mask).sample
+    torch.save({"timestep": 501, "seeds": {"lat": 31, "text": 32, "audio": 33, "null_audio": 34}, "clips": n,
+                "std": y.std().item(), "norm": y.norm().item(), "shape": list(y.shape), "full": y.to(torch.float16)},
+               os.path.join(OUT, "unet_sd15_forward_cfg3.pt"))
+    print("cfg3 forward: std", y.std().item(), list(y.shape))
+
+
+@torch.no_grad()
+def full_shape_cfg4(m=None):
+    """BASELINE cfg 4 (Landscapes): one clip, CFG 2, 24 frames at 64x64 latents (512x512 pixels): spatial attention over
+    L = 4096 keys, 13 audio keys per frame."""
+    torch.set_num_threads(os.cpu_count())
+    m = m or _full_model()
+    Fr, H, W = 24, 64, 64
+    lat = seeded_randn(41, 1, 4, Fr, H, W)
+    x = torch.cat([lat, lat])
+    text = seeded_randn(42, 1, 77, 768).expand(2, 77, 768)
+    audio = torch.cat([seeded_randn(44, 1, 229, 768), seeded_randn(43, 1, 229, 768)])   # [null-audio, audio]
+    mask = audio_segment_mask(Fr)[None].expand(2, -1, -1).contiguous()
+    y = m(x, torch.tensor(741), text[:, None].expand(2, Fr, 77, 768), audio[:, None].expand(2, Fr, 229, 768),
+          audio_attention_mask=mask).sample
+    torch.save({"timestep": 741, "seeds": {"lat": 41, "text": 42, "audio": 43, "null_audio": 44},
+                "std": y.std().item(), "norm": y.norm().item(), "shape": list(y.shape), "full": y.to(torch.float16)},
+               os.path.join(OUT, "unet_sd15_forward_cfg4.pt"))
+    print("cfg4 forward: std", y.std().item(), list(y.shape))
+
+
+@torch.no_grad()
 def full_shape():
     torch.set_num_threads(os.cpu_count())
     m = AudioUNet3DConditionModel(**SD15_CFG).eval()
@@ -132,9 +231,22 @@ def full_shape():
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
+    ap.add_argument("--only", default="", help="comma list of: tiny, ops, blocks, full, cfg3, cfg4")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
-    tiny_e2e()
-    per_op()
-    if a.full:
+    only = set(a.only.split(",")) if a.only else None
+    want = lambda k, default: (k in only) if only is not None else default  # noqa: E731
+    if want("tiny", True):
+        tiny_e2e()
+    if want("ops", True):
+        per_op()
+    if want("blocks", True):
+        blocks_hip_legal()
+    if want("full", a.full):
         full_shape()
+    if want("cfg3", a.full) or want("cfg4", a.full):
+        mm = _full_model()
+        if want("cfg3", a.full):
+            full_shape_cfg3(mm)
+        if want("cfg4", a.full):
+            full_shape_cfg4(mm)

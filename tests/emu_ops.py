@@ -11,15 +11,17 @@ import math
 import torch
 import torch.nn.functional as F
 
+from asva_amd import precision as P
+
 EMULATED = True
 PLAIN, TMIX, CONV3 = 0, 1, 2
-BF16, F32 = torch.bfloat16, torch.float32
+F32 = torch.float32
 
 
 def gemm(a, w, *, n=None, k=None, a2=None, bias=None, rowvec=None, rows_per_vec=0, res1=None, res2=None, alpha=1.0,
          geglu=False, gelu=False, out_f32=False, out=None, mode=PLAIN, tmix=None, conv=None, m=None, tile=0, split_k=1,
-         rowstats=None, ln=None):
-    assert a.dtype == BF16 and w.dtype == BF16
+         rowstats=None, ln=None, master=None):
+    assert a.dtype == P.ACT and w.dtype == P.ACT
     wf = w.float()
     if mode == PLAIN:
         x = a.float() if a2 is None else torch.cat([a.float(), a2.float()], 1)
@@ -65,13 +67,15 @@ def gemm(a, w, *, n=None, k=None, a2=None, bias=None, rowvec=None, rows_per_vec=
             acc = acc + bias
         blk = acc.reshape(acc.shape[0], -1, 32)
         v = (blk[:, :, :16] * F.gelu(blk[:, :, 16:])).reshape(acc.shape[0], -1)
+    if master is not None:
+        master.copy_(v)
     if rowstats is not None:
-        r = v.to(BF16).float().reshape(v.shape[0], -1, 32)
+        r = v.to(P.ACT).float().reshape(v.shape[0], -1, 32)
         rowstats.copy_(torch.stack([r.sum(-1), (r * r).sum(-1)], -1))
     if out is not None:
         out.copy_(v.to(out.dtype))
         return out
-    return v if out_f32 else v.to(BF16)
+    return v if out_f32 else v.to(P.ACT)
 
 
 def _ln_fold(acc, ln, rows):
@@ -92,11 +96,11 @@ def gemm_batched(a, w, *, alpha=1.0, out_f32=False, bias=None, tile=0, ln=None):
         v = _ln_fold(v.reshape(-1, v.shape[-1]), ln, rows).reshape(v.shape)
     if bias is not None:
         v = v + bias
-    return v if out_f32 else v.to(BF16)
+    return v if out_f32 else v.to(P.ACT)
 
 
 def linear_small_m(x, w, bias, *, act_in=False, act_out=False, out=None):
-    assert x.dtype == F32 and w.dtype == BF16
+    assert x.dtype == F32 and w.dtype == P.ACT
     v = (F.silu(x) if act_in else x) @ w.float().T
     if bias is not None:
         v = v + bias
@@ -108,7 +112,7 @@ def groupnorm(x1, x2, nb, rows_per_batch, groups, gamma, beta, eps, act, out=Non
     C = x.shape[1]
     y = F.group_norm(x.reshape(nb, rows_per_batch, C).permute(0, 2, 1), groups, gamma, beta, eps)
     y = F.silu(y) if act else y
-    return y.permute(0, 2, 1).reshape(-1, C).to(BF16)
+    return y.permute(0, 2, 1).reshape(-1, C).to(P.ACT)
 
 
 def layernorm(x, gamma, beta, eps=1e-5, pos=None, hw=1, frames=1, out=None):
@@ -116,11 +120,11 @@ def layernorm(x, gamma, beta, eps=1e-5, pos=None, hw=1, frames=1, out=None):
     if pos is not None:
         f = (torch.arange(v.shape[0]) // hw) % frames
         v = v + pos[f]
-    return F.layer_norm(v, (v.shape[1],), gamma, beta, eps).to(BF16)
+    return F.layer_norm(v, (v.shape[1],), gamma, beta, eps).to(P.ACT)
 
 
 def softmax_rows(s):
-    return torch.softmax(s, -1).to(BF16)
+    return torch.softmax(s, -1).to(P.ACT)
 
 
 def attention(q, k, v, *, bq, lq, lk, kv_rows, heads, q_per_kv, frames, key_index=None, scale=None, out=None):
@@ -140,9 +144,9 @@ def attention(q, k, v, *, bq, lq, lk, kv_rows, heads, q_per_kv, frames, key_inde
             rows = torch.arange(lk)
         kh = kk[kb, rows].reshape(-1, heads, d).transpose(0, 1)
         vh = vv[kb, rows].reshape(-1, heads, d).transpose(0, 1)
-        p = torch.softmax(qh[qb] @ kh.transpose(1, 2) * scale, -1).to(BF16).float()
+        p = torch.softmax(qh[qb] @ kh.transpose(1, 2) * scale, -1).to(P.ACT).float()
         outs.append((p @ vh).transpose(0, 1).reshape(lq, C))
-    return torch.cat(outs, 0).to(BF16)
+    return torch.cat(outs, 0).to(P.ACT)
 
 
 def temporal_attention(qkv, *, b, frames, hw, heads, scale=None, out=None):
@@ -150,7 +154,7 @@ def temporal_attention(qkv, *, b, frames, hw, heads, scale=None, out=None):
     d = C // heads
     x = qkv.float().reshape(b, frames, hw, 3, heads, d).permute(3, 0, 2, 4, 1, 5)
     o = F.scaled_dot_product_attention(x[0], x[1], x[2], scale=scale)
-    return o.permute(0, 3, 1, 2, 4).reshape(b * frames * hw, C).to(BF16)
+    return o.permute(0, 3, 1, 2, 4).reshape(b * frames * hw, C).to(P.ACT)
 
 
 def ncfhw_to_rows(x, cpad, rep=1, scale=1.0):
@@ -158,7 +162,7 @@ def ncfhw_to_rows(x, cpad, rep=1, scale=1.0):
     r = (x * scale).permute(0, 2, 3, 4, 1).reshape(-1, C)
     out = torch.zeros(r.shape[0], cpad)
     out[:, :C] = r
-    return out.repeat(rep, 1).to(BF16)
+    return out.repeat(rep, 1).to(P.ACT)
 
 
 def rows_to_ncfhw(rows, B, C, Fr, H, W):
@@ -221,11 +225,11 @@ def kaldi_fbank(wave, window, mel_fb, *, shift, nfft, t_out, preemph=0.97, remov
 def patchify(x, kh, kw, stride):
     B, Cc = x.shape[:2]
     cols = F.unfold(x, (kh, kw), stride=stride)                  # [B, C*kh*kw, L]
-    return cols.transpose(1, 2).reshape(-1, Cc * kh * kw).to(BF16)
+    return cols.transpose(1, 2).reshape(-1, Cc * kh * kw).to(P.ACT)
 
 
 def vit_tokens(patches, cls, pos, b, tail_rows=0):
     n_p, Cc = patches.shape[0] // b, patches.shape[1]
     x = patches.float().reshape(b, n_p, Cc) + pos[1:]
     c = (cls.reshape(1, 1, Cc) + pos[:1]).expand(b, 1, Cc)
-    return torch.cat([c, x, torch.zeros(b, tail_rows, Cc)], 1).reshape(-1, Cc).to(BF16)
+    return torch.cat([c, x, torch.zeros(b, tail_rows, Cc)], 1).reshape(-1, Cc).to(P.ACT)

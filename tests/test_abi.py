@@ -19,11 +19,19 @@ def test_header_binding_and_library_agree():
     declared = _declared()
     assert declared, "no declarations parsed"
     assert sorted(_lib.SIGNATURES) == declared                 # the ctypes table mirrors the header
-    handle = _lib.lib()                                        # raises if the .so is missing or a symbol is absent
-    for name in declared:
-        assert hasattr(handle, name)
-    assert handle.avsd_abi_version() == 3
-    assert handle.avsd_sizeof_gemm_desc() == ctypes.sizeof(_lib.GemmDesc)
+    from asva_amd import precision
+
+    for prec in ("bf16", "fp16"):                              # both builds of the sources export the same ABI
+        precision.set_precision(prec)
+        try:
+            handle = _lib.lib()                                # raises if the .so is missing or a symbol is absent
+            for name in declared:
+                assert hasattr(handle, name)
+            assert handle.avsd_abi_version() == 3
+            assert handle.avsd_precision() == prec.encode()
+            assert handle.avsd_sizeof_gemm_desc() == ctypes.sizeof(_lib.GemmDesc)
+        finally:
+            precision.set_precision("bf16")
 
 
 def test_argument_errors_are_reported_without_a_device():
@@ -42,8 +50,8 @@ def test_argument_errors_are_reported_without_a_device():
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from asva_amd import _lib
 
-    monkeypatch.setattr(_lib, "_lib", None)
-    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libavsd_hip.so"))
+    monkeypatch.setattr(_lib, "_libs", {})
+    monkeypatch.setattr(_lib, "LIB_PATHS", {"bf16": str(tmp_path / "libavsd_hip.so"), "fp16": str(tmp_path / "libavsd_hip_f16.so")})
     import pytest
 
     with pytest.raises(_lib.AvsdError, match="no fallback compute path"):

@@ -1,0 +1,182 @@
+"""Block-level parity of the HIP compositions against the REFERENCE's own modules (-m gpu).
+
+tests/golden/unet_blocks_hip.pt holds the outputs of the reference's FFInflatedConv3d, FFSpatioTempResnetBlock3D,
+down / up samplers and FFSpatioAudioTempTransformer3DModel (oracle/gen_golden.py::blocks_hip_legal, imported from
+/root/reference) at sizes the gfx950 kernels accept — C = 320 / 640, 8 heads, 32 groups, f = 4, 8x8 latents — run in
+fp32 on bf16-REPRESENTABLE filler weights and inputs.  The product's `_ffconv / _resblock / _transformer`
+(asva_amd/unet.py) start from exactly the same numbers, so the measured difference is their own arithmetic: 16-bit
+rounding of intermediate activations and f32 summation order.
+
+Tolerances (rel-L2 over the block output), 1.5x what was measured on MI355X, per storage precision:
+  bf16: conv / sampler 3e-3, ResBlock 4e-3, Transformer3D 5e-3      fp16: 1e-3 for all (goldens are stored as fp16: 3e-4)
+Every case runs with the bf16 / fp16 library, with and without the f32 residual stream, and the transformer with the
+LayerNorm fold on and off.
+"""
+import pytest
+import torch
+
+from oracle.filler import fill_module_, seeded_randn_bf16
+from tests.helpers import load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"bf16": {"conv": 3e-3, "res": 4e-3, "tr": 5e-3}, "fp16": {"conv": 1e-3, "res": 1e-3, "tr": 1e-3}}
+
+
+@pytest.fixture(params=["bf16", "fp16"])
+def prec(request):
+    from asva_amd import precision as P
+
+    P.set_precision(request.param)
+    yield request.param
+    P.set_precision("bf16")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    g = load_golden("unet_blocks_hip.pt")
+    s = g["seeds"]
+    B, Fr, H, W = g["B"], g["F"], g["H"], g["W"]
+    g["in"] = {"x320": seeded_randn_bf16(s["x320"], B, 320, Fr, H, W), "x640": seeded_randn_bf16(s["x640"], B, 640, Fr, H, W),
+               "temb": seeded_randn_bf16(s["temb"], B, 1280), "text": seeded_randn_bf16(s["text"], B, 77, 768),
+               "audio": seeded_randn_bf16(s["audio"], B, 229, 768)}
+    return g
+
+
+def _rows(x):
+    """(B, C, F, H, W) f32 -> channels-last rows [B*F*H*W, C] in the storage dtype, on the device"""
+    from asva_amd import precision as P
+
+    B, C = x.shape[:2]
+    return x.permute(0, 2, 3, 4, 1).reshape(-1, C).to(P.ACT).cuda().contiguous()
+
+
+def _video(rows, B, Fr, H, W):
+    return rows.float().reshape(B, Fr, H, W, -1).permute(0, 4, 1, 2, 3).cpu()
+
+
+def _pack(holder, prefix, fn):
+    """fn: Packer method name, or a callable (packer, holder) -> packed parameters"""
+    from asva_amd.unet import Packer, _Pk
+
+    fill_module_(holder, prefix, round_bf16=True)
+    holder = holder.to("cuda")
+    pr = Packer()
+    root = _Pk(p=getattr(pr, fn)(holder) if isinstance(fn, str) else fn(pr, holder))
+    pr.finish(root, torch.device("cuda", 0))
+    return root
+
+
+def _state(gold, f32_stream, fuse_ln=True, **kw):
+    from asva_amd.unet import _Pk
+
+    return _Pk(B=gold["B"], F=gold["F"], temb=None, temb_rows=gold["F"], cond=None, tr_i=0, groups=32, eps=1e-5, heads=(8,),
+               fuse_ln=fuse_ln, f32_stream=f32_stream, **kw)
+
+
+@pytest.mark.parametrize("f32_stream", [False, True])
+@pytest.mark.parametrize("name,cin,cout,k,kw,xkey", [
+    ("conv3_320", 320, 320, 3, {}, "x320"), ("conv3_s2_320", 320, 320, 3, {"stride": 2}, "x320"),
+    ("conv1_640_320", 640, 320, 1, {}, "x640"), ("conv1_640_320", 640, 320, 1, {"two_source": True}, "x640")])
+def test_ffconv_matches_reference(gold, prec, f32_stream, name, cin, cout, k, kw, xkey):
+    from asva_amd.unet import AudioUNet3DConditionModel as M, _Act, _FFConv
+
+    root = _pack(_FFConv(cin, cout, k), f"blk.{name}.", "ffconv")
+    st = _state(gold, f32_stream)
+    kw = dict(kw)
+    x = _rows(gold["in"][xkey])
+    if kw.pop("two_source", False):       # the UNet skip concat (unet_3d_blocks.py:1038) as two operands
+        out = M._ffconv(st, _Act(x[:, :320].contiguous()), root.p, (gold["H"], gold["W"]), x2=_Act(x[:, 320:].contiguous()), **kw)
+    else:
+        out = M._ffconv(st, _Act(x), root.p, (gold["H"], gold["W"]), **kw)
+    ref = gold[name].float()
+    got = _video(out.lo, gold["B"], gold["F"], ref.shape[-2], ref.shape[-1])
+    err = rel_l2(got, ref)
+    print(f"{name} {kw} [{prec}, f32_stream={f32_stream}]: rel-L2 vs reference {err:.3e}")
+    assert err < TOL[prec]["conv"]
+    if f32_stream:
+        assert out.hi is not None and rel_l2(_video(out.hi, gold["B"], gold["F"], ref.shape[-2], ref.shape[-1]), ref) <= err + 1e-4
+
+
+@pytest.mark.parametrize("f32_stream", [False, True])
+@pytest.mark.parametrize("name,which", [("down_320", "down"), ("up_320", "up")])
+def test_samplers_match_reference(gold, prec, f32_stream, name, which):
+    from asva_amd.unet import AudioUNet3DConditionModel as M, _Act, _Sampler
+
+    root = _pack(_Sampler(320), f"blk.{name}.", lambda pr, h: pr.ffconv(h.conv))
+    st = _state(gold, f32_stream)
+    x = _Act(_rows(gold["in"]["x320"]))
+    hw = (gold["H"], gold["W"])
+    out = M._ffconv(st, x, root.p, hw, stride=2) if which == "down" else M._ffconv(st, x, root.p, hw, ups=1)
+    ref = gold[name].float()
+    err = rel_l2(_video(out.lo, gold["B"], gold["F"], ref.shape[-2], ref.shape[-1]), ref)
+    print(f"{name} [{prec}, f32_stream={f32_stream}]: rel-L2 vs reference {err:.3e}")
+    assert err < TOL[prec]["conv"]
+
+
+@pytest.mark.parametrize("f32_stream", [False, True])
+@pytest.mark.parametrize("name,cin,xkey", [("res_320", 320, "x320"), ("res_640_320", 640, "x640")])
+def test_resblock_matches_reference(gold, prec, f32_stream, name, cin, xkey):
+    from asva_amd import ops
+    from asva_amd.unet import AudioUNet3DConditionModel as M, _Act, _ResBlock
+
+    root = _pack(_ResBlock(cin, 320, 1280), f"blk.{name}.", "res")
+    st = _state(gold, f32_stream)
+    st.temb = ops.linear_small_m(gold["in"]["temb"].cuda(), root.temb_w, root.temb_b, act_in=True)     # time_emb_proj(SiLU(temb))
+    x = _rows(gold["in"][xkey])
+    hw = (gold["H"], gold["W"])
+    if cin == 640:       # up-block form: x = [h | skip] never concatenated
+        out = M._resblock(st, _Act(x[:, :320].contiguous()), _Act(x[:, 320:].contiguous()), root.p, hw)
+    else:
+        out = M._resblock(st, _Act(x), None, root.p, hw)
+    ref = gold[name].float()
+    err = rel_l2(_video(out.lo, gold["B"], gold["F"], gold["H"], gold["W"]), ref)
+    print(f"{name} [{prec}, f32_stream={f32_stream}]: rel-L2 vs reference {err:.3e}")
+    assert err < TOL[prec]["res"]
+
+
+@pytest.mark.parametrize("f32_stream", [False, True])
+@pytest.mark.parametrize("fuse_ln", [True, False])
+@pytest.mark.parametrize("name,C,xkey", [("tr_320", 320, "x320"), ("tr_640", 640, "x640")])
+def test_transformer3d_matches_reference(gold, prec, f32_stream, fuse_ln, name, C, xkey):
+    from asva_amd import precision as P
+    from asva_amd.conditioning import audio_segment_mask, mask_to_key_index
+    from asva_amd.unet import AudioUNet3DConditionModel as M, _Act, _Pk, _Transformer3D
+
+    root = _pack(_Transformer3D(C, 768, 768), f"blk.{name}.", "tr")
+    Fr = gold["F"]
+    text = gold["in"]["text"].to(P.ACT).cuda()
+    audio = gold["in"]["audio"].to(P.ACT).cuda()
+    cond = M.make_cond_block(root.p, text, 1, audio, 1, Fr)
+    idx = mask_to_key_index(audio_segment_mask(Fr)).cuda()
+    st = _state(gold, f32_stream, fuse_ln)
+    st.cond = _Pk(blocks=[cond], key_index=idx, idx_frames=Fr, frames=Fr, batch=gold["B"])
+    out = M._transformer(st, _Act(_rows(gold["in"][xkey])), root.p, (gold["H"], gold["W"]), 8)
+    ref = gold[name].float()
+    err = rel_l2(_video(out.lo, gold["B"], Fr, gold["H"], gold["W"]), ref)
+    print(f"{name} [{prec}, f32_stream={f32_stream}, fuse_ln={fuse_ln}]: rel-L2 vs reference {err:.3e}")
+    assert err < TOL[prec]["tr"]
+
+
+def test_fused_layernorm_on_rows_with_large_mean(prec):
+    """the folded LayerNorm takes var = E[x^2] - mean^2 from per-32-column (sum, sumsq) pairs in f32.  Rows whose
+    mean is 30x their standard deviation (mean^2 / var = 900) must still match the two-pass LayerNorm kernel + GEMM."""
+    from asva_amd import ops, precision as P
+
+    torch.manual_seed(0)
+    M_, C, N = 512, 640, 320
+    dev = torch.device("cuda", 0)
+    a = (torch.randn(M_, C, device=dev) * 0.5).to(P.ACT)
+    w0 = (torch.randn(C, C, device=dev) * C ** -0.5).to(P.ACT)
+    res = (torch.randn(M_, C, device=dev) + 30.0).to(P.ACT)                       # residual stream: mean 30, std ~1.2
+    stats = torch.empty(M_, C // 32, 2, device=dev)
+    h = ops.gemm(a, w0, res1=res, rowstats=stats)
+    gamma, beta = 1 + 0.1 * torch.randn(C, device=dev), 0.1 * torch.randn(C, device=dev)
+    w = torch.randn(N, C, device=dev) * C ** -0.5
+    wf = (w * gamma[None, :]).to(P.ACT)
+    fused = ops.gemm(h, wf, bias=w @ beta, ln=(stats, wf.float().sum(1), 1e-5))
+    hn = torch.nn.functional.layer_norm(h.float(), (C,), gamma, beta, 1e-5)
+    ref = hn @ w.T
+    err = rel_l2(fused, ref)
+    print(f"folded LayerNorm, |mean| = 30 std [{prec}]: rel-L2 vs fp32 LayerNorm + Linear {err:.3e}")
+    assert err < (6e-3 if prec == "bf16" else 1.5e-3)

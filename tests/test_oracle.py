@@ -259,3 +259,41 @@ def test_vae_decoder_primitives():
     o = o @ sd[p + ".to_out.0.weight"].T + sd[p + ".to_out.0.bias"]
     ref = x + o.transpose(1, 2).reshape(1, 64, 4, 4)
     assert rel_l2(vae_ref.mid_attention(x, sd, p, 32), ref) < 1e-5
+
+
+def test_oracle_matches_hip_legal_block_goldens():
+    """The restatement against the reference's modules at the sizes the gfx950 kernels accept (C = 320 / 640, 8 heads,
+    32 groups, f = 4, 8x8; tests/golden/unet_blocks_hip.pt, bf16-representable filler weights and inputs).  The goldens are
+    stored as fp16 (3e-4 rounding), hence 1e-3 here; tests/test_blocks_gpu.py compares the HIP blocks with the same file."""
+    from asva_amd.conditioning import audio_segment_mask
+    from asva_amd.unet import _FFConv, _ResBlock, _Sampler, _Transformer3D
+    from oracle.filler import fill_module_, seeded_randn_bf16
+
+    g = load_golden("unet_blocks_hip.pt")
+    s = g["seeds"]
+    B, Fr, H, W = g["B"], g["F"], g["H"], g["W"]
+    x320, x640 = seeded_randn_bf16(s["x320"], B, 320, Fr, H, W), seeded_randn_bf16(s["x640"], B, 640, Fr, H, W)
+    temb = seeded_randn_bf16(s["temb"], B, 1280)[:, None].expand(B, Fr, 1280)
+    text = seeded_randn_bf16(s["text"], B, 77, 768)[:, None].expand(B, Fr, 77, 768)
+    audio = seeded_randn_bf16(s["audio"], B, 229, 768)[:, None].expand(B, Fr, 229, 768)
+    mask = audio_segment_mask(Fr)[None].expand(B, -1, -1)
+
+    def sd_of(holder, name):
+        fill_module_(holder, f"blk.{name}.", round_bf16=True)
+        return {f"{name}.{k}": v for k, v in holder.state_dict().items()}
+
+    tol = 1e-3
+    for name, (cin, cout, k, stride, pad, x) in {"conv3_320": (320, 320, 3, 1, 1, x320), "conv3_s2_320": (320, 320, 3, 2, 1, x320),
+                                                 "conv1_640_320": (640, 320, 1, 1, 0, x640)}.items():
+        y = unet_ref.ff_inflated_conv3d(x, sd_of(_FFConv(cin, cout, k), name), name, stride=stride, padding=pad)
+        assert rel_l2(y, g[name]) < tol, name
+    for name, (cin, x) in {"res_320": (320, x320), "res_640_320": (640, x640)}.items():
+        y = unet_ref.resnet_block(x, temb, sd_of(_ResBlock(cin, 320, 1280), name), name, 32, 1e-5)
+        assert rel_l2(y, g[name]) < tol, name
+    y = unet_ref.ff_inflated_conv3d(x320, sd_of(_Sampler(320), "down_320"), "down_320.conv", stride=2)
+    assert rel_l2(y, g["down_320"]) < tol
+    up = F.interpolate(x320, scale_factor=(1.0, 2.0, 2.0), mode="nearest")
+    assert rel_l2(unet_ref.ff_inflated_conv3d(up, sd_of(_Sampler(320), "up_320"), "up_320.conv"), g["up_320"]) < tol
+    for name, (C, x) in {"tr_320": (320, x320), "tr_640": (640, x640)}.items():
+        y = unet_ref.transformer_3d(x, text, audio, mask, sd_of(_Transformer3D(C, 768, 768), name), name, 8, 32)
+        assert rel_l2(y, g[name]) < tol, name

@@ -43,6 +43,25 @@ class GemmDesc(C.Structure):
     ]
 
 
+class XAttnDesc(C.Structure):
+    """Mirror of `avsd_xattn_desc` (include/avsd.h)."""
+
+    _fields_ = [
+        ("h", c_void_p), ("ldh", C.c_int32), ("res_f32", C.c_int32),
+        ("res", c_void_p), ("ldres", C.c_int32),
+        ("M", C.c_int32), ("C", C.c_int32), ("heads", C.c_int32), ("L", C.c_int32),
+        ("ln_stats", c_void_p), ("ln_eps", C.c_float), ("scale", C.c_float),
+        ("wq", c_void_p), ("ldwq", C.c_int32), ("lk", C.c_int32),
+        ("q_colsum", c_void_p), ("q_bias", c_void_p),
+        ("k", c_void_p), ("vt", c_void_p),
+        ("lk_pad", C.c_int32), ("q_per_kv", C.c_int32),
+        ("wo", c_void_p), ("ldwo", C.c_int32), ("ldo", C.c_int32),
+        ("o_bias", c_void_p), ("out", c_void_p),
+        ("out_master", c_void_p), ("ldm", C.c_int32), ("reserved0", C.c_int32),
+        ("rowstats", c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); exactly the symbols include/avsd.h declares
 SIGNATURES = {
     "avsd_abi_version": (c_int, []),
@@ -51,6 +70,9 @@ SIGNATURES = {
     "avsd_device_info": (c_int, [C.c_char_p, c_int, C.POINTER(c_int)]),
     "avsd_gemm_bf16": (c_int, [C.POINTER(GemmDesc), c_void_p]),
     "avsd_sizeof_gemm_desc": (c_int, []),
+    "avsd_cross_attention_block": (c_int, [C.POINTER(XAttnDesc), c_void_p]),
+    "avsd_cross_attention_block_supported": (c_int, [c_int, c_int, c_int]),
+    "avsd_sizeof_xattn_desc": (c_int, []),
     "avsd_linear_small_m": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "avsd_groupnorm_stats": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "avsd_groupnorm_apply": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
@@ -101,6 +123,10 @@ def lib() -> C.CDLL:
         if handle.avsd_sizeof_gemm_desc() != C.sizeof(GemmDesc):
             raise AvsdError(
                 f"avsd_gemm_desc layout mismatch: C {handle.avsd_sizeof_gemm_desc()} B vs ctypes {C.sizeof(GemmDesc)} B"
+            )
+        if handle.avsd_sizeof_xattn_desc() != C.sizeof(XAttnDesc):
+            raise AvsdError(
+                f"avsd_xattn_desc layout mismatch: C {handle.avsd_sizeof_xattn_desc()} B vs ctypes {C.sizeof(XAttnDesc)} B"
             )
         if handle.avsd_precision().decode() != P.NAME:
             raise AvsdError(f"{path} computes in {handle.avsd_precision().decode()}, expected {P.NAME}")

@@ -1,0 +1,272 @@
+// Pieces shared by the GEMM family (gemm.hip) and the fused kernels built on its main loop (xattn.hip):
+// the f32 epilogue, the LayerNorm-fold row statistics, counted vmcnt waits and the LDS-direct tile addressing.
+#pragma once
+#include "avsd_common.h"
+
+namespace {
+
+constexpr int BK = 64;
+
+// LayerNorm statistics of row m of A folded from the producer's per-32-column (sum, sumsq) pairs -> (rstd, mean * rstd)
+__device__ __forceinline__ void ln_row_stats(const avsd_gemm_desc& p, int m, int64_t bz, float& rstd, float& mr) {
+  const float2* st = reinterpret_cast<const float2*>(p.ln_stats) + ((int64_t)bz * (p.batch_stride_a / p.lda) + m) * p.ln_nblk;
+  float sm = 0.f, sq = 0.f;
+  int j = 0;
+  for (; j + 10 <= p.ln_nblk; j += 10) {      // ten independent loads in flight (C = 320 k -> 10 k pairs)
+    float2 t[10];
+#pragma unroll
+    for (int u = 0; u < 10; ++u) t[u] = st[j + u];
+#pragma unroll
+    for (int u = 0; u < 10; ++u) { sm += t[u].x; sq += t[u].y; }
+  }
+  for (; j < p.ln_nblk; ++j) {
+    const float2 t = st[j];
+    sm += t.x;
+    sq += t.y;
+  }
+  const float inv_k = 1.0f / (float)(p.ln_nblk * 32);
+  const float mean = sm * inv_k;
+  const float var = fmaxf(sq * inv_k - mean * mean, 0.f);
+  rstd = rsqrtf(var + p.ln_eps);
+  mr = mean * rstd;
+}
+
+// ---- shared f32 epilogue: lane holds row m = m_base + (lane&31) of fragment b, and columns
+// n = n_base + 32*a + 8q + 4*(lane>>5) + {0..3} of fragment a (see header of this file) ----------------
+// Residuals are 16-bit, or f32 under AVSD_GEMM_RES1_F32 / RES2_F32 (the f32 residual stream); with `out_master` the
+// un-rounded f32 result is stored next to the 16-bit one.
+template <int FN, int FM>
+__device__ __forceinline__ void epilogue(const avsd_gemm_desc& p, f32x16 (&acc)[FN][FM], int m_base, int n_base,
+                                         int lane, int64_t bz, const float (&pre_ln)[2 * FM], bool have_pre) {
+  const int frow = lane & 31;
+  const bool geglu = (p.flags & AVSD_GEMM_GEGLU) != 0;
+  const bool out_f32 = (p.flags & AVSD_GEMM_OUT_F32) != 0;
+  const bool gelu = (p.flags & AVSD_GEMM_GELU) != 0;
+  const bool lnfuse = (p.flags & AVSD_GEMM_LNFUSE) != 0;
+  const bool rowstats = (p.flags & AVSD_GEMM_ROWSTATS) != 0;
+  const bool r1f = (p.flags & AVSD_GEMM_RES1_F32) != 0, r2f = (p.flags & AVSD_GEMM_RES2_F32) != 0;
+  const h16_t* R1 = reinterpret_cast<const h16_t*>(p.res1);
+  const h16_t* R2 = reinterpret_cast<const h16_t*>(p.res2);
+  const float* R1f = reinterpret_cast<const float*>(p.res1);
+  const float* R2f = reinterpret_cast<const float*>(p.res2);
+  const int hsel = (lane >> 5) * 4;
+#pragma unroll
+  for (int b = 0; b < FM; ++b) {
+    const int m = m_base + b * 32 + frow;
+    if (m >= p.M) continue;
+    const float* rv = p.rowvec ? p.rowvec + (int64_t)(m / p.rows_per_vec) * p.ldv : nullptr;
+    // AVSD_GEMM_LNFUSE: LayerNorm statistics of this lane's row of A (rstd, mean * rstd)
+    float ln_rstd = 1.f, ln_mr = 0.f;
+    if (lnfuse) {
+      if (have_pre) { ln_rstd = pre_ln[2 * b]; ln_mr = pre_ln[2 * b + 1]; }
+      else ln_row_stats(p, m, bz, ln_rstd, ln_mr);
+    }
+    float2* rs_out = rowstats ? reinterpret_cast<float2*>(p.rowstats) + ((int64_t)bz * p.M + m) * (p.N >> 5) : nullptr;
+    const int64_t orow = bz * p.batch_stride_out + (int64_t)m * p.ldc;
+    float* mrow = p.out_master ? p.out_master + bz * p.batch_stride_out + (int64_t)m * p.ldm : nullptr;
+    // alpha * acc (+ LayerNorm fold) + bias + rowvec (+ GELU) for quad q of fragment (a, b) -> v[0..3]
+    auto head = [&](int a, int q, int n, float (&v)[4]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = p.alpha * acc[a][b][4 * q + i];
+      if (lnfuse) {
+        const float4 cs = *reinterpret_cast<const float4*>(p.ln_colsum + n);
+        v[0] = fmaf(v[0], ln_rstd, -ln_mr * cs.x); v[1] = fmaf(v[1], ln_rstd, -ln_mr * cs.y);
+        v[2] = fmaf(v[2], ln_rstd, -ln_mr * cs.z); v[3] = fmaf(v[3], ln_rstd, -ln_mr * cs.w);
+      }
+      if (p.bias) {
+        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+      }
+      if (rv) {
+        const float4 bb = *reinterpret_cast<const float4*>(rv + n);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+      }
+    };
+    auto add_f32 = [&](const float* R, int ldr, int n, float (&v)[4]) {
+      const float4 rr = *reinterpret_cast<const float4*>(R + bz * p.batch_stride_out + (int64_t)m * ldr + n);
+      v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+    };
+#pragma unroll
+    for (int a = 0; a < FN; ++a) {
+      const int nb = n_base + a * 32;  // first packed column of this fragment
+      if (nb >= p.N) continue;
+      // 16-bit output, fragment fully inside N, 16-byte-aligned rows: the two lanes that share a row (l, l ^ 32) trade
+      // halves with v_permlane32_swap so each stores (and reads 16-bit residuals as) 32 contiguous bytes — two dwordx4
+      // per fragment instead of four dwordx2 scattered 8 bytes apart (store issue, not bandwidth, bounds this tail).
+      const bool wide = !geglu && !out_f32 && nb + 32 <= p.N && (p.ldc & 7) == 0 && (!R1 || r1f || (p.ldr1 & 7) == 0) &&
+                        (!R2 || r2f || (p.ldr2 & 7) == 0);
+      if (wide) {
+        float v[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          head(a, q, nb + 8 * q + hsel, v[q]);
+          if (gelu) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[q][i] = gelu_erf_f(v[q][i]);
+          }
+        }
+        const int ncol = nb + 4 * hsel;   // this lane's 16 columns after the swap: nb (lanes 0-31) or nb + 16
+        auto add_res = [&](const h16_t* R, int ldr) {
+          const h16_t* rp = R + bz * p.batch_stride_out + (int64_t)m * ldr + ncol;
+          const uint4 lo = *reinterpret_cast<const uint4*>(rp);
+          const uint4 hi = *reinterpret_cast<const uint4*>(rp + 8);
+          const unsigned s0[2] = {lo.x, lo.y}, s1[2] = {lo.z, lo.w}, s2[2] = {hi.x, hi.y}, s3[2] = {hi.z, hi.w};
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            const auto e = __builtin_amdgcn_permlane32_swap(s0[d], s1[d], false, false);   // -> quads 0 and 2
+            const auto o = __builtin_amdgcn_permlane32_swap(s2[d], s3[d], false, false);   // -> quads 1 and 3
+            v[0][2 * d] += lo2f(e[0]); v[0][2 * d + 1] += hi2f(e[0]);
+            v[2][2 * d] += lo2f(e[1]); v[2][2 * d + 1] += hi2f(e[1]);
+            v[1][2 * d] += lo2f(o[0]); v[1][2 * d + 1] += hi2f(o[0]);
+            v[3][2 * d] += lo2f(o[1]); v[3][2 * d + 1] += hi2f(o[1]);
+          }
+        };
+        if (R1) {
+          if (r1f) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) add_f32(R1f, p.ldr1, nb + 8 * q + hsel, v[q]);
+          } else add_res(R1, p.ldr1);
+        }
+        if (R2) {
+          if (r2f) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) add_f32(R2f, p.ldr2, nb + 8 * q + hsel, v[q]);
+          } else add_res(R2, p.ldr2);
+        }
+        if (mrow) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(mrow + nb + 8 * q + hsel) = make_float4(v[q][0], v[q][1], v[q][2], v[q][3]);
+        }
+        unsigned x[2][2], y[2][2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const auto e = __builtin_amdgcn_permlane32_swap(pack2h(v[0][2 * d], v[0][2 * d + 1]), pack2h(v[2][2 * d], v[2][2 * d + 1]), false, false);
+          const auto o = __builtin_amdgcn_permlane32_swap(pack2h(v[1][2 * d], v[1][2 * d + 1]), pack2h(v[3][2 * d], v[3][2 * d + 1]), false, false);
+          x[0][d] = e[0]; x[1][d] = e[1];
+          y[0][d] = o[0]; y[1][d] = o[1];
+        }
+        h16_t* op = reinterpret_cast<h16_t*>(p.out) + orow + ncol;
+        *reinterpret_cast<uint4*>(op) = make_uint4(x[0][0], x[0][1], x[1][0], x[1][1]);
+        *reinterpret_cast<uint4*>(op + 8) = make_uint4(y[0][0], y[0][1], y[1][0], y[1][1]);
+        if (rs_out) {
+          // (sum, sum of squares) of the 16 rounded values this lane just stored, plus the partner lane's 16
+          float sm = 0.f, sq = 0.f;
+          const unsigned w8[8] = {x[0][0], x[0][1], x[1][0], x[1][1], y[0][0], y[0][1], y[1][0], y[1][1]};
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float lo = lo2f(w8[i]), hi = hi2f(w8[i]);
+            sm += lo + hi;
+            sq = fmaf(lo, lo, fmaf(hi, hi, sq));
+          }
+          const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(sm), __float_as_uint(sm), false, false);
+          const auto u = __builtin_amdgcn_permlane32_swap(__float_as_uint(sq), __float_as_uint(sq), false, false);
+          // lanes 0-31: t = (own, partner's); fixed order low half + high half on both lanes
+          if (hsel == 0) rs_out[nb >> 5] = make_float2(__uint_as_float(t[0]) + __uint_as_float(t[1]),
+                                                       __uint_as_float(u[0]) + __uint_as_float(u[1]));
+        }
+      } else if (!geglu) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = nb + 8 * q + hsel;
+          if (n >= p.N) continue;
+          float v[4];
+          head(a, q, n, v);
+          if (gelu) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = gelu_erf_f(v[i]);
+          }
+          if (R1) {
+            if (r1f) add_f32(R1f, p.ldr1, n, v);
+            else {
+              const uint2 rr = *reinterpret_cast<const uint2*>(R1 + bz * p.batch_stride_out + (int64_t)m * p.ldr1 + n);
+              v[0] += lo2f(rr.x); v[1] += hi2f(rr.x); v[2] += lo2f(rr.y); v[3] += hi2f(rr.y);
+            }
+          }
+          if (R2) {
+            if (r2f) add_f32(R2f, p.ldr2, n, v);
+            else {
+              const uint2 rr = *reinterpret_cast<const uint2*>(R2 + bz * p.batch_stride_out + (int64_t)m * p.ldr2 + n);
+              v[0] += lo2f(rr.x); v[1] += hi2f(rr.x); v[2] += lo2f(rr.y); v[3] += hi2f(rr.y);
+            }
+          }
+          if (mrow) *reinterpret_cast<float4*>(mrow + n) = make_float4(v[0], v[1], v[2], v[3]);
+          if (out_f32) {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow + n) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            uint2 st;
+            st.x = pack2h(v[0], v[1]);
+            st.y = pack2h(v[2], v[3]);
+            *reinterpret_cast<uint2*>(reinterpret_cast<h16_t*>(p.out) + orow + n) = st;
+          }
+        }
+      } else {
+        // GEGLU: packed 32-row block = [16 value rows | 16 gate rows]; quads 0,1 hold values, 2,3 their gates.
+        float v[2][4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          float gate[4];
+          head(a, q, nb + 8 * q + hsel, v[q]);
+          head(a, q + 2, nb + 8 * q + hsel + 16, gate);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[q][i] *= gelu_erf_f(gate[i]);
+        }
+        const int no = (nb >> 1) + hsel;   // output feature of quad 0; quad 1 sits 8 further
+        if (!out_f32 && (p.ldc & 7) == 0) {
+          // lanes l / l ^ 32 hold output columns {0-3, 8-11} / {4-7, 12-15} of the 16-column block: swap so that each stores
+          // 8 contiguous columns (one dwordx4 instead of two dwordx2)
+          unsigned e0[2], e1[2];
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            const auto e = __builtin_amdgcn_permlane32_swap(pack2h(v[0][2 * d], v[0][2 * d + 1]), pack2h(v[1][2 * d], v[1][2 * d + 1]), false, false);
+            e0[d] = e[0]; e1[d] = e[1];
+          }
+          *reinterpret_cast<uint4*>(reinterpret_cast<h16_t*>(p.out) + orow + (nb >> 1) + 2 * hsel) = make_uint4(e0[0], e0[1], e1[0], e1[1]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int64_t o = orow + no + 8 * q;
+            if (out_f32) {
+              *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) = make_float4(v[q][0], v[q][1], v[q][2], v[q][3]);
+            } else {
+              uint2 st;
+              st.x = pack2h(v[q][0], v[q][1]);
+              st.y = pack2h(v[q][2], v[q][3]);
+              *reinterpret_cast<uint2*>(reinterpret_cast<h16_t*>(p.out) + o) = st;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// s_waitcnt vmcnt(N) with N a compile-time constant (0..63), everything else unconstrained.  gfx9 encoding of the
+// immediate: vmcnt[3:0] in bits 3:0, vmcnt[5:4] in bits 15:14, expcnt (7 = no wait) in 6:4, lgkmcnt (15) in 11:8.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
+  asm volatile("" ::: "memory");
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+
+// ---- LDS-direct K tiles (gemm2_kernel and the fused kernels) ----------------------------------------------------------
+// Tile image: rows of 64 16-bit values = 128 B, two rows = one 256-B line L; the 16-byte slot index inside a line is
+// XOR-ed with (L & 15).  A 1-KiB piece = 4 lines, written lane-linearly by one buffer_load_dwordx4 ... lds: lane l
+// lands in line L = 4 * piece + l / 16, slot l % 16, and therefore fetches row 2L + (x >> 3), k-chunk (x & 7) * 8 with
+// x = (l % 16) ^ (L & 15).  Fragment reads undo the permutation: row r, 16-byte chunk c -> line r >> 1,
+// slot ((r & 1) << 3 | c) ^ ((r >> 1) & 15).
+__device__ __forceinline__ void piece_row_chunk(int piece, int lane, int& row, int& kchunk) {
+  const int L = piece * 4 + (lane >> 4);
+  const int x = (lane & 15) ^ (L & 15);
+  row = 2 * L + (x >> 3);
+  kchunk = (x & 7) * 8;
+}
+__device__ __forceinline__ int frag_offset(int r, int c) {   // byte offset of (row r, 16-byte chunk c) inside a tile image
+  return (r >> 1) * 256 + ((((r & 1) << 3) | c) ^ ((r >> 1) & 15)) * 16;
+}
+
+}  // namespace

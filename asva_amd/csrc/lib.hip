@@ -13,6 +13,7 @@ void avsd_set_error(const char* fmt, ...) {
 
 extern "C" int avsd_abi_version(void) { return AVSD_ABI_VERSION; }
 extern "C" const char* avsd_precision(void) { return AVSD_PRECISION_NAME; }
+extern "C" int avsd_sizeof_xattn_desc(void) { return (int)sizeof(avsd_xattn_desc); }
 
 extern "C" const char* avsd_last_error(void) { return g_err; }
 

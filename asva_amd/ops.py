@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 from . import precision as P
-from ._lib import GemmDesc, check
+from ._lib import GemmDesc, XAttnDesc, check
 
 PLAIN, TMIX, CONV3 = 0, 1, 2
 GEGLU, OUT_F32, GELU, XCD_N, ROWSTATS, LNFUSE, RES1_F32, RES2_F32 = 1, 2, 4, 8, 16, 32, 64, 128
@@ -535,6 +535,61 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, bq: int, lq:
           "avsd_attention")
     if ev is not None:
         _TIMER.stop(ev, "attention", 4.0 * bq * heads * lq * lk * d, _nbytes(q, out) + 4.0 * (bq // q_per_kv) * lk * Cc)
+    return out
+
+
+def cross_attention_block_supported(C: int, heads: int, lk_pad: int, M: int, L: int) -> bool:
+    return bool(_lib.lib().avsd_cross_attention_block_supported(C, heads, lk_pad)) and M % 128 == 0 and L % 128 == 0
+
+
+def cross_attention_block(h: torch.Tensor, stats: torch.Tensor, wq: torch.Tensor, q_colsum: torch.Tensor, q_bias: torch.Tensor,
+                          k: torch.Tensor, vt: torch.Tensor, lk: int, wo: torch.Tensor, o_bias: torch.Tensor, *, res: torch.Tensor,
+                          heads: int, L: int, q_per_kv: int, eps: float = 1e-5, scale: Optional[float] = None,
+                          rowstats: Optional[torch.Tensor] = None, master: Optional[torch.Tensor] = None,
+                          out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = res + to_out(softmax((LN(h) Wq^T) K^T scale) V) in one launch; see avsd_cross_attention_block (include/avsd.h).
+    k [nkv, lk_pad, C], vt [nkv, C, lk_pad] are the cached, padded (and for audio mask-gathered) K / V^T."""
+    _req(h, P.ACT, "h")
+    _req(wq, P.ACT, "wq")
+    _req(wo, P.ACT, "wo")
+    _req(k, P.ACT, "k")
+    _req(vt, P.ACT, "vt")
+    _req(stats, F32, "stats")
+    M, Cc = h.shape
+    lk_pad = k.shape[1]
+    if not k.is_contiguous() or not vt.is_contiguous() or vt.shape != (k.shape[0], Cc, lk_pad) or k.shape[2] != Cc:
+        raise ValueError("cross_attention_block: k must be contiguous [nkv, lk_pad, C] and vt [nkv, C, lk_pad]")
+    if not stats.is_contiguous() or stats.shape != (M, Cc // 32, 2):
+        raise ValueError("cross_attention_block: stats must be contiguous f32 [M, C/32, 2]")
+    if (M // L) // q_per_kv > k.shape[0] or (M // L) % q_per_kv:
+        raise ValueError("cross_attention_block: K/V blocks do not cover the query batches")
+    if out is None:
+        out = torch.empty((M, Cc), dtype=P.ACT, device=h.device)
+    d = XAttnDesc()
+    d.h, d.ldh = _p(h), _ld(h)
+    _req(res, F32 if res.dtype == F32 else P.ACT, "res")
+    d.res, d.ldres, d.res_f32 = _p(res), _ld(res), int(res.dtype == F32)
+    d.M, d.C, d.heads, d.L = M, Cc, heads, L
+    d.ln_stats, d.ln_eps = _p(stats), float(eps)
+    d.scale = float(scale) if scale is not None else float(Cc // heads) ** -0.5
+    d.wq, d.ldwq, d.q_colsum, d.q_bias = _p(wq), _ld(wq), _p(q_colsum), _p(q_bias)
+    d.k, d.vt, d.lk, d.lk_pad, d.q_per_kv = _p(k), _p(vt), lk, lk_pad, q_per_kv
+    d.wo, d.ldwo, d.o_bias = _p(wo), _ld(wo), _p(o_bias)
+    d.out, d.ldo = _p(out), _ld(out)
+    if master is not None:
+        _req(master, F32, "master")
+        d.out_master, d.ldm = _p(master), _ld(master)
+    if rowstats is not None:
+        _req(rowstats, F32, "rowstats")
+        d.rowstats = _p(rowstats)
+    ev = _TIMER.start() if _TIMER is not None else None
+    check(_lib.lib().avsd_cross_attention_block(C.byref(d), _stream()), "avsd_cross_attention_block")
+    if ev is not None:
+        dc = XAttnDesc.from_buffer_copy(d)
+        _TIMER.add_replay("cross_attention_block", lambda dc=dc: check(_lib.lib().avsd_cross_attention_block(C.byref(dc), _stream()),
+                                                                         "avsd_cross_attention_block"),
+                          (h, stats, wq, q_colsum, q_bias, k, vt, wo, o_bias, res, out, master, rowstats))
+        _TIMER.stop(ev, "cross_attention_block", 4.0 * M * Cc * Cc + 4.0 * M * lk * Cc, _nbytes(h, out, res, master) + 4.0 * Cc * Cc)
     return out
 
 

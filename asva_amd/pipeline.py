@@ -313,7 +313,8 @@ def generate_videos(pipeline, image_path: str = "", audio_path: str = "", video_
         # uint8 (f, H, W, 3) frames = (video.permute(0, 2, 3, 1) * 255).byte() of the reference (:448), made on the device
         video = pipeline(images=[clip["image"]] if "image" in clip else None, audios=[clip.get("audio")], texts=[category],
                          text_encodings=[category_text_encoding] if category_text_encoding is not None else None,
-                         video_length=video_num_frame, height=image_size[0], width=image_size[1], num_inference_steps=50,
+                         video_length=video_num_frame, height=image_size[0], width=image_size[1],
+                         num_inference_steps=getattr(pipeline, "generation_steps", 50),     # the reference hard-codes 50 (:442)
                          audio_guidance_scale=audio_guidance_scale, text_guidance_scale=text_guidance_scale,
                          generator=generator, return_dict=False, output_type="uint8", **kw)[0]
         if save_template:

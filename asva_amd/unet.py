@@ -41,6 +41,27 @@ _FUSE_LN = os.environ.get("AVSD_FUSE_LN", "1") != "0"    # fold LayerNorm 1 / au
 # Removes the ~100 chained roundings of the residual stream (the dominant error term of the 16-bit path) for one extra f32
 # write and a wider residual read per stream-producing GEMM.  Per model: `unet.f32_residual = True`.
 _F32_RES = os.environ.get("AVSD_F32_RESIDUAL", "0") != "0"
+_FUSE_XATTN = os.environ.get("AVSD_FUSE_XATTN", "1") != "0"   # audio / text cross-attention as one launch where the kernel is built
+
+
+def _xa_fill(kv: torch.Tensor, n_kv: int, rows: int, C: int, idx: Optional[torch.Tensor], old=None):
+    """Cached K|V [n_kv*rows, 2C] -> the layout avsd_cross_attention_block stages: K [nb, lk_pad, C] and V^T [nb, C, lk_pad],
+    keys padded to whole 32-key tiles; with a per-frame gather list idx [F, nk] (audio segment mask) nb = n_kv * F blocks
+    hold the visible keys of each frame.  Pure data movement, once per clip.  `old` is refreshed in place (a captured
+    hipGraph holds its addresses).  None when more than 96 keys remain (the separate kernels handle that)."""
+    kv3 = kv.view(n_kv, rows, 2 * C)
+    if idx is not None:
+        kv3 = kv3[:, idx.long()].reshape(n_kv * idx.shape[0], idx.shape[1], 2 * C)
+    nb, lk = kv3.shape[:2]
+    lkp = (lk + 31) // 32 * 32
+    if lkp > 96:
+        return None
+    if old is None:
+        old = _Pk(k=torch.zeros((nb, lkp, C), dtype=kv.dtype, device=kv.device),
+                  vt=torch.zeros((nb, C, lkp), dtype=kv.dtype, device=kv.device), lk=lk)
+    old.k[:, :lk].copy_(kv3[..., :C])
+    old.vt[:, :, :lk].copy_(kv3[..., C:].transpose(1, 2))
+    return old
 
 
 class FrozenConfig(dict):
@@ -715,22 +736,42 @@ class AudioUNet3DConditionModel(nn.Module):
             # denoising step (which holds their addresses) stays valid
             tb = text.reshape(-1, text.shape[-1])
             ab = None if audio is None else audio.reshape(-1, audio.shape[-1])
+            if key_index is not None:
+                old.key_index.copy_(key_index)
             for tp, c in zip(self._transformers(pk), old.blocks):
                 ops.gemm(tb, tp.attn2.wkv, out=c.text_kv)
                 if tp.audio:
                     ops.gemm(ab, tp.attn_audio.wkv, out=c.audio_kv)
-            if key_index is not None:
-                old.key_index.copy_(key_index)
+                self._xa_caches(c, tp, old.key_index, idx_frames, Fr)
             return old
-        blocks = [self.make_cond_block(tp, text, text_pf, audio, audio_pf, Fr) for tp in self._transformers(pk)]
+        blocks = [self.make_cond_block(tp, text, text_pf, audio, audio_pf, Fr, key_index, idx_frames) for tp in self._transformers(pk)]
         self._cond_version = getattr(self, "_cond_version", 0) + 1
         self._cond = _Pk(blocks=blocks, key_index=key_index, idx_frames=idx_frames, frames=Fr,
                          batch=text.shape[0] // text_pf, sig=sig, version=self._cond_version)
         return self._cond
 
     @staticmethod
-    def make_cond_block(tp, text, text_pf, audio, audio_pf, frames):
-        """Step-invariant inputs of one transformer block: text / audio K|V projections and the temporal position table."""
+    @staticmethod
+    def _xa_caches(c, tp, key_index, idx_frames, frames):
+        """(re)builds the padded K / V^T blocks of the fused cross-attention kernel from c.text_kv / c.audio_kv"""
+        C = tp.dim
+        c.xa_text = c.xa_audio = None
+        if not _FUSE_XATTN:
+            return
+        if c.text_pf == 1:
+            c.xa_text = _xa_fill(c.text_kv, c.text_kv.shape[0] // c.text_len, c.text_len, C, None, getattr(c, "_xa_text", None))
+            if c.xa_text is not None:
+                c.xa_text.q_per_kv = frames
+        if tp.audio and c.audio_pf == 1 and key_index is not None and idx_frames == frames:
+            c.xa_audio = _xa_fill(c.audio_kv, c.audio_kv.shape[0] // c.audio_len, c.audio_len, C, key_index, getattr(c, "_xa_audio", None))
+            if c.xa_audio is not None:
+                c.xa_audio.q_per_kv = 1
+        c._xa_text, c._xa_audio = c.xa_text, c.xa_audio
+
+    @staticmethod
+    def make_cond_block(tp, text, text_pf, audio, audio_pf, frames, key_index=None, idx_frames=None):
+        """Step-invariant inputs of one transformer block: text / audio K|V projections (also in the fused cross-attention
+        kernel's layout) and the temporal position table."""
         C = tp.dim
         c = _Pk()
         c.text_kv = ops.gemm(text.reshape(-1, text.shape[-1]), tp.attn2.wkv)
@@ -744,6 +785,7 @@ class AudioUNet3DConditionModel(nn.Module):
         emb = ops.timestep_embedding(ar, C)
         hid = ops.linear_small_m(emb, tp.pos1.w, tp.pos1.b, act_out=True)
         c.pos = ops.linear_small_m(hid, tp.pos2.w, tp.pos2.b)
+        AudioUNet3DConditionModel._xa_caches(c, tp, key_index, idx_frames if idx_frames is not None else frames, frames)
         return c
 
     @staticmethod
@@ -938,6 +980,22 @@ def _transformer(st, x: _Act, p, hw, heads) -> _Act:
             return _Act(ops.gemm(a, w, bias=bias, res1=None if res is None else res.res, rowstats=stats[si], master=m), m)
         return _Act(ops.gemm(a, w, bias=bias, res1=None if res is None else res.res, master=m), m)
 
+    def cross(h, a, norm, xa, want_stats, unfused):
+        """h + to_out(attention(LN(h) Wq, cached K, V)): one launch where the fused kernel is built, else q-proj + attention
+        + out-proj"""
+        nonlocal si
+        if fused and xa is not None and ops.cross_attention_block_supported(C, heads, xa.k.shape[1], M, L):
+            m = _master(st, h.lo, C)
+            s_in = stats[si]
+            s_out = None
+            if want_stats:
+                si ^= 1
+                s_out = stats[si]
+            out = ops.cross_attention_block(h.lo, s_in, a.wq_ln, a.sq_ln, a.bq_ln, xa.k, xa.vt, xa.lk, a.wo, a.bo, res=h.res,
+                                            heads=heads, L=L, q_per_kv=xa.q_per_kv, eps=eps, rowstats=s_out, master=m)
+            return _Act(out, m)
+        return stream(unfused(), a.wo, a.bo, h, want_stats=want_stats)
+
     def proj(h, norm, wl, bl, sl, w_plain):
         """Linear(LayerNorm(h)): folded into one GEMM on the raw stream, or LayerNorm kernel + plain GEMM"""
         if fused:
@@ -960,19 +1018,25 @@ def _transformer(st, x: _Act, p, hw, heads) -> _Act:
     # 2. audio cross-attention: cached K/V, segment mask as a key gather (:315-325)
     if p.audio:
         aa = p.attn_audio
-        q = proj(h, p.norm_audio, getattr(aa, "wq_ln", None), getattr(aa, "bq_ln", None), getattr(aa, "sq_ln", None), aa.wq)
-        idx = st.cond.key_index
-        o = ops.attention(q, c.audio_kv[:, :C], c.audio_kv[:, C:], bq=B * Fr, lq=L,
-                          lk=idx.shape[1] if idx is not None else c.audio_len, kv_rows=c.audio_len, heads=heads,
-                          q_per_kv=Fr if c.audio_pf == 1 else 1, frames=st.cond.idx_frames if idx is not None else Fr,
-                          key_index=idx)
-        h = stream(o, aa.wo, aa.bo, h)
+
+        def audio_attention():
+            q = proj(h, p.norm_audio, getattr(aa, "wq_ln", None), getattr(aa, "bq_ln", None), getattr(aa, "sq_ln", None), aa.wq)
+            idx = st.cond.key_index
+            return ops.attention(q, c.audio_kv[:, :C], c.audio_kv[:, C:], bq=B * Fr, lq=L,
+                                 lk=idx.shape[1] if idx is not None else c.audio_len, kv_rows=c.audio_len, heads=heads,
+                                 q_per_kv=Fr if c.audio_pf == 1 else 1, frames=st.cond.idx_frames if idx is not None else Fr,
+                                 key_index=idx)
+
+        h = cross(h, aa, p.norm_audio, getattr(c, "xa_audio", None), True, audio_attention)
     # 3. text cross-attention: cached K/V (:328-341)
     a2 = p.attn2
-    q = proj(h, p.norm2, getattr(a2, "wq_ln", None), getattr(a2, "bq_ln", None), getattr(a2, "sq_ln", None), a2.wq)
-    o = ops.attention(q, c.text_kv[:, :C], c.text_kv[:, C:], bq=B * Fr, lq=L, lk=c.text_len, kv_rows=c.text_len,
-                      heads=heads, q_per_kv=Fr if c.text_pf == 1 else 1, frames=Fr)
-    h = stream(o, a2.wo, a2.bo, h, want_stats=False)            # norm_temp below is a kernel of its own
+
+    def text_attention():
+        q = proj(h, p.norm2, getattr(a2, "wq_ln", None), getattr(a2, "bq_ln", None), getattr(a2, "sq_ln", None), a2.wq)
+        return ops.attention(q, c.text_kv[:, :C], c.text_kv[:, C:], bq=B * Fr, lq=L, lk=c.text_len, kv_rows=c.text_len,
+                             heads=heads, q_per_kv=Fr if c.text_pf == 1 else 1, frames=Fr)
+
+    h = cross(h, a2, p.norm2, getattr(c, "xa_text", None), False, text_attention)   # norm_temp below is a kernel of its own
     # 4. temporal attention across frames per pixel; LN(h + pos[f]); residual is h itself (:346-358)
     nt = ops.layernorm(h.lo, p.norm_temp.g, p.norm_temp.b, pos=c.pos, hw=L, frames=Fr)
     qkv = ops.gemm(nt, p.attn_temp.wqkv)

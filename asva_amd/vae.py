@@ -203,6 +203,21 @@ class AutoencoderKL(nn.Module):
         model.load_state_dict(sd)
         return model.eval()
 
+    def save_pretrained(self, save_directory: str, safe_serialization: bool = True):
+        """diffusers directory layout: config.json + diffusion_pytorch_model.safetensors (current attention names)."""
+        os.makedirs(save_directory, exist_ok=True)
+        cfg = {"_class_name": "AutoencoderKL", "_diffusers_version": "0.29.2"}
+        cfg.update({k: (list(v) if isinstance(v, tuple) else v) for k, v in dict(self.config).items()})
+        with open(os.path.join(save_directory, "config.json"), "w") as f:
+            json.dump(cfg, f, indent=2)
+        sd = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}
+        if safe_serialization:
+            from safetensors.torch import save_file
+
+            save_file(sd, os.path.join(save_directory, "diffusion_pytorch_model.safetensors"))
+        else:
+            torch.save(sd, os.path.join(save_directory, "diffusion_pytorch_model.bin"))
+
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         """Accepts diffusers AutoencoderKL checkpoints of either vintage: legacy attention names
         (query/key/value/proj_attn) are mapped and legacy [C, C, 1, 1] attention weights are squeezed."""

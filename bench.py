@@ -37,9 +37,13 @@ sys.path.insert(0, ROOT)
 
 SD15 = dict(block_out_channels=(320, 640, 1280, 1280), attention_head_dim=8, norm_num_groups=32,
             cross_attention_dim=768, audio_cross_attention_dim=768, sample_size=32)
+SD15_VAE = dict(in_channels=3, out_channels=3, latent_channels=4, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
+                norm_num_groups=32, scaling_factor=0.18215, act_fn="silu", sample_size=512)      # SD1.5 vae/config.json
 ALGORITHMIC_TFLOP_PER_STEP = 5.427     # SURVEY.md §8(d), (2,12,32x32)
 PEAK_BF16_TFLOPS = 2500.0              # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
+VAE_TFLOP_PER_CLIP = 7.47                # AutoencoderKL.decode of 12 x 256 x 256
+VAE_GB_PER_CLIP = 6.4
 
 
 def build_unet(device, rank, world, seed=0):
@@ -76,8 +80,63 @@ def synthetic_clip(device, seed, n=1):
     return [t.to(device) for t in (lat, text, audio, null_audio)]
 
 
+def build_id() -> str:
+    """sha256 over the kernel library and the tile table that produced the timed kernels (first 16 hex digits): lets a
+    PMC summary under profiles/ be tied to the build it was collected from."""
+    import hashlib
+
+    from asva_amd import _lib, ops
+
+    h = hashlib.sha256()
+    for path in (_lib.LIB_PATHS["bf16"], os.environ.get("AVSD_TILE_CACHE") or ops.DEFAULT_TILE_TABLE):
+        if path and os.path.isfile(path):
+            with open(path, "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` outside a launcher: re-executes itself as N ranks (one per GPU) under
+    torch.distributed.run on 127.0.0.1, with the dmabuf IPC mode RCCL needs on this host driver."""
+    import socket
+    import subprocess
+
+    if torch.cuda.device_count() < n:
+        raise SystemExit(f"--gpus {n} but only {torch.cuda.device_count()} GPU(s) are visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def vae_decode_leg(device, latents, reps=5):
+    """VAE decode of the clip each rank just denoised (pipeline_audio_cond_animation.py:206-213, :368-370): SD1.5
+    AutoencoderKL decoder, random-init weights, 12 x (4, 32, 32) latents -> 12 x (3, 256, 256), uint8 frames made on the
+    device.  Algorithmic work per clip: 7.47 TFLOP, >= 6.4 GB of HBM traffic."""
+    from asva_amd import dist as adist
+    from asva_amd.vae import AutoencoderKL
+
+    torch.manual_seed(1)
+    with torch.device(device):
+        vae = AutoencoderKL(**SD15_VAE).eval()
+    vae.decode_to_uint8_frames(latents)          # warm-up: packs the weights
+    torch.cuda.synchronize()
+    adist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        vae.decode_to_uint8_frames(latents)
+    torch.cuda.synchronize()
+    adist.barrier()
+    return time.perf_counter() - t0
+
+
 def cpu_baseline(unet, clip):
-    """Oracle (fp32 torch CPU restatement of the reference UNet) on the same CFG forward: 1 warm-up + 1 timed."""
+    """Oracle (fp32 torch CPU restatement of the reference UNet) on the same CFG forward: 1 warm-up + 3 timed, median
+    (BASELINE.md 4)."""
     from asva_amd.conditioning import audio_segment_mask
     from oracle.unet_ref import unet_forward
 
@@ -106,13 +165,14 @@ def cpu_baseline(unet, clip):
     cfg = dict(unet.config)
     times = []
     with torch.no_grad():
-        for _ in range(2):
+        for _ in range(4):
             t0 = time.perf_counter()
             unet_forward(sd, cfg, x, 981, txt, aud, mask)
             times.append(time.perf_counter() - t0)
-    return {"value": 1.0 / times[-1], "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": "oracle/unet_ref.py fp32 torch-CPU CFG UNet forward (B=2x12x32x32), 1 warm-up + 1 timed",
-            "seconds_per_step": times[-1]}
+    med = sorted(times[1:])[1]
+    return {"value": 1.0 / med, "unit": "steps/s", "cores": cores, "host_cores": os.cpu_count(), "kind": "port",
+            "sample": "oracle/unet_ref.py fp32 torch-CPU CFG UNet forward (B=2x12x32x32), 1 warm-up + 3 timed, median",
+            "seconds_per_step": med, "seconds_all": [round(t, 3) for t in times[1:]]}
 
 
 def main():
@@ -124,6 +184,7 @@ def main():
     ap.add_argument("--save-tiles", default="", help="write the autotuned tile table here (reload with AVSD_TILE_CACHE=<file>)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-vae", action="store_true", help="skip the VAE-decode leg")
     ap.add_argument("--clips-per-gpu", type=int, default=1,
                     help="independent clips batched into one UNet forward per GPU (BASELINE cfg 3 uses 4); "
                          "the default 1 is BASELINE cfg 2 / the reference's one-clip-per-call")
@@ -135,14 +196,21 @@ def main():
     from asva_amd.engine import DenoiseEngine
     from asva_amd.schedulers import DDIMScheduler
 
-    rank, local_rank, world = adist.env_rank_world()
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(a.gpus))         # one process per GPU; rank 0 of the child job prints the JSON line
+    rank, local_rank, world = adist.env_rank_world()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     adist.init_process_group("nccl")
+    import torch.distributed as tdist
+
+    world_observed = tdist.get_world_size() if tdist.is_initialized() else 1
+    if world_observed != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but the RCCL communicator has {world_observed} ranks")
 
     unet = build_unet(device, rank, world)
     cpg = a.clips_per_gpu
@@ -171,7 +239,10 @@ def main():
     gpu_ms = ev0.elapsed_time(ev1)
     finite = bool(torch.isfinite(latents).all())
 
-    rows = adist.gather_metrics([wall, gpu_ms, float(a.steps * cpg), float(finite)], device=device)
+    vae_wall, vae_reps = 0.0, 5
+    if not a.no_vae:
+        vae_wall = vae_decode_leg(device, latents, vae_reps)
+    rows = adist.gather_metrics([wall, gpu_ms, float(a.steps * cpg), float(finite), vae_wall], device=device)
     if rank != 0:
         return
     max_wall = max(r[0] for r in rows)
@@ -180,7 +251,7 @@ def main():
     ms_per_step = max_wall / a.steps * 1e3
     out = {
         "metric": "UNet denoising steps/sec, 12x256x256 bf16, CFG on",
-        "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "world_size_rccl": world_observed, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: AVSync15 shape, {cpg} clip(s) per GPU per forward, 12x256x256 (latent 12x32x32), "
@@ -192,7 +263,17 @@ def main():
         "all_finite": all(r[3] == 1.0 for r in rows),
         "step_tflops": round(ALGORITHMIC_TFLOP_PER_STEP * cpg / (ms_per_step * 1e-3), 2),
         "step_mfma_frac": round(ALGORITHMIC_TFLOP_PER_STEP * cpg / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS, 4),
+        "build_id": build_id(),
     }
+    if not a.no_vae:
+        vmax = max(r[4] for r in rows)
+        per_clip = vmax / (vae_reps * cpg)
+        out["vae_decode"] = {"clips_per_s": round(world * vae_reps * cpg / vmax, 2), "ms_per_clip": round(per_clip * 1e3, 3),
+                             "tflops": round(VAE_TFLOP_PER_CLIP / per_clip, 1), "gbs": round(VAE_GB_PER_CLIP / per_clip, 1),
+                             "frac_mfma": round(VAE_TFLOP_PER_CLIP / per_clip / PEAK_BF16_TFLOPS, 4),
+                             "frac_hbm": round(VAE_GB_PER_CLIP / per_clip / PEAK_HBM_GBS, 4),
+                             "workload": f"SD1.5 AutoencoderKL decoder, {12 * cpg} x (4,32,32) latents -> uint8 256x256 frames, "
+                                         f"{vae_reps} reps, random-init weights; 7.47 TFLOP and >= 6.4 GB per 12-frame clip (SURVEY 8d)"}
 
     if not a.no_roofline:
         timer = ops.KernelTimer()
@@ -222,7 +303,9 @@ def main():
                 tr = json.load(f)
             out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
             out["roofline"]["traffic_detail"] = {k: tr[k] for k in ("fetch_bytes_x2_per_launch", "write_bytes_per_launch",
-                                                                    "launches_profiled", "source") if k in tr}
+                                                                    "launches_profiled", "source", "build_id") if k in tr}
+            # the counters were collected from the build whose id the summary carries; say so when this run's differs
+            out["roofline"]["traffic_from_this_build"] = tr.get("build_id") == out["build_id"]
         out["roofline"]["algorithmic_bytes_per_launch"] = round(sum(f["bytes"] for f in mm) / launches)
         out["kernel_families"] = {
             k: {"launches": v["launches"], "ms": round(v["ms"], 4),

@@ -135,6 +135,41 @@ int avsd_gemm_bf16(const avsd_gemm_desc* desc_host, void* stream);
 /* sizeof(avsd_gemm_desc) as compiled: lets an FFI binding verify its mirror of the struct. */
 int avsd_sizeof_gemm_desc(void);
 
+/* ---- fused cross-attention block --------------------------------------------------------------------------------
+ * One launch per residual-stream update of the audio / text cross-attention of BasicTransformerBlock
+ * (ff_spatio_audio_temp_transformer_3d.py:315-341; diffusers Attention + AttnProcessor2_0):
+ *     out = res + to_out( softmax( (LayerNorm(h) Wq^T) K^T * scale ) V ) + o_bias
+ * h [M][C] is the 16-bit residual stream with its LayerNorm statistics `ln_stats` [M][C/32][2] as written by
+ * AVSD_GEMM_ROWSTATS; wq / q_colsum / q_bias are the LayerNorm-folded to_q of AVSD_GEMM_LNFUSE; `res` is h again (16-bit)
+ * or its f32 master (res_f32).  K / V are the step-invariant projections of the conditioning, cached by the host in the
+ * layout this kernel stages: k [nkv][lk_pad][C] (rows >= lk are padding) and vt [nkv][C][lk_pad] (V transposed), where
+ * rows [q*L, (q+1)*L) of h use block q / q_per_kv — for the audio branch the host gathers the keys the segment mask
+ * leaves visible per frame (segmask_imagebind.py:62-78,104-114), so masked keys are simply absent.
+ * Outputs like avsd_gemm_bf16: `out` 16-bit [M][ldo], optional `out_master` f32 and `rowstats` of the rounded output.
+ * Built for C = 320 with 8 heads (SD1.5 level 0) and lk_pad in {32, 64, 96}: avsd_cross_attention_block_supported()
+ * tells; other shapes run the three separate kernels. */
+typedef struct avsd_xattn_desc {
+  const void* h;        int32_t ldh;
+  int32_t res_f32;
+  const void* res;      int32_t ldres;
+  int32_t M, C, heads, L;
+  const float* ln_stats; float ln_eps;
+  float scale;
+  const void* wq;       int32_t ldwq;  int32_t lk;
+  const float* q_colsum;
+  const float* q_bias;
+  const void* k;        const void* vt;
+  int32_t lk_pad, q_per_kv;
+  const void* wo;       int32_t ldwo;  int32_t ldo;
+  const float* o_bias;
+  void* out;
+  float* out_master;    int32_t ldm;   int32_t reserved0;
+  float* rowstats;
+} avsd_xattn_desc;
+int avsd_cross_attention_block_supported(int C, int heads, int lk_pad);
+int avsd_cross_attention_block(const avsd_xattn_desc* desc_host, void* stream);
+int avsd_sizeof_xattn_desc(void);
+
 /* out[M, N] (f32) = act_out( act_in(x[M, K] f32) . W[N, K]^T + bias ), M <= 16.
  * act: 0 none, 1 SiLU.  Time-embedding MLP and the per-ResBlock time_emb_proj
  * (audio_cond_unet_3d_condition.py:673-680, ff_spatio_temp_resnet_3d.py:170), and the

@@ -150,6 +150,13 @@ def blocks_hip_legal():
                                                 audio_cross_attention_dim=768, norm_num_groups=32)
         fill_module_(m, "blk." + name + ".", round_bf16=True)
         g[name] = m(x, encoder_hidden_states=tx, audio_encoder_hidden_states=au, audio_attention_mask=mk).sample
+    # the same C = 320 transformer on an 8 x 16 latent: L = 128 rows per frame, the smallest the fused cross-attention kernel takes
+    x320w = seeded_randn_bf16(25, B, 320, Fr, 8, 16)
+    g["seeds"]["x320w"] = 25
+    m = FFSpatioAudioTempTransformer3DModel(8, 40, in_channels=320, num_layers=1, cross_attention_dim=768,
+                                            audio_cross_attention_dim=768, norm_num_groups=32)
+    fill_module_(m, "blk.tr_320.", round_bf16=True)
+    g["tr_320_wide"] = m(x320w, encoder_hidden_states=tx, audio_encoder_hidden_states=au, audio_attention_mask=mk).sample
     g = {k: (v.to(torch.float16) if torch.is_tensor(v) else v) for k, v in g.items()}     # outputs are O(1): 3e-4 rel rounding
     torch.save(g, os.path.join(OUT, "unet_blocks_hip.pt"))
     print("HIP-legal block goldens:", [k for k, v in g.items() if torch.is_tensor(v)])

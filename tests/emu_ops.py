@@ -149,6 +149,26 @@ def attention(q, k, v, *, bq, lq, lk, kv_rows, heads, q_per_kv, frames, key_inde
     return torch.cat(outs, 0).to(P.ACT)
 
 
+def cross_attention_block_supported(C, heads, lk_pad, M, L):
+    return C == 320 and heads == 8 and lk_pad in (32, 64, 96) and M % 128 == 0 and L % 128 == 0
+
+
+def cross_attention_block(h, stats, wq, q_colsum, q_bias, k, vt, lk, wo, o_bias, *, res, heads, L, q_per_kv, eps=1e-5, scale=None,
+                          rowstats=None, master=None, out=None):
+    """same rounding points as the fused kernel: q, P and o are rounded to the storage type"""
+    M, C = h.shape
+    d = C // heads
+    scale = d ** -0.5 if scale is None else scale
+    q = gemm(h, wq, bias=q_bias, ln=(stats, q_colsum, eps)).float().reshape(M // L, L, heads, d)
+    kv = torch.arange(M // L) // q_per_kv
+    kk = k[kv, :lk].float().reshape(M // L, lk, heads, d)
+    vv = vt[kv, :, :lk].float().reshape(M // L, heads, d, lk)
+    s = torch.einsum("blhd,bkhd->bhlk", q, kk) * scale
+    pr = torch.softmax(s, -1).to(P.ACT).float()
+    o = torch.einsum("bhlk,bhdk->blhd", pr, vv).reshape(M, C).to(P.ACT)
+    return gemm(o, wo, bias=o_bias, res1=res, rowstats=rowstats, master=master, out=out)
+
+
 def temporal_attention(qkv, *, b, frames, hw, heads, scale=None, out=None):
     C = qkv.shape[1] // 3
     d = C // heads

@@ -38,6 +38,7 @@ def gold():
     s = g["seeds"]
     B, Fr, H, W = g["B"], g["F"], g["H"], g["W"]
     g["in"] = {"x320": seeded_randn_bf16(s["x320"], B, 320, Fr, H, W), "x640": seeded_randn_bf16(s["x640"], B, 640, Fr, H, W),
+               "x320w": seeded_randn_bf16(s["x320w"], B, 320, Fr, 8, 16),
                "temb": seeded_randn_bf16(s["temb"], B, 1280), "text": seeded_randn_bf16(s["text"], B, 77, 768),
                "audio": seeded_randn_bf16(s["audio"], B, 229, 768)}
     return g
@@ -137,23 +138,30 @@ def test_resblock_matches_reference(gold, prec, f32_stream, name, cin, xkey):
 
 @pytest.mark.parametrize("f32_stream", [False, True])
 @pytest.mark.parametrize("fuse_ln", [True, False])
-@pytest.mark.parametrize("name,C,xkey", [("tr_320", 320, "x320"), ("tr_640", 640, "x640")])
+@pytest.mark.parametrize("name,C,xkey", [("tr_320", 320, "x320"), ("tr_640", 640, "x640"), ("tr_320_wide", 320, "x320w")])
 def test_transformer3d_matches_reference(gold, prec, f32_stream, fuse_ln, name, C, xkey):
+    """tr_320_wide (8 x 16 latent, L = 128) runs the audio and text cross-attentions through the one-launch
+    avsd_cross_attention_block when fuse_ln is on; the 8 x 8 cases use the three separate kernels."""
     from asva_amd import precision as P
     from asva_amd.conditioning import audio_segment_mask, mask_to_key_index
     from asva_amd.unet import AudioUNet3DConditionModel as M, _Act, _Pk, _Transformer3D
 
-    root = _pack(_Transformer3D(C, 768, 768), f"blk.{name}.", "tr")
+    root = _pack(_Transformer3D(C, 768, 768), "blk.tr_320." if name == "tr_320_wide" else f"blk.{name}.", "tr")
     Fr = gold["F"]
+    H, W = gold["in"][xkey].shape[-2:]
     text = gold["in"]["text"].to(P.ACT).cuda()
     audio = gold["in"]["audio"].to(P.ACT).cuda()
-    cond = M.make_cond_block(root.p, text, 1, audio, 1, Fr)
     idx = mask_to_key_index(audio_segment_mask(Fr)).cuda()
+    cond = M.make_cond_block(root.p, text, 1, audio, 1, Fr, idx, Fr)
     st = _state(gold, f32_stream, fuse_ln)
     st.cond = _Pk(blocks=[cond], key_index=idx, idx_frames=Fr, frames=Fr, batch=gold["B"])
-    out = M._transformer(st, _Act(_rows(gold["in"][xkey])), root.p, (gold["H"], gold["W"]), 8)
+    if name == "tr_320_wide" and fuse_ln:
+        from asva_amd import ops
+
+        assert cond.xa_text is not None and cond.xa_audio is not None and ops.cross_attention_block_supported(320, 8, 96, 2 * Fr * H * W, H * W)
+    out = M._transformer(st, _Act(_rows(gold["in"][xkey])), root.p, (H, W), 8)
     ref = gold[name].float()
-    err = rel_l2(_video(out.lo, gold["B"], Fr, gold["H"], gold["W"]), ref)
+    err = rel_l2(_video(out.lo, gold["B"], Fr, H, W), ref)
     print(f"{name} [{prec}, f32_stream={f32_stream}, fuse_ln={fuse_ln}]: rel-L2 vs reference {err:.3e}")
     assert err < TOL[prec]["tr"]
 

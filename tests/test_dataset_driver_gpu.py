@@ -1,0 +1,168 @@
+"""The reference's dataset driver end to end on the MI355X (-m gpu): SURVEY 8 rows P4 and (f)-1.
+
+`avgen.pipelines.pipeline_audio_cond_animation.generate_videos_for_dataset` is called with the reference's 12 keyword
+arguments (pipeline_audio_cond_animation.py:472-485) inside a scratch directory that holds everything the reference
+expects on disk, written by this test:
+
+  <exp_root>/ckpts/checkpoint-7/modules/unet/{config.json, diffusion_pytorch_model.safetensors}   (trainer layout, :516)
+  pretrained/stable-diffusion-v1-5/{tokenizer, text_encoder, scheduler, vae}/                     (SD1.5 layout, :508-513)
+  pretrained/openai-clip-l_null_text_encoding.pt          .checkpoints/imagebind_huge.pth         (ImageBind's own file)
+  datasets/AVSync15/{test.txt, class_mapping.json, class_clip_text_encodings_stable-diffusion-v1-5.pt, videos/...}
+
+Models are small and randomly filled (closed-form filler), the "videos" are pre-decoded .npz clips (no codec in this
+image).  Checked: the checkpoint directories load, every clip of every listed video is generated and written under
+<exp_root>/evaluations/checkpoint-7/AG-4.0_TG-1.0/seed-0/videos/<name>_clip-XX, and the frames equal the oracle pipeline
+(oracle/pipeline_ref.py + vae_ref.py) run on the same image latent / noise / audio encodings.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.filler import fill_module_
+from tests.helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+UNET_CFG = dict(block_out_channels=(80, 160, 160, 160), attention_head_dim=2, norm_num_groups=16, cross_attention_dim=768,
+                audio_cross_attention_dim=768, sample_size=8)
+VAE_CFG = dict(block_out_channels=(32, 64, 128, 128), layers_per_block=2, norm_num_groups=32, latent_channels=4, in_channels=3,
+               out_channels=3, scaling_factor=0.18215)
+STEPS, FRAMES, FPS, SIZE, NCLIPS = 4, 4, 2, (64, 64), 2
+
+
+def _write_tree(root):
+    from safetensors.torch import save_file
+    from tokenizers import pre_tokenizers
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTokenizer
+
+    from asva_amd.audio_encoder import ImageBindSegmaskAudioEncoder
+    from asva_amd.unet import AudioUNet3DConditionModel
+    from asva_amd.vae import AutoencoderKL
+
+    sd15 = root / "pretrained" / "stable-diffusion-v1-5"
+    chars = sorted(pre_tokenizers.ByteLevel.alphabet())
+    vocab = {}
+    for c in chars + [c + "</w>" for c in chars] + ["<|startoftext|>", "<|endoftext|>"]:
+        vocab[c] = len(vocab)
+    CLIPTokenizer(vocab=vocab, merges=[]).save_pretrained(str(sd15 / "tokenizer"))
+    CLIPTextModel(CLIPTextConfig(vocab_size=len(vocab), hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2,
+                                 max_position_embeddings=77, projection_dim=32)).save_pretrained(str(sd15 / "text_encoder"))
+    (sd15 / "scheduler").mkdir(parents=True)
+    (sd15 / "scheduler" / "scheduler_config.json").write_text(json.dumps({
+        "_class_name": "PNDMScheduler", "_diffusers_version": "0.6.0", "beta_end": 0.012, "beta_schedule": "scaled_linear",
+        "beta_start": 0.00085, "num_train_timesteps": 1000, "set_alpha_to_one": False, "skip_prk_steps": True, "steps_offset": 1,
+        "trained_betas": None, "clip_sample": False}))
+    vae = AutoencoderKL.from_config(VAE_CFG).eval()
+    fill_module_(vae)
+    vae.save_pretrained(str(sd15 / "vae"))
+    g = torch.Generator().manual_seed(5)
+    torch.save(torch.randn(1, 77, 768, generator=g), root / "pretrained" / "openai-clip-l_null_text_encoding.pt")
+    # ImageBind's own checkpoint file: the audio branch under ImageBind's module names (+ a tensor of another modality)
+    enc = ImageBindSegmaskAudioEncoder(n_segment=FRAMES)
+    ren = {"preprocessor.": "modality_preprocessors.audio.", "trunk.": "modality_trunks.audio.", "head.": "modality_heads.audio.",
+           "postprocessor.": "modality_postprocessors.audio."}
+    full = {"modality_trunks.vision.blocks.0.attn.in_proj_bias": torch.zeros(8)}
+    for k, v in enc.state_dict().items():
+        for old, new in ren.items():
+            if k.startswith(old):
+                full[new + k[len(old):]] = v.clone()
+    (root / ".checkpoints").mkdir()
+    torch.save(full, root / ".checkpoints" / "imagebind_huge.pth")
+    # the trained UNet as the reference trainer writes it (audio_cond_animation_trainer.py:152-155)
+    unet = AudioUNet3DConditionModel(**UNET_CFG).eval()
+    fill_module_(unet)
+    unet.save_pretrained(str(root / "exp" / "ckpts" / "checkpoint-7" / "modules" / "unet"))
+    # dataset: two categories, one pre-decoded clip each (3 s at 12 fps, 96 x 128 pixels; mono audio at 22.05 kHz)
+    ds = root / "datasets" / "AVSync15"
+    rng = np.random.default_rng(0)
+    names = ["dog/clip_a.npz", "cat/clip_b.npz"]
+    for n in names:
+        (ds / "videos" / n).parent.mkdir(parents=True, exist_ok=True)
+        base = rng.integers(0, 255, (1, 12, 16, 3), dtype=np.uint8)
+        frames = np.repeat(np.repeat(np.repeat(base, 36, 0), 8, 1), 8, 2)                     # (36, 96, 128, 3), smooth blocks
+        frames = (frames.astype(np.int32) + np.arange(36)[:, None, None, None] * 2).clip(0, 255).astype(np.uint8)
+        audio = (rng.standard_normal((1, 3 * 22050)) * 0.1).astype(np.float32)
+        np.savez(ds / "videos" / n, frames=frames, fps=12.0, audio=audio, audio_sr=22050)
+    (ds / "test.txt").write_text("\n".join(names) + "\n")
+    (ds / "class_mapping.json").write_text(json.dumps({"dog": "dog barking", "cat": "cat meowing"}))
+    torch.save({"dog barking": torch.randn(77, 768, generator=g), "cat meowing": torch.randn(77, 768, generator=g)},
+               ds / "class_clip_text_encodings_stable-diffusion-v1-5.pt")
+    return names
+
+
+def test_generate_videos_for_dataset_from_checkpoint_directories(tmp_path, monkeypatch):
+    import avgen.pipelines.pipeline_audio_cond_animation as ref_api
+    import asva_amd.pipeline as P
+    from asva_amd.audio_encoder import ImageBindSegmaskAudioEncoder
+    from asva_amd.data_utils import load_av_clips_uniformly
+    from asva_amd.unet import AudioUNet3DConditionModel
+    from asva_amd.vae import AutoencoderKL
+    from asva_amd.video_io import read_mjpeg_avi
+    from oracle import pipeline_ref
+
+    names = _write_tree(tmp_path)
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(P.AudioCondAnimationPipeline, "generation_steps", STEPS, raising=False)   # the driver hard-codes 50 (:442)
+    written = []
+    real_writer = P.write_video
+
+    def tap(filename, video_array, fps, audio_array=None, audio_fps=16000, audio_codec="aac"):
+        written.append((filename, video_array.clone(), fps, None if audio_array is None else tuple(audio_array.shape)))
+        return real_writer(filename, video_array, fps, audio_array, audio_fps, audio_codec)
+
+    monkeypatch.setattr(P, "write_video", tap)
+    dev = torch.device("cuda")
+    ref_api.generate_videos_for_dataset(exp_root="exp", checkpoint=7, dataset="AVSync15", image_size=SIZE, video_fps=FPS,
+                                        video_num_frame=FRAMES, num_clips_per_video=NCLIPS, audio_guidance_scale=4.0,
+                                        text_guidance_scale=1.0, random_seed=0, device=dev, dtype=torch.float32)
+    out_root = tmp_path / "exp" / "evaluations" / "checkpoint-7" / "AG-4.0_TG-1.0" / "seed-0" / "videos"
+    assert len(written) == len(names) * NCLIPS
+    for n in names:
+        for k in range(NCLIPS):
+            f = out_root / (n[:-4] + f"_clip-{k:02d}.avi")
+            assert f.is_file(), f
+            v, fps, a, afps = read_mjpeg_avi(str(f))
+            assert v.shape == (FRAMES, *SIZE, 3) and fps == FPS and a is not None and afps == 16000
+
+    # ---- oracle: the same clip through oracle/pipeline_ref.py on identical latents / noise / encodings -------------------
+    unet = AudioUNet3DConditionModel.from_pretrained("exp/ckpts/checkpoint-7/modules", subfolder="unet")
+    vae = AutoencoderKL.from_pretrained("pretrained/stable-diffusion-v1-5", subfolder="vae")
+    enc = ImageBindSegmaskAudioEncoder(n_segment=FRAMES, imagebind_checkpoint=ImageBindSegmaskAudioEncoder.IMAGEBIND_CKPT).to(dev).eval()
+    text = torch.load("datasets/AVSync15/class_clip_text_encodings_stable-diffusion-v1-5.pt")["dog barking"].view(1, 77, 768)
+    vids, auds = load_av_clips_uniformly(str(tmp_path / "datasets" / "AVSync15" / "videos" / names[0]), FPS, FRAMES, SIZE, NCLIPS,
+                                         load_audio_as_melspectrogram=False)
+    pipe = P.AudioCondAnimationPipeline(unet=unet.to(dev), scheduler=P.PNDMScheduler(), vae=vae.to(dev), audio_encoder=enc)
+    pipe.to(torch_device=dev)
+    mel = pipe.audio_processor([auds[0]], device=dev)
+    _, a_enc, a_mask = enc(mel, normalize=False, return_dict=False)
+    _, a_null, _ = enc(torch.zeros(1, 1, 128, 204, device=dev), normalize=False, return_dict=False)
+    # the driver seeds a device generator with random_seed for every clip (:433) and samples the image latent from the
+    # GLOBAL generator (:202): re-draw both on the device, then hand the very same numbers to the CPU oracle
+    gen = torch.Generator(device=dev).manual_seed(0)
+    noise = torch.randn((1, 4, FRAMES - 1, SIZE[0] // 8, SIZE[1] // 8), generator=gen, device=dev)
+    dist = vae.encode((vids[0][:1] * 2 - 1).to(dev)).latent_dist
+    lat0 = dist.mean * 0.18215                                              # compare on the distribution mean: no RNG
+    got = pipe(text_encodings=[text], video_length=FRAMES, height=SIZE[0], width=SIZE[1], num_inference_steps=STEPS,
+               audio_guidance_scale=4.0, image_latents=lat0, audio_encodings=a_enc, null_audio_encodings=a_null, audio_masks=a_mask,
+               noise=noise, output_latents=True)
+    sd = {k: v.float().cpu() for k, v in unet.state_dict().items()}
+    x0 = pipeline_ref.prepare_video_latents(lat0.cpu(), noise.cpu())
+    want = pipeline_ref.denoise(sd, dict(unet.config), x0, text, a_enc.float().cpu(), a_null.float().cpu(), a_mask[0].cpu() if a_mask.dim() == 3 else a_mask.cpu(),
+                                STEPS, 4.0, "pndm")
+    err = rel_l2(got, want)
+    print(f"dataset driver clip 0: denoised latents vs oracle pipeline rel-L2 {err:.3e}")
+    assert err < 5e-2
+    frames_or = pipeline_ref.decode({k: v.float().cpu() for k, v in vae.state_dict().items()}, VAE_CFG, want)
+    frames_hip = pipe.vae.decode_to_uint8_frames(got)[0].cpu()
+    want_u8 = (frames_or[0].permute(0, 2, 3, 1) * 255).to(torch.uint8)
+    diff = (frames_hip.int() - want_u8.int()).abs().float().mean().item()
+    print(f"dataset driver clip 0: uint8 frames vs oracle, mean abs difference {diff:.2f} / 255")
+    assert diff < 4.0
+    # the driver itself sampled the image latent, so its frames differ from the mean-latent run only through that sample:
+    # same shape, same first-frame statistics within the VAE's posterior spread
+    drv = written[0][1]
+    assert drv.shape == frames_hip.shape and drv.dtype == torch.uint8
+    assert abs(drv.float().mean().item() - frames_hip.float().mean().item()) < 25.0

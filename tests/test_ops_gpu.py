@@ -469,3 +469,63 @@ def test_vae_postprocess(ops):
     out = ops.vae_postprocess(rows, n, H, W)
     ref = (rows[:, :3].float().reshape(n, H, W, 3).permute(0, 3, 1, 2) / 2 + 0.5).clamp(0, 1)
     assert torch.allclose(out, ref, atol=1e-6)
+
+
+# ---- fused cross-attention block ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("f32_res", [False, True])
+@pytest.mark.parametrize("kind,lk,per_frame", [("audio", 25, True), ("audio4", 61, True), ("text", 77, False)])
+def test_cross_attention_block_matches_separate_kernels_and_fp32(ops, kind, lk, per_frame, f32_res):
+    """avsd_cross_attention_block (one launch) against (a) the three kernels it replaces — LayerNorm-folded Q projection,
+    attention over the gathered keys, output projection + residual — and (b) a plain fp32 statement of
+    h + to_out(softmax(LN(h) Wq K^T / sqrt(d)) V).  C = 320, 8 heads of 40, 2 clips x 3 frames x 256 rows."""
+    torch.manual_seed(0)
+    B, Fr, L, C, heads = 2, 3, 256, 320, 8
+    d = C // heads
+    M = B * Fr * L
+    a0 = rnd(M, C, seed=1)
+    w0 = rnd(C, C, seed=2, scale=C ** -0.5)
+    res0 = rnd(M, C, seed=3) + 0.5
+    stats = torch.empty(M, C // 32, 2, device=dev())
+    h = ops.gemm(a0, w0, res1=res0, rowstats=stats)                     # residual stream + its LayerNorm statistics
+    gamma, beta = 1 + 0.1 * rndf(C, seed=4), 0.1 * rndf(C, seed=5)
+    wq = rndf(C, C, seed=6, scale=C ** -0.5)
+    wq_f = (wq * gamma[None, :]).to(torch.bfloat16)
+    q_colsum, q_bias = wq_f.float().sum(1), wq @ beta
+    wo, bo = rnd(C, C, seed=7, scale=C ** -0.5), rndf(C, seed=8)
+    nkv = B * Fr if per_frame else B
+    lkp = (lk + 31) // 32 * 32
+    kk, vv = rnd(nkv, lk, C, seed=9), rnd(nkv, lk, C, seed=10)
+    k_pad = torch.zeros(nkv, lkp, C, dtype=torch.bfloat16, device=dev())
+    vt_pad = torch.zeros(nkv, C, lkp, dtype=torch.bfloat16, device=dev())
+    k_pad[:, :lk] = kk
+    vt_pad[:, :, :lk] = vv.transpose(1, 2)
+    q_per_kv = 1 if per_frame else Fr
+    master_in = h.float() + 1e-3 * rndf(M, C, seed=11) if f32_res else None      # an f32 master that differs from its 16-bit copy
+    res = master_in if f32_res else h
+    stats_out = torch.empty_like(stats)
+    master = torch.empty(M, C, device=dev()) if f32_res else None
+    out = ops.cross_attention_block(h, stats, wq_f, q_colsum, q_bias, k_pad, vt_pad, lk, wo, bo, res=res, heads=heads, L=L,
+                                    q_per_kv=q_per_kv, rowstats=stats_out, master=master)
+    # (a) the separate kernels
+    q = ops.gemm(h, wq_f, bias=q_bias, ln=(stats, q_colsum, 1e-5))
+    o = ops.attention(q, kk.reshape(nkv * lk, C), vv.reshape(nkv * lk, C), bq=B * Fr, lq=L, lk=lk, kv_rows=lk, heads=heads,
+                      q_per_kv=q_per_kv, frames=Fr)
+    stats_sep = torch.empty_like(stats)
+    sep = ops.gemm(o, wo, bias=bo, res1=res, rowstats=stats_sep)
+    # (b) fp32
+    hn = F.layer_norm(h.float(), (C,), gamma, beta, 1e-5)
+    qf = (hn @ wq.T).reshape(B * Fr, L, heads, d).transpose(1, 2)
+    kv_of = torch.arange(B * Fr, device=dev()) // q_per_kv
+    kf = kk.float()[kv_of].reshape(B * Fr, lk, heads, d).transpose(1, 2)
+    vf = vv.float()[kv_of].reshape(B * Fr, lk, heads, d).transpose(1, 2)
+    of = F.scaled_dot_product_attention(qf, kf, vf).transpose(1, 2).reshape(M, C)
+    ref = of @ wo.float().T + bo + res.float()
+    e_sep, e_ref = rel_l2(out, sep), rel_l2(out, ref)
+    print(f"cross_attention_block {kind} lk={lk} f32_res={f32_res}: vs separate kernels {e_sep:.3e}, vs fp32 {e_ref:.3e}")
+    assert e_sep < 3e-3 and e_ref < TOL_BF16
+    # attention-only part: subtracting the residual leaves to_out(attention) — compare that too (the residual dominates `out`)
+    assert rel_l2(out.float() - res.float(), ref - res.float()) < 2.5e-2
+    ob = out.float().reshape(M, C // 32, 32)
+    assert torch.allclose(stats_out[..., 0], ob.sum(-1), atol=1e-3, rtol=1e-5) and torch.allclose(stats_out[..., 1], (ob * ob).sum(-1), atol=1e-2, rtol=1e-5)
+    if f32_res:
+        assert rel_l2(master, ref) < 2e-3 and rel_l2(master.to(torch.bfloat16), out) < 1e-6

@@ -294,6 +294,8 @@ def test_oracle_matches_hip_legal_block_goldens():
     assert rel_l2(y, g["down_320"]) < tol
     up = F.interpolate(x320, scale_factor=(1.0, 2.0, 2.0), mode="nearest")
     assert rel_l2(unet_ref.ff_inflated_conv3d(up, sd_of(_Sampler(320), "up_320"), "up_320.conv"), g["up_320"]) < tol
-    for name, (C, x) in {"tr_320": (320, x320), "tr_640": (640, x640)}.items():
-        y = unet_ref.transformer_3d(x, text, audio, mask, sd_of(_Transformer3D(C, 768, 768), name), name, 8, 32)
+    x320w = seeded_randn_bf16(s["x320w"], B, 320, Fr, 8, 16)
+    for name, (C, x, wname) in {"tr_320": (320, x320, "tr_320"), "tr_640": (640, x640, "tr_640"), "tr_320_wide": (320, x320w, "tr_320")}.items():
+        sd = sd_of(_Transformer3D(C, 768, 768), wname)
+        y = unet_ref.transformer_3d(x, text, audio, mask, sd, wname, 8, 32)
         assert rel_l2(y, g[name]) < tol, name

@@ -27,5 +27,9 @@ out = {"hbm_bytes_per_launch": round(fb + wb), "fetch_bytes_x2_per_launch": roun
        "launches_profiled": len(gf),
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) -- python bench.py --no-graph "
                  "--steps 2 --warmup 1 --no-cpu-baseline --no-roofline, tuned tiles preloaded; tools/pmc_traffic.py"}
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+out["build_id"] = bench.build_id()      # ties the counters to the kernel library + tile table they were collected from
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(out)

@@ -578,7 +578,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm2_kernel(const avsd_g
     }
     return;
   }
-  epilogue<FN, FM>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
+  epilogue<FN, FM, (64 * (WM * WN + LW) > 512)>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
 }
 
 // out = epilogue(sum_s ws[s]) for split-K launches: one thread per 4 consecutive columns

@@ -127,7 +127,12 @@ __global__ __launch_bounds__(512, 2) void xattn_kernel(const XAttnArgs p) {
   {
     const float2* st = reinterpret_cast<const float2*>(p.ln_stats) + (int64_t)(row0 + a_row) * p.ln_nblk;
     float sm = 0.f, sq = 0.f;
-    for (int j = 0; j < p.ln_nblk; ++j) { const float2 t = st[j]; sm += t.x; sq += t.y; }
+    constexpr int NB = C / 32;               // all pairs of the row requested at once: one round trip, not NB
+    float2 t[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) t[j] = st[j];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) { sm += t[j].x; sq += t[j].y; }
     const float inv_k = 1.0f / (float)(p.ln_nblk * 32);
     const float mean = sm * inv_k;
     ln_rstd = rsqrtf(fmaxf(sq * inv_k - mean * mean, 0.f) + p.ln_eps);

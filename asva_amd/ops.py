@@ -515,8 +515,9 @@ def softmax_rows(s: torch.Tensor) -> torch.Tensor:
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, bq: int, lq: int, lk: int, kv_rows: int,
               heads: int, q_per_kv: int, frames: int, key_index: Optional[torch.Tensor] = None,
-              scale: Optional[float] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """q [bq*lq, heads*d]; k, v [(bq/q_per_kv)*kv_rows, >= heads*d] (views into a fused k|v buffer are fine)."""
+              scale: Optional[float] = None, out: Optional[torch.Tensor] = None, fp8: Optional[tuple] = None) -> torch.Tensor:
+    """q [bq*lq, heads*d]; k, v [(bq/q_per_kv)*kv_rows, >= heads*d] (views into a fused k|v buffer are fine).
+    fp8 = (q_scale, k_scale, v_scale): the e4m3 Q/K/V kernel (avsd_attention_fp8, BASELINE cfg 5) instead of the 16-bit one."""
     _req(q, P.ACT, "q")
     _req(k, P.ACT, "k")
     _req(v, P.ACT, "v")
@@ -530,9 +531,15 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, bq: int, lq:
     if scale is None:
         scale = float(d) ** -0.5
     ev = _TIMER.start() if _TIMER is not None else None
-    check(_lib.lib().avsd_attention(_p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(out), _ld(out), bq, lq, lk, kv_rows,
-                                    heads, d, q_per_kv, _p(key_index), frames, float(scale), _stream()),
-          "avsd_attention")
+    if fp8 is not None:
+        qs, ks, vs = (float(x) for x in fp8)
+        check(_lib.lib().avsd_attention_fp8(_p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(out), _ld(out), bq, lq, lk, kv_rows,
+                                            heads, d, q_per_kv, _p(key_index), frames, float(scale), qs, ks, vs, _stream()),
+              "avsd_attention_fp8")
+    else:
+        check(_lib.lib().avsd_attention(_p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(out), _ld(out), bq, lq, lk, kv_rows,
+                                        heads, d, q_per_kv, _p(key_index), frames, float(scale), _stream()),
+              "avsd_attention")
     if ev is not None:
         _TIMER.stop(ev, "attention", 4.0 * bq * heads * lq * lk * d, _nbytes(q, out) + 4.0 * (bq // q_per_kv) * lk * Cc)
     return out

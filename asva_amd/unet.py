@@ -41,6 +41,9 @@ _FUSE_LN = os.environ.get("AVSD_FUSE_LN", "1") != "0"    # fold LayerNorm 1 / au
 # Removes the ~100 chained roundings of the residual stream (the dominant error term of the 16-bit path) for one extra f32
 # write and a wider residual read per stream-producing GEMM.  Per model: `unet.f32_residual = True`.
 _F32_RES = os.environ.get("AVSD_F32_RESIDUAL", "0") != "0"
+# BASELINE cfg 5: e4m3 Q / K / V in the first-frame and cross attentions (avsd_attention_fp8), f32 softmax / accumulation.
+# Per model: `unet.fp8_attention = True` (optionally `unet.fp8_scales = (q, k, v)` per-tensor scales, default 1.0).
+_ATTN_FP8 = os.environ.get("AVSD_ATTN_FP8", "0") != "0"
 _FUSE_XATTN = os.environ.get("AVSD_FUSE_XATTN", "1") != "0"   # audio / text cross-attention as one launch where the kernel is built
 
 
@@ -880,7 +883,8 @@ class AudioUNet3DConditionModel(nn.Module):
         st = _Pk(B=B, F=Fr, temb=temb, temb_rows=(Fr if (t.numel() == B and B > 1) else B * Fr), cond=cond, tr_i=0,
                  groups=self.config.norm_num_groups, eps=float(self.config.norm_eps),
                  heads=_per_block(self.config.attention_head_dim, nblk), fuse_ln=getattr(self, "fuse_layernorm", _FUSE_LN),
-                 f32_stream=getattr(self, "f32_residual", _F32_RES))
+                 f32_stream=getattr(self, "f32_residual", _F32_RES),
+                 fp8=(tuple(getattr(self, "fp8_scales", (1.0, 1.0, 1.0))) if getattr(self, "fp8_attention", _ATTN_FP8) else None))
 
         h = _Act(ops.ncfhw_to_rows(x32, cpad=pk.conv_in.cin, rep=rep))
         hw = (H, W)
@@ -984,7 +988,7 @@ def _transformer(st, x: _Act, p, hw, heads) -> _Act:
         """h + to_out(attention(LN(h) Wq, cached K, V)): one launch where the fused kernel is built, else q-proj + attention
         + out-proj"""
         nonlocal si
-        if fused and xa is not None and ops.cross_attention_block_supported(C, heads, xa.k.shape[1], M, L):
+        if fused and st.fp8 is None and xa is not None and ops.cross_attention_block_supported(C, heads, xa.k.shape[1], M, L):
             m = _master(st, h.lo, C)
             s_in = stats[si]
             s_out = None
@@ -1013,7 +1017,7 @@ def _transformer(st, x: _Act, p, hw, heads) -> _Act:
         n1 = ops.layernorm(h.lo, p.norm1.g, p.norm1.b)
         q = ops.gemm(n1, a1.wq)
         kv = ops.gemm_batched(n1.view(B, Fr * L, C)[:, :L], a1.wkv.unsqueeze(0).expand(B, 2 * C, C)).view(B * L, 2 * C)
-    o = ops.attention(q, kv[:, :C], kv[:, C:], bq=B * Fr, lq=L, lk=L, kv_rows=L, heads=heads, q_per_kv=Fr, frames=Fr)
+    o = ops.attention(q, kv[:, :C], kv[:, C:], bq=B * Fr, lq=L, lk=L, kv_rows=L, heads=heads, q_per_kv=Fr, frames=Fr, fp8=st.fp8)
     h = stream(o, a1.wo, a1.bo, h)
     # 2. audio cross-attention: cached K/V, segment mask as a key gather (:315-325)
     if p.audio:
@@ -1025,7 +1029,7 @@ def _transformer(st, x: _Act, p, hw, heads) -> _Act:
             return ops.attention(q, c.audio_kv[:, :C], c.audio_kv[:, C:], bq=B * Fr, lq=L,
                                  lk=idx.shape[1] if idx is not None else c.audio_len, kv_rows=c.audio_len, heads=heads,
                                  q_per_kv=Fr if c.audio_pf == 1 else 1, frames=st.cond.idx_frames if idx is not None else Fr,
-                                 key_index=idx)
+                                 key_index=idx, fp8=st.fp8)
 
         h = cross(h, aa, p.norm_audio, getattr(c, "xa_audio", None), True, audio_attention)
     # 3. text cross-attention: cached K/V (:328-341)
@@ -1034,7 +1038,7 @@ def _transformer(st, x: _Act, p, hw, heads) -> _Act:
     def text_attention():
         q = proj(h, p.norm2, getattr(a2, "wq_ln", None), getattr(a2, "bq_ln", None), getattr(a2, "sq_ln", None), a2.wq)
         return ops.attention(q, c.text_kv[:, :C], c.text_kv[:, C:], bq=B * Fr, lq=L, lk=c.text_len, kv_rows=c.text_len,
-                             heads=heads, q_per_kv=Fr if c.text_pf == 1 else 1, frames=Fr)
+                             heads=heads, q_per_kv=Fr if c.text_pf == 1 else 1, frames=Fr, fp8=st.fp8)
 
     h = cross(h, a2, p.norm2, getattr(c, "xa_text", None), False, text_attention)   # norm_temp below is a kernel of its own
     # 4. temporal attention across frames per pixel; LN(h + pos[f]); residual is h itself (:346-358)

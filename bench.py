@@ -185,6 +185,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE-decode leg")
+    ap.add_argument("--fp8-attention", action="store_true",
+                    help="BASELINE cfg 5: e4m3 Q/K/V in the first-frame and cross attentions (f32 softmax / accumulation)")
+    ap.add_argument("--f32-residual", action="store_true", help="keep the residual stream in f32 (precision mode; slower)")
     ap.add_argument("--clips-per-gpu", type=int, default=1,
                     help="independent clips batched into one UNet forward per GPU (BASELINE cfg 3 uses 4); "
                          "the default 1 is BASELINE cfg 2 / the reference's one-clip-per-call")
@@ -213,6 +216,8 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but the RCCL communicator has {world_observed} ranks")
 
     unet = build_unet(device, rank, world)
+    unet.fp8_attention = a.fp8_attention
+    unet.f32_residual = a.f32_residual
     cpg = a.clips_per_gpu
     clip = synthetic_clip(device, seed=1000 + rank, n=cpg)
     lat, text, audio, null_audio = clip
@@ -253,7 +258,8 @@ def main():
         "metric": "UNet denoising steps/sec, 12x256x256 bf16, CFG on",
         "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "world_size_rccl": world_observed, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
+        "dtype": "bf16" + (" (fp8 e4m3 attention Q/K/V)" if a.fp8_attention else "") + (" + f32 residual stream" if a.f32_residual else ""),
+        "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: AVSync15 shape, {cpg} clip(s) per GPU per forward, 12x256x256 (latent 12x32x32), "
                                "SD1.5-shaped AudioUNet3D 1.17B params random-init, CFG batch 2 (audio guidance 4.0), "
                                "DDIM-50 schedule, step = UNet forward + guidance + scheduler update",

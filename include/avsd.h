@@ -223,6 +223,16 @@ int avsd_attention(const void* Q, int ldq, const void* K, int ldk, const void* V
                    void* O, int ldo, int Bq, int Lq, int Lk, int kv_rows, int heads, int d,
                    int q_per_kv, const int32_t* key_index, int frames, float scale, void* stream);
 
+/* FP8 (OCP e4m3) variant of avsd_attention — BASELINE.json configuration 5: Q, K, V and the probabilities are rounded to
+ * e4m3 and both matrix products run on v_mfma_f32_32x32x16_fp8_fp8; softmax, running statistics and accumulation stay
+ * f32.  Same tensors (16-bit in, 16-bit out), shapes and gather list as avsd_attention; q / k / v are multiplied by
+ * q_scale / k_scale / v_scale before rounding (1.0 = raw values; |x| <= 448 is representable) and the scales are folded
+ * back out.  Replaces the SDPA calls of utils.py:151-153 and ff_spatio_audio_temp_transformer_3d.py:315-341. */
+int avsd_attention_fp8(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
+                       int Bq, int Lq, int Lk, int kv_rows, int heads, int d, int q_per_kv,
+                       const int32_t* key_index, int frames, float scale, float q_scale, float k_scale,
+                       float v_scale, void* stream);
+
 /* Temporal self-attention across frames for every pixel
  * (ff_spatio_audio_temp_transformer_3d.py:352-358): qkv is [B*F*hw][ldqkv] with q|k|v at
  * column offsets 0, C, 2C; sequence (b, p) = rows {(b*F + f)*hw + p : f}. */

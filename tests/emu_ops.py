@@ -127,7 +127,7 @@ def softmax_rows(s):
     return torch.softmax(s, -1).to(P.ACT)
 
 
-def attention(q, k, v, *, bq, lq, lk, kv_rows, heads, q_per_kv, frames, key_index=None, scale=None, out=None):
+def attention(q, k, v, *, bq, lq, lk, kv_rows, heads, q_per_kv, frames, key_index=None, scale=None, out=None, fp8=None):
     C = q.shape[1]
     d = C // heads
     scale = scale if scale is not None else d ** -0.5

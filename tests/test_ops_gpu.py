@@ -529,3 +529,42 @@ def test_cross_attention_block_matches_separate_kernels_and_fp32(ops, kind, lk, 
     assert torch.allclose(stats_out[..., 0], ob.sum(-1), atol=1e-3, rtol=1e-5) and torch.allclose(stats_out[..., 1], (ob * ob).sum(-1), atol=1e-2, rtol=1e-5)
     if f32_res:
         assert rel_l2(master, ref) < 2e-3 and rel_l2(master.to(torch.bfloat16), out) < 1e-6
+
+
+# ---- FP8 (e4m3) Q/K/V attention: BASELINE cfg 5 -----------------------------------------------------------------------
+TOL_FP8 = 8e-2      # e4m3 keeps 3 mantissa bits (2^-4 relative rounding) on q, k, v and the probabilities; measured 4-6e-2
+
+
+@pytest.mark.parametrize("d,heads", [(40, 8), (64, 12), (80, 8), (128, 4), (160, 8)])
+@pytest.mark.parametrize("case", ["first_frame", "text", "audio_gather"])
+def test_attention_fp8_matches_bf16_kernel_and_fp32(ops, d, heads, case):
+    """avsd_attention_fp8 against the 16-bit kernel and an fp32 SDPA on the same inputs: first-frame layout (K/V of frame 0
+    shared by the frames of a clip), text cross-attention (77 keys) and the audio key gather (25 of 229 keys per frame)."""
+    B, Fr, C = 2, 3, d * heads
+    if case == "first_frame":
+        L, lk, kv_rows, q_per_kv, idx = 200, 200, 200, Fr, None
+    elif case == "text":
+        L, lk, kv_rows, q_per_kv, idx = 160, 77, 77, Fr, None
+    else:
+        L, lk, kv_rows, q_per_kv = 160, 25, 229, Fr
+        g = torch.Generator().manual_seed(5)
+        idx = torch.stack([torch.randperm(229, generator=g)[:lk].sort().values for _ in range(Fr)]).to(torch.int32).to(dev())
+    q = rnd(B * Fr * L, C, seed=1)
+    k, v = rnd(B * kv_rows, C, seed=2), rnd(B * kv_rows, C, seed=3)
+    kw = dict(bq=B * Fr, lq=L, lk=lk, kv_rows=kv_rows, heads=heads, q_per_kv=q_per_kv, frames=Fr, key_index=idx)
+    o16 = ops.attention(q, k, v, **kw)
+    o8 = ops.attention(q, k, v, fp8=(1.0, 1.0, 1.0), **kw)
+    qf = q.float().reshape(B, Fr, L, heads, d).permute(0, 1, 3, 2, 4)
+    kf = k.float().reshape(B, kv_rows, heads, d).permute(0, 2, 1, 3)
+    vf = v.float().reshape(B, kv_rows, heads, d).permute(0, 2, 1, 3)
+    outs = []
+    for f in range(Fr):
+        sel = idx[f].long() if idx is not None else torch.arange(lk, device=dev())
+        outs.append(F.scaled_dot_product_attention(qf[:, f], kf[:, :, sel], vf[:, :, sel]))
+    ref = torch.stack(outs, 1).permute(0, 1, 3, 2, 4).reshape(B * Fr * L, C)
+    e16, e8, e816 = rel_l2(o16, ref), rel_l2(o8, ref), rel_l2(o8, o16)
+    print(f"attention fp8 d={d} {case}: bf16 kernel vs fp32 {e16:.3e} | fp8 vs fp32 {e8:.3e} | fp8 vs bf16 kernel {e816:.3e}")
+    assert e16 < TOL_BF16 and e8 < TOL_FP8 and e816 < TOL_FP8
+    # per-tensor scales that are powers of two only shift exponents: same roundings, same result
+    o8s = ops.attention(q, k, v, fp8=(4.0, 0.5, 2.0), **kw)
+    assert rel_l2(o8s, o8) < 1e-2      # (values that fall into the subnormal range of e4m3 under one scaling and not the other round differently)

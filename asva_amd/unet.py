@@ -44,7 +44,45 @@ _F32_RES = os.environ.get("AVSD_F32_RESIDUAL", "0") != "0"
 # BASELINE cfg 5: e4m3 Q / K / V in the first-frame and cross attentions (avsd_attention_fp8), f32 softmax / accumulation.
 # Per model: `unet.fp8_attention = True` (optionally `unet.fp8_scales = (q, k, v)` per-tensor scales, default 1.0).
 _ATTN_FP8 = os.environ.get("AVSD_ATTN_FP8", "0") != "0"
-_FUSE_XATTN = os.environ.get("AVSD_FUSE_XATTN", "1") != "0"   # audio / text cross-attention as one launch where the kernel is built
+_FUSE_XATTN = os.environ.get("AVSD_FUSE_XATTN", "1") != "0"
+# Optional (AVSD_SIDE_STREAM=1): independent side work (ResBlock shortcut convolutions, the frame-0 K/V projection of the
+# spatial attention, the time-embedding MLP) on a second HIP stream, forked from and joined back into the main one — parallel
+# branches of the captured hipGraph.  Measured on MI355X: two whole B=1 forwards on two streams take 0.71x their sum
+# (tools/two_chain_probe.py), but these short branches cost more in cross-queue fork/join dependencies than they hide:
+# 74.5 vs 75.7 steps/s with them.  Off by default.
+_SIDE_STREAM = os.environ.get("AVSD_SIDE_STREAM", "0") != "0"
+
+
+class _Side:
+    """fork / join of a side stream; no-op without a CUDA device (CPU contract emulation) or when switched off"""
+
+    def __init__(self, enabled: bool):
+        self.on = bool(enabled) and torch.cuda.is_available() and not getattr(ops, "EMULATED", False)
+        self.stream = None
+        self.pending = False
+        self._ctx = None
+
+    def __enter__(self):
+        if not self.on:
+            return self
+        if self.stream is None:
+            self.stream = torch.cuda.Stream()
+        self.stream.wait_stream(torch.cuda.current_stream())          # fork: everything issued so far happens first
+        self._ctx = torch.cuda.stream(self.stream)
+        self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self._ctx.__exit__(*exc)
+            self._ctx = None
+            self.pending = True
+        return False
+
+    def join(self):
+        if self.on and self.pending:
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self.pending = False   # audio / text cross-attention as one launch where the kernel is built
 
 
 def _xa_fill(kv: torch.Tensor, n_kv: int, rows: int, C: int, idx: Optional[torch.Tensor], old=None):
@@ -874,13 +912,18 @@ class AudioUNet3DConditionModel(nn.Module):
             raise ValueError(f"conditioning was prepared for batch {cond.batch} x {cond.frames} frames, sample has {B} x {Fr}")
         if t.numel() not in (1, B):
             raise ValueError("timestep must be a scalar or have one entry per batch element")
-        # -- time embedding: sinusoid -> MLP -> all ResBlock time_emb_proj at once (:657-681, resnet :170)
+        side = getattr(self, "_side", None)
+        if side is None or side.on != (_SIDE_STREAM and torch.cuda.is_available() and not getattr(ops, "EMULATED", False)):
+            side = self._side = _Side(_SIDE_STREAM)
+        # -- time embedding: sinusoid -> MLP -> all ResBlock time_emb_proj at once (:657-681, resnet :170); on the side
+        #    stream: it only meets the main path at conv1's epilogue of the first ResBlock
         ch0 = self.config.block_out_channels[0]
-        e = ops.timestep_embedding(t, ch0)
-        e = ops.linear_small_m(e, pk.t1.w, pk.t1.b, act_out=True)
-        e = ops.linear_small_m(e, pk.t2.w, pk.t2.b)
-        temb = ops.linear_small_m(e, pk.temb_w, pk.temb_b, act_in=True)          # [1 or B, sum(Cout)]
-        st = _Pk(B=B, F=Fr, temb=temb, temb_rows=(Fr if (t.numel() == B and B > 1) else B * Fr), cond=cond, tr_i=0,
+        with side:
+            e = ops.timestep_embedding(t, ch0)
+            e = ops.linear_small_m(e, pk.t1.w, pk.t1.b, act_out=True)
+            e = ops.linear_small_m(e, pk.t2.w, pk.t2.b)
+            temb = ops.linear_small_m(e, pk.temb_w, pk.temb_b, act_in=True)          # [1 or B, sum(Cout)]
+        st = _Pk(B=B, F=Fr, side=side, temb=temb, temb_rows=(Fr if (t.numel() == B and B > 1) else B * Fr), cond=cond, tr_i=0,
                  groups=self.config.norm_num_groups, eps=float(self.config.norm_eps),
                  heads=_per_block(self.config.attention_head_dim, nblk), fuse_ln=getattr(self, "fuse_layernorm", _FUSE_LN),
                  f32_stream=getattr(self, "f32_residual", _F32_RES),
@@ -889,6 +932,7 @@ class AudioUNet3DConditionModel(nn.Module):
         h = _Act(ops.ncfhw_to_rows(x32, cpad=pk.conv_in.cin, rep=rep))
         hw = (H, W)
         h = _ffconv(st, h, pk.conv_in, hw)
+        side.join()                                # time embedding ready
         skips = [h]
         for i, blk in enumerate(pk.down):
             for j, r in enumerate(blk.resnets):
@@ -944,15 +988,17 @@ def _ffconv(st, x: _Act, p, hw, stride=1, ups=0, temb=None, res: Optional[_Act] 
 # that the reference torch.cat's onto x (unet_3d_blocks.py:358,1038) — never materialised here
 def _resblock(st, x: _Act, skip: Optional[_Act], p, hw) -> _Act:
     rows_b = st.F * hw[0] * hw[1]
+    if p.shortcut is not None:
+        with st.side:                                                    # independent of the main path until conv2's epilogue
+            s = _ffconv(st, x, p.shortcut, hw, x2=skip)
+    else:
+        assert skip is None
+        s = x
     a = ops.groupnorm(x.lo, None if skip is None else skip.lo, st.B, rows_b, st.groups, p.norm1.g, p.norm1.b, st.eps, True)
     tv = st.temb[:, p.temb_off:p.temb_off + p.cout]
     h = _ffconv(st, _Act(a), p.conv1, hw, temb=tv, master=False)         # feeds GroupNorm only
     a2 = ops.groupnorm(h.lo, None, st.B, rows_b, st.groups, p.norm2.g, p.norm2.b, st.eps, True)
-    if p.shortcut is not None:
-        s = _ffconv(st, x, p.shortcut, hw, x2=skip)
-    else:
-        assert skip is None
-        s = x
+    st.side.join()
     return _ffconv(st, _Act(a2), p.conv2, hw, res=s)
 
 
@@ -1010,9 +1056,11 @@ def _transformer(st, x: _Act, p, hw, heads) -> _Act:
     # 1. first-frame attention: Q from every frame, K/V projected for frame 0 only (utils.py:133-143)
     a1 = p.attn1
     if fused:
+        with st.side:                                                    # K/V of frame 0 beside the Q projection
+            kv = ops.gemm_batched(h.lo.view(B, Fr * L, C)[:, :L], a1.wkv_ln.unsqueeze(0).expand(B, 2 * C, C), bias=a1.bkv_ln,
+                                  ln=(stats[si], a1.skv_ln, eps)).view(B * L, 2 * C)
         q = ops.gemm(h.lo, a1.wq_ln, bias=a1.bq_ln, ln=(stats[si], a1.sq_ln, eps))
-        kv = ops.gemm_batched(h.lo.view(B, Fr * L, C)[:, :L], a1.wkv_ln.unsqueeze(0).expand(B, 2 * C, C), bias=a1.bkv_ln,
-                              ln=(stats[si], a1.skv_ln, eps)).view(B * L, 2 * C)
+        st.side.join()
     else:
         n1 = ops.layernorm(h.lo, p.norm1.g, p.norm1.b)
         q = ops.gemm(n1, a1.wq)

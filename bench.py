@@ -185,6 +185,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE-decode leg")
+    ap.add_argument("--also-clips", type=int, default=4,
+                    help="after the headline measurement, also time this many clips batched into one forward per GPU "
+                         "(BASELINE cfg 3 runs 4 per GPU); 0 = skip")
     ap.add_argument("--fp8-attention", action="store_true",
                     help="BASELINE cfg 5: e4m3 Q/K/V in the first-frame and cross attentions (f32 softmax / accumulation)")
     ap.add_argument("--f32-residual", action="store_true", help="keep the residual stream in f32 (precision mode; slower)")
@@ -318,6 +321,28 @@ def main():
                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
                 "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in fam.items()}
 
+    if a.also_clips and a.also_clips != cpg and world == 1:
+        # BASELINE cfg 3's per-GPU shape: several independent clips in one forward (UNet batch 2 x clips) — same kernels,
+        # 4x the rows per launch; reported next to the headline, never instead of it
+        n = a.also_clips
+        lat_b, text_b, audio_b, null_b = synthetic_clip(device, seed=2000, n=n)
+        eng_b = DenoiseEngine(unet, DDIMScheduler(), audio_guidance_scale=4.0, use_graph=not a.no_graph)
+        eng_b.set_conditioning(text_b, audio_b, null_b, audio_segment_mask(12), 12)
+        lb = lat_b.clone()
+        eng_b.prepare(lb, n_sched)
+        ks = max(10, a.steps // 2)
+        for i in range(5):
+            eng_b.step(lb, i)
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for i in range(ks):
+            eng_b.step(lb, (5 + i) % n_sched)
+        torch.cuda.synchronize()
+        tb = time.perf_counter() - tb
+        out["batched"] = {"clips_per_gpu": n, "unet_batch": 2 * n, "value": round(ks * n / tb, 3), "unit": "steps/s",
+                          "ms_per_forward": round(tb / ks * 1e3, 4), "steps": ks,
+                          "step_mfma_frac": round(ALGORITHMIC_TFLOP_PER_STEP * n / (tb / ks) / PEAK_BF16_TFLOPS, 4),
+                          "workload": f"BASELINE configs[2] per-GPU shape: {n} clips per forward"}
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(unet, clip)
         out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)

@@ -351,6 +351,221 @@ int launch_attn(const AttnArgs& a, int Bq, int heads, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// attn_wide_kernel<D>: single wide head (D = 512: the VAE mid-block attention, diffusers AutoencoderKL UNetMidBlock2D with
+// one head over all channels).  A 32-query block's output accumulator is D x 32 f32 = 256 registers per lane for one
+// wave, so the head dimension is split over the 4 waves of the workgroup instead of the queries: wave w owns channels
+// [w D/4, (w+1) D/4) for BOTH products.  Per 32-key tile every wave computes the partial scores of its channel slice,
+// the four partials meet in LDS and every wave sums them in the same order (identical S in all waves, so the softmax
+// decisions agree), then each wave accumulates P . V for its slice.  Flash-style: no L x L score matrix in memory
+// (the three-GEMM form wrote n L^2 f32 scores + as many 16-bit probabilities: 1.6 GB + 0.8 GB per 24-frame 512^2 chunk).
+template <int D>
+__global__ __launch_bounds__(256, 1) void attn_wide_kernel(const AttnArgs p) {
+  constexpr int NW = 4;
+  constexpr int DS = D / NW;               // channel slice of a wave
+  static_assert(DS % 32 == 0, "slice must be whole 32-channel output fragments");
+  constexpr int NCK = DS / 16;
+  constexpr int NDB = DS / 32;
+  constexpr int KS = D + 8;                // sK row stride (elements)
+  constexpr int VS = 32 + 4;               // sVt row stride (elements)
+  constexpr int KVEC = D / 8;
+  constexpr int KITEMS = 32 * KVEC;        // one 16-byte vector per item
+  constexpr int VITEMS = 16 * KVEC;        // the same 8 channels of two adjacent keys per item
+  constexpr int NKV = KITEMS / 256, NVV = VITEMS / 256;
+  static_assert(KITEMS % 256 == 0 && VITEMS % 256 == 0, "staging items must split evenly over 256 threads");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smw[];
+  h16_t* sK = reinterpret_cast<h16_t*>(smw);                       // [2][32][KS]
+  h16_t* sVt = sK + 2 * 32 * KS;                                    // [2][D][VS]
+  float* sS = reinterpret_cast<float*>(sVt + 2 * D * VS);           // [NW][64 lanes][16]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+  const int qb = blockIdx.z;
+  const int kb = qb / p.q_per_kv;
+  const int q = blockIdx.x * 32 + l31;
+  const int c0 = wave * DS;                // first channel of this wave's slice
+
+  h16x8 qf[NCK];
+  {
+    const h16_t* qrow = p.Q + ((int64_t)qb * p.Lq + min(q, p.Lq - 1)) * p.ldq + c0;
+#pragma unroll
+    for (int c = 0; c < NCK; ++c) qf[c] = __builtin_bit_cast(h16x8, *reinterpret_cast<const uint4*>(qrow + c * 16 + half * 8));
+  }
+  f32x16 acc_o[NDB];
+#pragma unroll
+  for (int b = 0; b < NDB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_o[b][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  const h16_t* Kb = p.K + (int64_t)kb * p.kv_rows * p.ldk;
+  const h16_t* Vb = p.V + (int64_t)kb * p.kv_rows * p.ldv;
+  const float sl2 = p.scale * 1.4426950408889634f;
+  const int ntiles = (p.Lk + 31) / 32;
+
+  uint4 rk[NKV], rv[NVV][2];
+  auto gload = [&](int t) {
+    t = min(t, ntiles - 1);
+#pragma unroll
+    for (int u = 0; u < NKV; ++u) {
+      const int v = tid + u * 256;
+      const int kk = min(t * 32 + v / KVEC, p.Lk - 1);
+      rk[u] = *reinterpret_cast<const uint4*>(Kb + (int64_t)kk * p.ldk + (v % KVEC) * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < NVV; ++u) {
+      const int v = tid + u * 256;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int kk = min(t * 32 + 2 * (v & 15) + h, p.Lk - 1);
+        rv[u][h] = *reinterpret_cast<const uint4*>(Vb + (int64_t)kk * p.ldv + (v >> 4) * 8);
+      }
+    }
+  };
+  auto lstore = [&](int st) {
+#pragma unroll
+    for (int u = 0; u < NKV; ++u) {
+      const int v = tid + u * 256;
+      const int key = v / KVEC;
+      *reinterpret_cast<uint4*>(sK + (st * 32 + key) * KS + (v - key * KVEC) * 8) = rk[u];
+    }
+#pragma unroll
+    for (int u = 0; u < NVV; ++u) {
+      const int v = tid + u * 256;
+      const int j = v & 15;
+      const int dv = (v >> 4) * 8;
+      const uint4 a = rv[u][0], b = rv[u][1];
+      uint32_t* dst = reinterpret_cast<uint32_t*>(sVt + (st * D + dv) * VS + 2 * j);
+      constexpr int RS = VS / 2;
+      dst[0 * RS] = __builtin_amdgcn_perm(b.x, a.x, 0x05040100u); dst[1 * RS] = __builtin_amdgcn_perm(b.x, a.x, 0x07060302u);
+      dst[2 * RS] = __builtin_amdgcn_perm(b.y, a.y, 0x05040100u); dst[3 * RS] = __builtin_amdgcn_perm(b.y, a.y, 0x07060302u);
+      dst[4 * RS] = __builtin_amdgcn_perm(b.z, a.z, 0x05040100u); dst[5 * RS] = __builtin_amdgcn_perm(b.z, a.z, 0x07060302u);
+      dst[6 * RS] = __builtin_amdgcn_perm(b.w, a.w, 0x05040100u); dst[7 * RS] = __builtin_amdgcn_perm(b.w, a.w, 0x07060302u);
+    }
+  };
+  gload(0);
+  lstore(0);
+  for (int t = 0; t < ntiles; ++t) {
+    const int st = t & 1;
+    __syncthreads();                     // stage st written; everybody is done with stage st ^ 1 and with sS
+    if (t + 1 < ntiles) gload(t + 1);    // in flight during this tile's matrix work
+    // ---- partial S^T[key][query] over this wave's channel slice ----
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCK; ++c) {
+      const h16x8 kf = *reinterpret_cast<const h16x8*>(sK + (st * 32 + l31) * KS + c0 + c * 16 + half * 8);
+      s = mfma32x32x16(kf, qf[c], s, 0, 0, 0);
+    }
+    float4* my = reinterpret_cast<float4*>(sS + (wave * 64 + lane) * 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) my[j] = make_float4(s[4 * j], s[4 * j + 1], s[4 * j + 2], s[4 * j + 3]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {        // fixed order w = 0..3: bit-identical totals in all four waves
+      float4 tot = reinterpret_cast<const float4*>(sS + (0 * 64 + lane) * 16)[j];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) {
+        const float4 o = reinterpret_cast<const float4*>(sS + (w * 64 + lane) * 16)[j];
+        tot.x += o.x; tot.y += o.y; tot.z += o.z; tot.w += o.w;
+      }
+      s[4 * j] = tot.x; s[4 * j + 1] = tot.y; s[4 * j + 2] = tot.z; s[4 * j + 3] = tot.w;
+    }
+    if ((t + 1 == ntiles) && (p.Lk & 31)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (t * 32 + key >= p.Lk) s[r] = -1e30f;
+      }
+    }
+    // ---- online softmax (as attn_kernel: log2 domain, lazy running max) ----
+    float pmax = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) pmax = fmaxf(pmax, s[r]);
+    const float mt = pmax * sl2;
+    if (__builtin_amdgcn_ballot_w64(mt > m_run + 8.f) != 0) {
+      const float m_new = fmaxf(m_run, fmaxf(mt, __shfl_xor(mt, 32, 64)));
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int b = 0; b < NDB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[b][r] *= alpha;
+    }
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -m_run));
+      psum += s[r];
+    }
+    l_run += psum;
+    h16x8 pf[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      uint4 v;
+      v.x = pack2h(s[8 * c + 0], s[8 * c + 1]);
+      v.y = pack2h(s[8 * c + 2], s[8 * c + 3]);
+      v.z = pack2h(s[8 * c + 4], s[8 * c + 5]);
+      v.w = pack2h(s[8 * c + 6], s[8 * c + 7]);
+      pf[c] = __builtin_bit_cast(h16x8, v);
+    }
+    // ---- O^T[channel][query] += V^T . P^T for this wave's channels ----
+#pragma unroll
+    for (int b = 0; b < NDB; ++b) {
+      const h16_t* vrow = sVt + (st * D + c0 + b * 32 + l31) * VS + 4 * half;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const uint2 lo = *reinterpret_cast<const uint2*>(vrow + 16 * c);
+        const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16 * c + 8);
+        acc_o[b] = mfma32x32x16(__builtin_bit_cast(h16x8, make_uint4(lo.x, lo.y, hi.x, hi.y)), pf[c], acc_o[b], 0, 0, 0);
+      }
+    }
+    if (t + 1 < ntiles) lstore(st ^ 1);
+  }
+  const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
+  if (q < p.Lq) {
+    h16_t* orow = p.O + ((int64_t)qb * p.Lq + q) * p.ldo + c0;
+#pragma unroll
+    for (int b = 0; b < NDB; ++b) {
+      unsigned x[2][2], y[2][2];
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const auto e = __builtin_amdgcn_permlane32_swap(pack2h(acc_o[b][2 * d] * inv, acc_o[b][2 * d + 1] * inv),
+                                                        pack2h(acc_o[b][8 + 2 * d] * inv, acc_o[b][8 + 2 * d + 1] * inv), false, false);
+        const auto o = __builtin_amdgcn_permlane32_swap(pack2h(acc_o[b][4 + 2 * d] * inv, acc_o[b][4 + 2 * d + 1] * inv),
+                                                        pack2h(acc_o[b][12 + 2 * d] * inv, acc_o[b][12 + 2 * d + 1] * inv), false, false);
+        x[0][d] = e[0]; x[1][d] = e[1];
+        y[0][d] = o[0]; y[1][d] = o[1];
+      }
+      h16_t* op = orow + b * 32 + 16 * half;
+      *reinterpret_cast<uint4*>(op) = make_uint4(x[0][0], x[0][1], x[1][0], x[1][1]);
+      *reinterpret_cast<uint4*>(op + 8) = make_uint4(y[0][0], y[0][1], y[1][0], y[1][1]);
+    }
+  }
+}
+
+template <int D>
+int launch_attn_wide(const AttnArgs& a, int Bq, hipStream_t s) {
+  constexpr size_t lds = (size_t)2 * 32 * (D + 8) * 2 + (size_t)2 * D * 36 * 2 + (size_t)4 * 64 * 16 * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_wide_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      avsd_set_error("attention (wide head): hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+      return AVSD_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_wide_kernel<D>), dim3((unsigned)((a.Lq + 31) / 32), 1, (unsigned)Bq), dim3(256), lds, s, a);
+  AVSD_CHECK_LAUNCH("attention (wide head) launch");
+  return AVSD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 struct TAttnArgs {
   const h16_t* QKV; h16_t* O;
   int ldqkv, ldo, frames, hw, heads;
@@ -516,7 +731,10 @@ extern "C" int avsd_attention(const void* Q, int ldq, const void* K, int ldk, co
     case 80: return launch_attn<80>(a, Bq, heads, s);
     case 128: return launch_attn<128>(a, Bq, heads, s);
     case 160: return launch_attn<160>(a, Bq, heads, s);
-    default: AVSD_REQUIRE(false, "attention: unsupported head dim %d (40/64/80/128/160)", d);
+    case 512:
+      AVSD_REQUIRE(heads == 1 && !key_index && (ldo % 8) == 0, "attention: head dim 512 is the single-head form (VAE mid block): heads == 1, no gather list, ldo %% 8 == 0");
+      return launch_attn_wide<512>(a, Bq, s);
+    default: AVSD_REQUIRE(false, "attention: unsupported head dim %d (40/64/80/128/160, or 512 with one head)", d);
   }
 }
 

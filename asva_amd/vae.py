@@ -314,6 +314,8 @@ class AutoencoderKL(nn.Module):
                        wqk=reg(pack_linear(torch.cat([at.to_q.weight, at.to_k.weight], 0).float())),
                        bqk=reg(torch.cat([at.to_q.bias, at.to_k.bias], 0).detach().float()),
                        wv=reg(pack_linear(at.to_v.weight.float())), bv=reg(at.to_v.bias.detach().float()),
+                       wqkv=reg(pack_linear(torch.cat([at.to_q.weight, at.to_k.weight, at.to_v.weight], 0).float())),
+                       bqkv=reg(torch.cat([at.to_q.bias, at.to_k.bias, at.to_v.bias], 0).detach().float()),
                        wo=reg(pack_linear(at.to_out[0].weight.float())), bo=reg(at.to_out[0].bias.detach().float()),
                        dim=at.to_q.weight.shape[0])
 
@@ -370,8 +372,10 @@ class AutoencoderKL(nn.Module):
         N, _, h, w = z.shape
         up = 2 ** (len(self.config.block_out_channels) - 1)
         if frames_per_chunk is None:
-            # largest activation: rows x 256 ch bf16 at full resolution (+ the mid attention scores, f32 HW x HW)
-            per_frame = max((h * up) * (w * up) * 256 * 2, (h * w) ** 2 * 4)
+            # largest activation: rows x 256 ch 16-bit at full resolution (the mid attention is flash-style at C = 512; the
+            # explicit form of other channel counts materialises f32 HW x HW scores)
+            mid_c = self.config.block_out_channels[-1]
+            per_frame = max((h * up) * (w * up) * 256 * 2, 0 if mid_c == 512 else (h * w) ** 2 * 4)
             frames_per_chunk = max(1, min(N, int((2 ** 31 - 1) // per_frame)))
         outs = []
         z32 = z.to(device=dev, dtype=torch.float32).contiguous()
@@ -407,10 +411,17 @@ class AutoencoderKL(nn.Module):
         return ops.gemm(a, p.conv2.w, bias=p.conv2.b, res1=s, mode=ops.CONV3, conv=(n, hw[0], hw[1], 1, 0))
 
     def _mid_attention(self, x, a, n, hw, groups):
-        """mid-block attention, one head of width C: S = QK^T/sqrt(C) (f32) -> softmax -> P V ; V^T comes straight out of
-        a GEMM with the roles swapped, and V's bias is added after P.V (softmax rows sum to 1)"""
+        """mid-block attention, one head of width C (diffusers UNetMidBlock2D: softmax(Q K^T / sqrt(C)) V per image): one
+        fused q|k|v projection, then the single-wide-head flash kernel (attn_wide_kernel: C = 512 split over the waves of a
+        workgroup) — no L x L score matrix in memory.  Channel counts that kernel is not built for (tiny test
+        configurations) take the explicit form: S = QK^T/sqrt(C) (f32) -> softmax -> P V; V^T comes straight out of a GEMM
+        with the roles swapped, and V's bias is added after P.V (softmax rows sum to 1)."""
         C, L = a.dim, hw[0] * hw[1]
         xn = ops.groupnorm(x, None, n, L, groups, a.norm.g, a.norm.b, 1e-6, False)
+        if C == 512:
+            qkv = ops.gemm(xn, a.wqkv, bias=a.bqkv)                                                   # [n*L, 3C]
+            o = ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], bq=n, lq=L, lk=L, kv_rows=L, heads=1, q_per_kv=1, frames=1)
+            return ops.gemm(o, a.wo, bias=a.bo, res1=x)
         qk = ops.gemm(xn, a.wqk, bias=a.bqk).view(n, L, 2 * C)
         s = ops.gemm_batched(qk[:, :, :C], qk[:, :, C:], alpha=float(C) ** -0.5, out_f32=True)      # [n, L, L]
         p = ops.softmax_rows(s.view(n * L, L)).view(n, L, L)

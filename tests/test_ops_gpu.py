@@ -568,3 +568,17 @@ def test_attention_fp8_matches_bf16_kernel_and_fp32(ops, d, heads, case):
     # per-tensor scales that are powers of two only shift exponents: same roundings, same result
     o8s = ops.attention(q, k, v, fp8=(4.0, 0.5, 2.0), **kw)
     assert rel_l2(o8s, o8) < 1e-2      # (values that fall into the subnormal range of e4m3 under one scaling and not the other round differently)
+
+
+@pytest.mark.parametrize("L", [1024, 200, 77])
+def test_attention_single_wide_head_512(ops, L):
+    """The VAE mid-block attention: one head over all 512 channels (attn_wide_kernel: the head dimension split over the four
+    waves of a workgroup, partial scores summed through LDS).  q | k | v as strided views of one fused projection."""
+    n, C = 3, 512
+    qkv = rnd(n * L, 3 * C, seed=1, scale=0.5)
+    o = ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], bq=n, lq=L, lk=L, kv_rows=L, heads=1, q_per_kv=1, frames=1)
+    f = qkv.float().reshape(n, L, 3, C)
+    ref = F.scaled_dot_product_attention(f[:, None, :, 0], f[:, None, :, 1], f[:, None, :, 2]).reshape(n * L, C)
+    err = rel_l2(o, ref)
+    print(f"attention d=512 one head, L={L}: rel-L2 vs fp32 {err:.3e}")
+    assert o.shape == (n * L, C) and err < TOL_BF16

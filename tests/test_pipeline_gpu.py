@@ -92,7 +92,10 @@ def test_pipeline_matches_oracle_pipeline(kind):
     print(f"{kind}: latents after {steps} steps rel-L2 {e1:.3e}; decoded video rel-L2 {e2:.3e}")
     assert e1 < 5e-2 and e2 < 5e-2
     assert vid.device.type == "cpu" and vid.shape == (1, f, 3, h * 8, w * 8)
-    # graph-replayed engine == eager reference-style loop on the same kernels
+    # tile selection is deterministic (committed table / static rule): the same call again is bit-identical
+    assert torch.equal(pipe(**kw, output_latents=True), lat)
+    # graph-replayed engine vs eager reference-style loop on the same UNet kernels: the guidance + scheduler arithmetic differs
+    # (one fused f32 kernel vs torch ops), the 1e-7 differences are amplified by the 16-bit roundings of the following steps
     pipe.use_engine = False
     lat2 = pipe(**kw, output_latents=True)
     assert rel_l2(lat2, lat) < 2e-2

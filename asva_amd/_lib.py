@@ -37,7 +37,7 @@ class GemmDesc(C.Structure):
         ("hs", C.c_int32), ("ws", C.c_int32), ("ho", C.c_int32), ("wo", C.c_int32),
         ("cin", C.c_int32), ("stride", C.c_int32), ("ups", C.c_int32), ("pad", C.c_int32),
         ("tile", C.c_int32),
-        ("split_k", C.c_int32), ("splitk_ws", c_void_p),
+        ("split_k", C.c_int32), ("splitk_ws", c_void_p), ("splitk_cnt", c_void_p),
         ("rowstats", c_void_p), ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("ln_nblk", C.c_int32), ("ln_eps", C.c_float),
         ("out_master", c_void_p), ("ldm", C.c_int32), ("reserved0", C.c_int32),
     ]

@@ -576,7 +576,49 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm2_kernel(const avsd_g
                 make_float4(acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]);
         }
     }
-    return;
+    if (p.splitk_cnt == nullptr) return;      // two-launch form: splitk_reduce_kernel folds the slabs
+    // ---- in-launch reduction by the last-arriving slice of this tile (cdna_hip_programming.md 5, split-K recipe): plain slab
+    // stores -> every wave drains -> barrier -> one lane: agent-scope release, drain again (the compiler may drop the wait
+    // behind buffer_wbl2), relaxed agent-scope ticket.  The slice that draws the last ticket acquires (one lane + barrier) and
+    // folds ALL slabs in slice order — the same f32 order as splitk_reduce_kernel, so both forms are bit-identical and
+    // independent of arrival order — then runs the epilogue.  It also zeroes the ticket word for the next launch on the
+    // stream (the words start at zero: ops allocates them once, zero-filled).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    volatile int* flag = reinterpret_cast<volatile int*>(smem2);     // the ring is dead; all LDS stays one object
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      *flag = __hip_atomic_fetch_add(p.splitk_cnt + wg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (*flag != nsplit - 1) return;
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(p.splitk_cnt + wg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < FN; ++a)
+#pragma unroll
+      for (int b = 0; b < FM; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    for (int sl = 0; sl < nsplit; ++sl) {
+      const float* slab = p.splitk_ws + (int64_t)sl * p.M * p.N;
+#pragma unroll
+      for (int b = 0; b < FM; ++b) {
+        const int m = min(tm * BM + wm * (BM / WM) + b * 32 + (lane & 31), p.M - 1);
+#pragma unroll
+        for (int a = 0; a < FN; ++a)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int n = min(tn * BN + wn * (BN / WN) + a * 32 + 8 * q + hsel, p.N - 4);
+            const float4 v = *reinterpret_cast<const float4*>(slab + (int64_t)m * p.N + n);
+            acc[a][b][4 * q] += v.x; acc[a][b][4 * q + 1] += v.y; acc[a][b][4 * q + 2] += v.z; acc[a][b][4 * q + 3] += v.w;
+          }
+      }
+    }
   }
   epilogue<FN, FM, (64 * (WM * WN + LW) > 512)>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
 }
@@ -681,7 +723,7 @@ int launch2(const avsd_gemm_desc& d, hipStream_t s) {
   dim3 grid((unsigned)(ntm * ntn), (unsigned)nsplit, (unsigned)d.batch);
   hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM, WN, STAGES, MODE, LW>), grid, dim3(64 * (WM * WN + LW)), lds, s, d);
   AVSD_CHECK_LAUNCH("gemm2 launch");
-  if (nsplit > 1) {
+  if (nsplit > 1 && d.splitk_cnt == nullptr) {
     const int64_t total = (int64_t)d.M * (d.N / 4);
     int64_t g = (total + 255) / 256;
     if (g > 2048) g = 2048;
@@ -825,6 +867,7 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
     AVSD_REQUIRE(!(d.flags & AVSD_GEMM_GEGLU) && d.batch == 1, "gemm: split_k cannot be combined with GEGLU or batching");
     AVSD_REQUIRE(d.tile >= 4 && d.tile <= 28, "gemm: split_k needs an LDS-direct tile (4..28), got %d", d.tile);
     AVSD_REQUIRE(d.split_k <= (d.K + 63) / 64, "gemm: split_k (%d) exceeds the number of K tiles", d.split_k);
+    AVSD_REQUIRE(!d.splitk_cnt || d.N % 32 == 0, "gemm: the in-launch split-K reduction needs N %% 32 == 0 (got %d)", d.N);
   }
   int tile = d.tile;
   // v2 tiles (>= 4) address A/W with 32-bit byte offsets: fall back to v1 for tensors >= 2 GiB

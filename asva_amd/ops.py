@@ -237,6 +237,23 @@ def _pick_tile(key, launch, candidates=TILE_CANDIDATES, warm=None):
     return best
 
 
+# Optional in-launch split-K reduction (avsd_gemm_desc.splitk_cnt, AVSD_SPLITK_INLAUNCH=1): one zero-filled ticket buffer per
+# device, shared by every launch (they are ordered on one stream; the last arriver of a tile leaves its word zero again).
+# Bit-identical to the separate splitk_reduce launch (tests/test_ops_gpu.py), 79 launches fewer per step — and slower on
+# MI355X: 70.8 vs 75.4 steps/s.  Every slice pays an agent-scope release that writes its freshly dirtied 64-KB slab back
+# (~6 us) and the last arriver reads the other slabs alone, against a 7-us reduce kernel that runs chip-wide.  Off by default.
+_SPLITK_INLAUNCH = os.environ.get("AVSD_SPLITK_INLAUNCH", "0") != "0"
+_SPLITK_TICKETS: dict = {}
+_SPLITK_MAX_TILES = 1 << 16
+
+
+def _splitk_tickets(device) -> torch.Tensor:
+    t = _SPLITK_TICKETS.get(device)
+    if t is None:
+        t = _SPLITK_TICKETS[device] = torch.zeros(_SPLITK_MAX_TILES, dtype=torch.int32, device=device)
+    return t
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -373,6 +390,10 @@ def gemm(
             if ws is None or ws.numel() < sk * M * N:
                 ws = torch.empty((sk * M * N,), dtype=F32, device=a.device)
             d.splitk_ws = _p(ws)
+            tiles = ((M + 63) // 64) * ((N + 63) // 64)
+            d.splitk_cnt = _p(_splitk_tickets(a.device)) if (_SPLITK_INLAUNCH and N % 32 == 0 and tiles <= _SPLITK_MAX_TILES) else None
+        else:
+            d.splitk_cnt = None
 
     if tile == 0:
         def _launch(t, sk):

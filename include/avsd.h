@@ -112,6 +112,10 @@ typedef struct avsd_gemm_desc {
    * Deterministic (no atomics).  split_k <= 1 disables it.  Not combinable with GEGLU or batch > 1. */
   int32_t split_k;
   float* splitk_ws;
+  /* optional: one zero-initialised int32 ticket per output tile (>= ceil(M/64) * ceil(N/64) words).  When given, the slice
+   * of a tile that arrives last folds the slabs itself (same order, same bits) and applies the epilogue: one launch instead
+   * of two; it leaves the words zero again.  Launches that share the words must be ordered on one stream. */
+  int32_t* splitk_cnt;
   /* LayerNorm folded into the GEMMs around it (ff_spatio_audio_temp_transformer_3d.py:300-371: every LayerNorm there
    * feeds linear layers only).  Producer side, AVSD_GEMM_ROWSTATS: besides `out`, the epilogue writes for every row m and
    * every 32-column block j the pair (sum, sum of squares) of the bf16-ROUNDED outputs to rowstats[(m * N/32 + j) * 2]

@@ -582,3 +582,36 @@ def test_attention_single_wide_head_512(ops, L):
     err = rel_l2(o, ref)
     print(f"attention d=512 one head, L={L}: rel-L2 vs fp32 {err:.3e}")
     assert o.shape == (n * L, C) and err < TOL_BF16
+
+
+@pytest.mark.parametrize("tile,split", [(6, 2), (6, 8), (25, 2), (25, 4), (20, 4), (9, 4), (24, 8), (4, 4), (7, 2), (26, 8)])
+def test_splitk_in_launch_reduction_is_bit_identical_and_never_stale(ops, tile, split):
+    """Split-K with the slabs folded by the last-arriving slice of each tile (one launch) against the two-launch form
+    (splitk_reduce_kernel): same slab order, so the results must be bit-identical.  40 rounds with fresh inputs through the
+    SAME workspace and ticket words (the allocator hands the block back), other work in flight on a second stream: a slab
+    line served stale from an L1 / L2 of the reducer, or a ticket left non-zero, shows up as a mismatch."""
+    M, N, K = 384, 1280, 3840
+    g = torch.Generator().manual_seed(1)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(dev())
+    bias = rndf(N, seed=2)
+    side = torch.cuda.Stream()
+    noise_a, noise_b = rnd(4096, 4096, seed=3), rnd(4096, 4096, seed=4)
+    for it in range(40):
+        a = (torch.randn(M, K, generator=g)).to(torch.bfloat16).to(dev())
+        res = (torch.randn(M, N, generator=g)).to(torch.bfloat16).to(dev())
+        with torch.cuda.stream(side):                      # uneven load beside the launches under test
+            ops.gemm(noise_a, noise_b, tile=6)
+        saved = ops._SPLITK_INLAUNCH
+        try:
+            ops._SPLITK_INLAUNCH = False
+            two = ops.gemm(a, w, bias=bias, res1=res, tile=tile, split_k=split)
+            ops._SPLITK_INLAUNCH = True
+            one = ops.gemm(a, w, bias=bias, res1=res, tile=tile, split_k=split)
+        finally:
+            ops._SPLITK_INLAUNCH = saved
+        assert torch.equal(one, two), f"round {it}: in-launch reduction differs from the two-launch form"
+        if it == 0:
+            ref = a.float() @ w.float().T + bias + res.float()
+            assert rel_l2(one, ref) < TOL_BF16
+    torch.cuda.synchronize()
+    assert int(ops._splitk_tickets(dev()).abs().sum()) == 0          # every ticket word is back to zero

@@ -70,7 +70,8 @@ class DenoiseEngine:
     def _capture(self, latents: torch.Tensor):
         # the graph bakes in the addresses of the conditioning cache: re-capture only when that was re-allocated
         # (new geometry); same-shape clips refresh it in place (AudioUNet3DConditionModel.set_conditioning)
-        key = (tuple(latents.shape), latents.device, self.unet._cond.version, id(self.unet._packed))
+        key = (tuple(latents.shape), latents.device, self.unet._cond.version, id(self.unet._packed),
+               tuple(sorted(getattr(self.unet._cond, "share", {}).items())))   # launch sequence depends on the shared prefix
         if self._graph is not None and self._graph_key == key:
             return
         self._x_static = torch.zeros_like(latents)

@@ -51,6 +51,16 @@ _FUSE_XATTN = os.environ.get("AVSD_FUSE_XATTN", "1") != "0"
 # (tools/two_chain_probe.py), but these short branches cost more in cross-queue fork/join dependencies than they hide:
 # 74.5 vs 75.7 steps/s with them.  Off by default.
 _SIDE_STREAM = os.environ.get("AVSD_SIDE_STREAM", "0") != "0"
+# Classifier-free-guidance branches that share latents, timestep AND text conditioning (audio-only guidance: text [t, t],
+# pipeline_audio_cond_animation.py:155) are identical until the first audio cross-attention: conv_in, the first ResBlock and the
+# first transformer's GroupNorm / proj_in / first-frame attention are computed once and replicated (the reference computes them
+# per branch on its torch.cat'ed batch).  14 launches run on half (a third) of the rows.
+_SHARE_PREFIX = os.environ.get("AVSD_SHARE_PREFIX", "1") != "0"
+
+
+def _replicate(a: "_Act", r: int) -> "_Act":
+    """rows of all branches = r copies of the shared rows, branch-major like torch.cat([latents] * r) (pure data movement)"""
+    return _Act(torch.cat([a.lo] * r), None if a.hi is None else torch.cat([a.hi] * r))
 
 
 class _Side:
@@ -771,6 +781,9 @@ class AudioUNet3DConditionModel(nn.Module):
                 idx_frames = m.shape[0]
         sig = (tuple(text.shape), text_pf, None if audio is None else tuple(audio.shape), audio_pf,
                None if key_index is None else tuple(key_index.shape), idx_frames, Fr)
+        nb = text.shape[0] // text_pf
+        # which branch counts r see the same text in all r batch chunks (once per clip; a host sync is fine here)
+        share = {r: bool(nb % r == 0 and all(torch.equal(text[: text.shape[0] // r], c) for c in text.chunk(r)[1:])) for r in (2, 3)}
         old = self._cond
         if old is not None and getattr(old, "sig", None) == sig:
             # same geometry as the previous clip: refresh the cached tensors IN PLACE so a captured hipGraph of the
@@ -779,6 +792,7 @@ class AudioUNet3DConditionModel(nn.Module):
             ab = None if audio is None else audio.reshape(-1, audio.shape[-1])
             if key_index is not None:
                 old.key_index.copy_(key_index)
+            old.share = share
             for tp, c in zip(self._transformers(pk), old.blocks):
                 ops.gemm(tb, tp.attn2.wkv, out=c.text_kv)
                 if tp.audio:
@@ -788,7 +802,7 @@ class AudioUNet3DConditionModel(nn.Module):
         blocks = [self.make_cond_block(tp, text, text_pf, audio, audio_pf, Fr, key_index, idx_frames) for tp in self._transformers(pk)]
         self._cond_version = getattr(self, "_cond_version", 0) + 1
         self._cond = _Pk(blocks=blocks, key_index=key_index, idx_frames=idx_frames, frames=Fr,
-                         batch=text.shape[0] // text_pf, sig=sig, version=self._cond_version)
+                         batch=text.shape[0] // text_pf, sig=sig, version=self._cond_version, share=share)
         return self._cond
 
     @staticmethod
@@ -929,7 +943,11 @@ class AudioUNet3DConditionModel(nn.Module):
                  f32_stream=getattr(self, "f32_residual", _F32_RES),
                  fp8=(tuple(getattr(self, "fp8_scales", (1.0, 1.0, 1.0))) if getattr(self, "fp8_attention", _ATTN_FP8) else None))
 
-        h = _Act(ops.ncfhw_to_rows(x32, cpad=pk.conv_in.cin, rep=rep))
+        # branches that are still identical (see _SHARE_PREFIX): run them once until the first audio cross-attention
+        pre = rep if (_SHARE_PREFIX and rep > 1 and t.numel() == 1 and getattr(cond, "share", {}).get(rep, False)
+                      and pk.down[0].attentions and pk.down[0].attentions[0].audio) else 1
+        st.B = B // pre
+        h = _Act(ops.ncfhw_to_rows(x32, cpad=pk.conv_in.cin, rep=rep // pre))
         hw = (H, W)
         h = _ffconv(st, h, pk.conv_in, hw)
         side.join()                                # time embedding ready
@@ -938,7 +956,10 @@ class AudioUNet3DConditionModel(nn.Module):
             for j, r in enumerate(blk.resnets):
                 h = _resblock(st, h, None, r, hw)
                 if blk.attentions:
-                    h = _transformer(st, h, blk.attentions[j], hw, st.heads[i])
+                    h = _transformer(st, h, blk.attentions[j], hw, st.heads[i], split=pre)
+                    if pre > 1:                    # the transformer left st.B at the full batch; the shared skip follows
+                        skips[0] = _replicate(skips[0], pre)
+                        pre = 1
                 skips.append(h)
             if blk.down is not None:
                 h = _ffconv(st, h, blk.down, hw, stride=2)
@@ -1004,7 +1025,9 @@ def _resblock(st, x: _Act, skip: Optional[_Act], p, hw) -> _Act:
 
 # FFSpatioAudioTempTransformer3DModel.forward + BasicTransformerBlock.forward
 # (ff_spatio_audio_temp_transformer_3d.py:94-158, :278-373)
-def _transformer(st, x: _Act, p, hw, heads) -> _Act:
+def _transformer(st, x: _Act, p, hw, heads, split: int = 1) -> _Act:
+    """split > 1: the rows hold ONE copy of `split` still-identical guidance branches (st.B = shared batch); everything up to
+    and including the first-frame attention runs on them, then the stream is replicated and st.B becomes the full batch."""
     B, Fr = st.B, st.F
     L = hw[0] * hw[1]
     C = p.dim
@@ -1067,6 +1090,14 @@ def _transformer(st, x: _Act, p, hw, heads) -> _Act:
         kv = ops.gemm_batched(n1.view(B, Fr * L, C)[:, :L], a1.wkv.unsqueeze(0).expand(B, 2 * C, C)).view(B * L, 2 * C)
     o = ops.attention(q, kv[:, :C], kv[:, C:], bq=B * Fr, lq=L, lk=L, kv_rows=L, heads=heads, q_per_kv=Fr, frames=Fr, fp8=st.fp8)
     h = stream(o, a1.wo, a1.bo, h)
+    if split > 1:          # the branches part here: audio (and, under dual guidance, text) conditioning differs from now on
+        h, x = _replicate(h, split), _replicate(x, split)
+        st.B = B = B * split
+        M = B * Fr * L
+        if fused:
+            cur = stats[si]
+            stats = [torch.empty((M, C // 32, 2), dtype=torch.float32, device=n.device) for _ in range(2)]
+            torch.cat([cur] * split, out=stats[si])
     # 2. audio cross-attention: cached K/V, segment mask as a key gather (:315-325)
     if p.audio:
         aa = p.attn_audio

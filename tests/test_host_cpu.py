@@ -115,6 +115,42 @@ def test_per_frame_conditioning_and_batch_masks(emulated):
     assert rel_l2(out, ref) < 3e-2
 
 
+def test_shared_guidance_prefix_is_exact(emulated, monkeypatch):
+    """Audio-only guidance feeds both branches the same latents, timestep and text (pipeline_audio_cond_animation.py:155):
+    the layers before the first audio cross-attention are computed once and replicated.  Replication is data movement, so
+    the result equals the per-branch computation exactly; branches with different text must not take the shortcut."""
+    from asva_amd import unet as U
+    from asva_amd.conditioning import audio_segment_mask
+
+    g = load_golden("unet_tiny_e2e.pt")
+    m = filled_unet(g["config"])
+    Fr = g["sample"].shape[2]
+    gen = torch.Generator().manual_seed(11)
+    lat = torch.randn(1, 4, Fr, *g["sample"].shape[3:], generator=gen)
+    text1 = torch.randn(1, g["text"].shape[1], g["text"].shape[2], generator=gen)
+    audio = torch.randn(2, Fr, 229, g["audio"].shape[-1], generator=gen)
+    t = torch.full((1,), 501.0)
+    calls = []
+    real = U._replicate
+    monkeypatch.setattr(U, "_replicate", lambda a, r: (calls.append(r), real(a, r))[1])
+
+    def run(text, share):
+        monkeypatch.setattr(U, "_SHARE_PREFIX", share)
+        m.set_conditioning(text, audio, audio_segment_mask(Fr) if g["mask"] is None else g["mask"], Fr)
+        return m.denoise_forward(lat, t, rep=2)
+
+    same = torch.cat([text1, text1])
+    a = run(same, True)
+    assert calls and all(r == 2 for r in calls)
+    n = len(calls)
+    b = run(same, False)
+    assert len(calls) == n and torch.equal(a, b)
+    diff = torch.cat([text1, torch.zeros_like(text1)])
+    c = run(diff, True)
+    assert len(calls) == n, "branches with different text must run the prefix per branch"
+    assert not torch.equal(a, c)
+
+
 def test_save_and_from_pretrained_roundtrip(tmp_path, emulated):
     from asva_amd.unet import AudioUNet3DConditionModel
 

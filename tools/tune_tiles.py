@@ -1,7 +1,7 @@
 """Produces asva_amd/tiles_gfx950.json: runs the BASELINE.json workloads once with the measuring tuner on
 (AVSD_AUTOTUNE=1 semantics, asva_amd/ops.py) and writes the chosen (tile, split_k) per GEMM shape.
 
-    python tools/tune_tiles.py [--out gpurun_out/tiles_gfx950.json] [--skip-cfg4]
+    python tools/tune_tiles.py [--out gpurun_out/tiles_gfx950.json] [--skip-cfg4] [--extend]
 
 Workloads: cfg 2 (one clip, CFG batch 2), cfg 3 (4 clips per forward), both with and without the f32 residual stream,
 conditioning K/V projections, the SD1.5 VAE decode / encode at 12 x 256 x 256, cfg 4 (24 x 64 x 64 latents + VAE 512^2),
@@ -14,7 +14,8 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("AVSD_TILE_CACHE", "/nonexistent")        # start from an empty table
+if "--extend" not in sys.argv:
+    os.environ.setdefault("AVSD_TILE_CACHE", "/nonexistent")    # start from an empty table (--extend: keep the shipped one, add what is missing)
 os.environ["AVSD_SIDE_STREAM"] = "0"                            # the measuring tuner times on one stream
 import torch  # noqa: E402
 
@@ -27,6 +28,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="gpurun_out/tiles_gfx950.json")
     ap.add_argument("--skip-cfg4", action="store_true")
+    ap.add_argument("--extend", action="store_true", help="keep the shipped table's entries; tune only the shapes it lacks")
     a = ap.parse_args()
     ops.set_autotune(True)
     dev = torch.device("cuda", 0)
@@ -38,11 +40,13 @@ def main():
         lat = torch.randn(n_clips, 4, frames, hw, hw, generator=g).to(dev)
         text = torch.randn(branches * n_clips, 77, 768, generator=g).to(dev)
         audio = torch.randn(branches * n_clips, 229, 768, generator=g).to(dev)
-        unet.set_conditioning(text, audio, audio_segment_mask(frames), frames)
         t = torch.full((1,), 501.0, device=dev)
-        for f32 in (False, True):
-            unet.f32_residual = f32
-            unet.denoise_forward(lat, t, rep=branches)
+        # per-branch text (dual guidance) and shared text (audio-only guidance: the prefix runs once, asva_amd/unet.py _SHARE_PREFIX)
+        for txt in ([text] if branches == 1 else [text, torch.cat([text[:n_clips]] * branches)]):
+            unet.set_conditioning(txt, audio, audio_segment_mask(frames), frames)
+            for f32 in (False, True):
+                unet.f32_residual = f32
+                unet.denoise_forward(lat, t, rep=branches)
         unet.f32_residual = False
         torch.cuda.synchronize()
         print(f"tuned ({branches * n_clips}, 4, {frames}, {hw}, {hw}): {len(ops.tile_cache())} shapes, {time.time() - t0:.0f} s", flush=True)

@@ -496,14 +496,8 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm2_kernel(const avsd_g
   const int chalf = lane >> 5;
 
   const int nk = max(kt1 - kt0, 0);
-  auto wait_stage = [&](int kt) {   // tiles kt+1 .. kt+STAGES-2 may stay in flight
-    if constexpr (STAGES == 3) {
-      if (kt + 1 < nk) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
-    } else if constexpr (STAGES == 4) {
-      if (kt + 2 < nk) wait_vmcnt<2 * LPT>(); else if (kt + 1 < nk) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
-    } else {   // STAGES == 2: the tile issued during the previous iteration must have landed
-      wait_vmcnt<0>();
-    }
+  auto wait_stage = [&](int kt) {   // tiles kt+1 .. kt+STAGES-2 may stay in flight (fewer at the end of the K range)
+    wait_tiles_ahead<STAGES - 2, LPT>(nk - 1 - kt);
   };
   if (is_loader) {
 #pragma unroll
@@ -768,6 +762,12 @@ int dispatch_tile(const avsd_gemm_desc& d, int tile, hipStream_t s) {
     case 26: return launch2<128, 128, 2, 4, 3, MODE, 2>(d, s);
     case 27: return launch2<256, 64, 4, 2, 3, MODE, 2>(d, s);
     case 28: return launch2<64, 320, 2, 2, 3, MODE, 2>(d, s);
+    // deep rings for the weight-streaming low-resolution layers (M = 384 / 1536, K up to 23040): what bounds them is the
+    // bytes in flight per CU against the ~2 us HBM round trip, so the ring takes all of LDS
+    case 29: return launch2<128, 128, 2, 4, 5, MODE>(d, s);     // 160 KB, 4 tiles (128 KB) in flight
+    case 30: return launch2<128, 128, 2, 4, 4, MODE>(d, s);     // 128 KB
+    case 31: return launch2<128, 256, 2, 4, 3, MODE>(d, s);     // 144 KB, weight-heavy tile
+    // (measured and dropped: 128x64 with a 6-deep ring, 128x128 x 5 with loader waves — never the tuner's pick)
     default: return launch<64, 64, MODE>(d, s);
   }
 }
@@ -865,7 +865,7 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
   if (d.split_k > 1) {
     AVSD_REQUIRE(d.splitk_ws != nullptr, "gemm: split_k needs a workspace");
     AVSD_REQUIRE(!(d.flags & AVSD_GEMM_GEGLU) && d.batch == 1, "gemm: split_k cannot be combined with GEGLU or batching");
-    AVSD_REQUIRE(d.tile >= 4 && d.tile <= 28, "gemm: split_k needs an LDS-direct tile (4..28), got %d", d.tile);
+    AVSD_REQUIRE(d.tile >= 4 && d.tile <= AVSD_GEMM_MAX_TILE, "gemm: split_k needs an LDS-direct tile (4..31), got %d", d.tile);
     AVSD_REQUIRE(d.split_k <= (d.K + 63) / 64, "gemm: split_k (%d) exceeds the number of K tiles", d.split_k);
     AVSD_REQUIRE(!d.splitk_cnt || d.N % 32 == 0, "gemm: the in-launch split-K reduction needs N %% 32 == 0 (got %d)", d.N);
   }
@@ -883,7 +883,7 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
       tile = (d.N > 64 && d.M > 2048) ? 2 : 3;
     }
   }
-  if (tile < 1 || tile > 28) tile = pick_tile(d.M, (d.flags & AVSD_GEMM_GEGLU) ? d.N : d.N, d.batch);
+  if (tile < 1 || tile > AVSD_GEMM_MAX_TILE) tile = pick_tile(d.M, (d.flags & AVSD_GEMM_GEGLU) ? d.N : d.N, d.batch);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (d.mode) {
     case AVSD_GEMM_PLAIN: return avsd_gemm_dispatch_plain(d, tile, s);

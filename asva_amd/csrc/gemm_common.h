@@ -527,6 +527,17 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("" ::: "memory");
 }
 
+// waits until at most min(MAXA, ahead) tiles of LPT loads each are still in flight (ahead is wave-uniform)
+template <int MAXA, int LPT>
+__device__ __forceinline__ void wait_tiles_ahead(int ahead) {
+  if constexpr (MAXA <= 0) {
+    wait_vmcnt<0>();
+  } else {
+    if (ahead >= MAXA) wait_vmcnt<MAXA * LPT>();
+    else wait_tiles_ahead<MAXA - 1, LPT>(ahead);
+  }
+}
+
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 

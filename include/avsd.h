@@ -82,6 +82,7 @@ int avsd_device_info(char* name_host, int len, int* num_cu_host);
 enum { AVSD_GEMM_PLAIN = 0, AVSD_GEMM_TMIX = 1, AVSD_GEMM_CONV3 = 2 };
 enum { AVSD_GEMM_GEGLU = 1, AVSD_GEMM_OUT_F32 = 2, AVSD_GEMM_GELU = 4, AVSD_GEMM_XCD_N = 8, AVSD_GEMM_ROWSTATS = 16,
        AVSD_GEMM_LNFUSE = 32, AVSD_GEMM_RES1_F32 = 64, AVSD_GEMM_RES2_F32 = 128 };
+#define AVSD_GEMM_MAX_TILE 31
 
 typedef struct avsd_gemm_desc {
   const void* A;        /* bf16 */
@@ -105,7 +106,7 @@ typedef struct avsd_gemm_desc {
   int32_t hs, ws, ho, wo, cin, stride, ups;
   int32_t pad;                          /* CONV3 top/left zero padding: 1 (symmetric "padding=1") or 0 (the VAE encoder's
                                            F.pad(0,1,0,1) + stride-2 conv); bottom/right reads beyond the image are zero */
-  int32_t tile;                         /* 0 = library heuristic; 1..3 register-staged tiles, 4..28 LDS-direct
+  int32_t tile;                         /* 0 = library heuristic; 1..3 register-staged tiles, 4..AVSD_GEMM_MAX_TILE LDS-direct
                                            tiles (see gemm.hip dispatch_tile) */
   /* split-K (LDS-direct tiles only): K is cut into split_k slices computed by separate workgroups that
    * store f32 partial tiles to splitk_ws[split_k][M][N]; a second launch reduces them and applies the epilogue.

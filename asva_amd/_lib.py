@@ -97,6 +97,23 @@ SIGNATURES = {
                                  c_void_p, c_int, c_float, c_float, c_void_p]),
     "avsd_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "avsd_vit_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "avsd_copy": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "avsd_xattn_pack_kv": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    # launch plans (asva_amd/plan.py records them; any host replays them)
+    "avsd_plan_bundle_load": (c_int, [C.c_char_p, C.POINTER(c_void_p)]),
+    "avsd_plan_bundle_free": (None, [c_void_p]),
+    "avsd_plan_bundle_num_buffers": (c_int, [c_void_p]),
+    "avsd_plan_bundle_buffer_bytes": (c_int64, [c_void_p, c_int]),
+    "avsd_plan_bundle_bind": (c_int, [c_void_p, c_int, c_void_p]),
+    "avsd_plan_bundle_num_regions": (c_int, [c_void_p]),
+    "avsd_plan_bundle_region": (c_int, [c_void_p, c_int, C.POINTER(C.c_char_p), C.POINTER(c_int), C.POINTER(c_int64), C.POINTER(c_int64),
+                                        C.POINTER(c_int)]),
+    "avsd_plan_bundle_find_region": (c_int, [c_void_p, C.c_char_p]),
+    "avsd_plan_bundle_num_plans": (c_int, [c_void_p]),
+    "avsd_plan_bundle_plan_name": (C.c_char_p, [c_void_p, c_int]),
+    "avsd_plan_bundle_find_plan": (c_int, [c_void_p, C.c_char_p]),
+    "avsd_plan_num_calls": (c_int, [c_void_p, c_int]),
+    "avsd_plan_run": (c_int, [c_void_p, c_int, c_void_p]),
 }
 
 _libs = {}

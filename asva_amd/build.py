@@ -16,11 +16,14 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libavsd_hip.so")
 # two builds of the same sources: bfloat16 storage (default) and IEEE-half storage (-DAVSD_F16=1), asva_amd/precision.py
 VARIANTS = {"bf16": ("", LIB, []), "fp16": ("_f16", os.path.join(HERE, "libavsd_hip_f16.so"), ["-DAVSD_F16=1"])}
-SOURCES = ["lib.hip", "attention.hip", "norm.hip", "elementwise.hip", "audio.hip", "xattn.hip", "attention_fp8.hip"]
+SOURCES = ["lib.hip", "attention.hip", "norm.hip", "elementwise.hip", "audio.hip", "xattn.hip", "attention_fp8.hip", "plan.hip"]
 # gemm.hip instantiates ~270 kernels: compiled as four translation units (one per A-loader mode + the entry point)
 GEMM_UNITS = 4
 HEADERS = [os.path.join(CSRC, "avsd_common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(HERE, "..", "include", "avsd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+PLAN_HOST = os.path.join(HERE, "plan_host")
 
 
 def _hipcc() -> str:
@@ -77,6 +80,10 @@ def build(verbose: bool = False, force: bool = False, variants=("bf16", "fp16"))
     for lib, objs, stale in links:
         if force or stale or _stale(lib, objs):
             run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
+    # the Python-free host of the launch plans (include/avsd.h "launch plans"): dlopens either library
+    host_src = os.path.join(HERE, "..", "tools", "plan_host.cpp")
+    if os.path.exists(host_src) and (force or _stale(PLAN_HOST, [host_src] + HEADERS)):
+        run([hipcc, "-O2", "-std=c++17", "-I", os.path.join(HERE, "..", "include"), host_src, "-ldl", "-o", PLAN_HOST])
     return LIB
 
 

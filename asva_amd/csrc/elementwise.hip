@@ -159,6 +159,33 @@ inline unsigned grid_for(int64_t n, int block) {
   return (unsigned)g;
 }
 
+// dst[r][i] = src[i], 16 bytes per thread per round: each vector is read once and written `rep` times
+__global__ void copy_rep_kernel(const uint4* src, uint4* dst, int64_t nvec, int rep) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint4 v = src[i];
+    for (int r = 0; r < rep; ++r) dst[(int64_t)r * nvec + i] = v;
+  }
+}
+
+// one thread per (block b, key slot j, 8-channel chunk): K rows copied as they are, V written transposed
+__global__ void xattn_pack_kv_kernel(const h16_t* kv, int rows, int C, const int32_t* idx, int n_frames, int nk, int lk,
+                                     h16_t* k_out, h16_t* vt_out, int lk_pad, int64_t total) {
+  const int c8n = C / 8;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int c8 = (int)(t % c8n);
+    const int j = (int)((t / c8n) % lk);
+    const int b = (int)(t / ((int64_t)c8n * lk));
+    const int n = idx ? b / n_frames : b;
+    const int key = idx ? idx[(b % n_frames) * nk + j] : j;
+    const h16_t* src = kv + ((int64_t)n * rows + key) * 2 * C + c8 * 8;
+    *reinterpret_cast<uint4*>(k_out + ((int64_t)b * lk_pad + j) * C + c8 * 8) = *reinterpret_cast<const uint4*>(src);
+    const uint4 v = *reinterpret_cast<const uint4*>(src + C);
+    const h16_t* ve = reinterpret_cast<const h16_t*>(&v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vt_out[((int64_t)b * C + c8 * 8 + e) * lk_pad + j] = ve[e];
+  }
+}
+
 }  // namespace
 
 extern "C" int avsd_ncfhw_to_rows(const float* src, void* dst, int B, int C, int F, int HW, int cpad, int rep,
@@ -236,5 +263,29 @@ extern "C" int avsd_vae_postprocess_u8(const void* src, int ld, void* dst, int N
   hipLaunchKernelGGL(vae_postprocess_u8_kernel, dim3(grid_for(n, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      (const h16_t*)src, ld, (uint8_t*)dst, n);
   AVSD_CHECK_LAUNCH("vae_postprocess_u8 launch");
+  return AVSD_OK;
+}
+
+extern "C" int avsd_copy(const void* src, void* dst, int64_t bytes, int rep, void* stream) {
+  AVSD_REQUIRE(src && dst && bytes > 0 && bytes % 16 == 0 && rep >= 1, "copy: need non-null pointers, bytes %% 16 == 0, rep >= 1");
+  AVSD_REQUIRE(((uintptr_t)src | (uintptr_t)dst) % 16 == 0, "copy: pointers must be 16-byte aligned");
+  const int64_t nvec = bytes / 16;
+  hipLaunchKernelGGL(copy_rep_kernel, dim3(grid_for(nvec, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     (const uint4*)src, (uint4*)dst, nvec, rep);
+  AVSD_CHECK_LAUNCH("copy launch");
+  return AVSD_OK;
+}
+
+extern "C" int avsd_xattn_pack_kv(const void* kv, int n_kv, int rows, int C, const int32_t* idx, int n_frames, int nk,
+                                  void* k_out, void* vt_out, int lk_pad, void* stream) {
+  AVSD_REQUIRE(kv && k_out && vt_out && n_kv > 0 && rows > 0 && C > 0 && C % 8 == 0, "xattn_pack_kv: bad arguments");
+  AVSD_REQUIRE(!idx || (n_frames > 0 && nk > 0 && nk <= rows), "xattn_pack_kv: a gather list needs n_frames > 0 and 0 < nk <= rows");
+  const int lk = idx ? nk : rows;
+  AVSD_REQUIRE(lk_pad >= lk, "xattn_pack_kv: lk_pad (%d) < keys per block (%d)", lk_pad, lk);
+  const int nb = idx ? n_kv * n_frames : n_kv;
+  const int64_t total = (int64_t)nb * lk * (C / 8);
+  hipLaunchKernelGGL(xattn_pack_kv_kernel, dim3(grid_for(total, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     (const h16_t*)kv, rows, C, idx, n_frames, nk, lk, (h16_t*)k_out, (h16_t*)vt_out, lk_pad, total);
+  AVSD_CHECK_LAUNCH("xattn_pack_kv launch");
   return AVSD_OK;
 }

@@ -767,6 +767,7 @@ int dispatch_tile(const avsd_gemm_desc& d, int tile, hipStream_t s) {
     case 29: return launch2<128, 128, 2, 4, 5, MODE>(d, s);     // 160 KB, 4 tiles (128 KB) in flight
     case 30: return launch2<128, 128, 2, 4, 4, MODE>(d, s);     // 128 KB
     case 31: return launch2<128, 256, 2, 4, 3, MODE>(d, s);     // 144 KB, weight-heavy tile
+    case 32: return launch2<256, 256, 2, 2, 2, MODE>(d, s);     // 128 KB, 4 waves with 128x128 wave tiles: 0.5 KB of LDS reads per MFMA
     // (measured and dropped: 128x64 with a 6-deep ring, 128x128 x 5 with loader waves — never the tuner's pick)
     default: return launch<64, 64, MODE>(d, s);
   }

@@ -93,7 +93,7 @@ class DenoiseEngine:
         if not self.use_graph:
             return self.unet.denoise_forward(latents, t_dev, rep=self.n_branch)
         self._capture(latents)
-        self._x_static.copy_(latents)
+        ops.copy(latents, self._x_static)
         self._t_static.copy_(t_dev)
         self._graph.replay()
         return self._noise_static
@@ -112,7 +112,7 @@ class DenoiseEngine:
         p: StepPlan = self._plans[i]
         noise = self.unet_step(latents, self._ts[i:i + 1])
         if p.save_sample:
-            self._saved.copy_(latents)
+            ops.copy(latents, self._saved)
         ops.guided_step(noise, self.n_branch, self.g, self._saved if p.use_saved_sample else latents, latents, p.ca, p.cb,
                         eps_hist=self._hist, store_slot=p.store_slot, w_cur=p.w_cur, hist_idx=p.hist_idx, w=p.hist_w, g2=self.g2)
 

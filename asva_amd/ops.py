@@ -650,6 +650,38 @@ def ncfhw_to_rows(x: torch.Tensor, cpad: int, rep: int = 1, scale: float = 1.0) 
     return out
 
 
+def copy(src: torch.Tensor, dst: Optional[torch.Tensor] = None, rep: int = 1) -> torch.Tensor:
+    """dst = `rep` copies of the contiguous tensor `src` along dim 0 (torch.cat([src] * rep)); with dst given, a device copy into
+    it.  A library launch instead of a torch op, so that it is part of a recorded launch plan (asva_amd/plan.py)."""
+    if not (src.is_cuda and src.is_contiguous()):
+        raise ValueError("copy: src must be a contiguous device tensor")
+    if dst is None:
+        dst = torch.empty((rep * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    nbytes = src.numel() * src.element_size()
+    if not dst.is_contiguous() or dst.numel() * dst.element_size() != rep * nbytes or nbytes % 16:
+        raise ValueError("copy: dst must be contiguous and hold rep x src (a multiple of 16 bytes)")
+    check(_lib.lib().avsd_copy(_p(src), _p(dst), nbytes, rep, _stream()), "avsd_copy")
+    return dst
+
+
+def xattn_pack_kv(kv: torch.Tensor, n_kv: int, rows: int, Cc: int, idx: Optional[torch.Tensor], k_out: torch.Tensor,
+                  vt_out: torch.Tensor) -> None:
+    """kv [n_kv*rows, 2C] -> k_out [nb, lk_pad, C], vt_out [nb, C, lk_pad] (operands of cross_attention_block); idx [F, nk]
+    int32 gathers the visible keys of each frame (nb = n_kv * F).  Padding columns are left as they are (zero-filled once)."""
+    _req(kv, P.ACT, "kv")
+    _req(k_out, P.ACT, "k_out")
+    _req(vt_out, P.ACT, "vt_out")
+    if idx is not None:
+        _req(idx, torch.int32, "idx")
+    nfr, nk = (idx.shape if idx is not None else (0, 0))
+    nb = n_kv * nfr if idx is not None else n_kv
+    lkp = k_out.shape[1]
+    if tuple(k_out.shape) != (nb, lkp, Cc) or tuple(vt_out.shape) != (nb, Cc, lkp) or not (kv.is_contiguous() and k_out.is_contiguous() and vt_out.is_contiguous()):
+        raise ValueError("xattn_pack_kv: k_out [nb, lk_pad, C] / vt_out [nb, C, lk_pad] expected, all contiguous")
+    check(_lib.lib().avsd_xattn_pack_kv(_p(kv), n_kv, rows, Cc, _p(idx), nfr, nk, _p(k_out), _p(vt_out), lkp, _stream()),
+          "avsd_xattn_pack_kv")
+
+
 def rows_to_ncfhw(rows: torch.Tensor, B: int, Cc: int, Fr: int, H: int, W: int) -> torch.Tensor:
     _req(rows, F32, "rows")
     out = torch.empty((B, Cc, Fr, H, W), dtype=F32, device=rows.device)

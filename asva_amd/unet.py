@@ -60,7 +60,7 @@ _SHARE_PREFIX = os.environ.get("AVSD_SHARE_PREFIX", "1") != "0"
 
 def _replicate(a: "_Act", r: int) -> "_Act":
     """rows of all branches = r copies of the shared rows, branch-major like torch.cat([latents] * r) (pure data movement)"""
-    return _Act(torch.cat([a.lo] * r), None if a.hi is None else torch.cat([a.hi] * r))
+    return _Act(ops.copy(a.lo, rep=r), None if a.hi is None else ops.copy(a.hi, rep=r))
 
 
 class _Side:
@@ -100,19 +100,40 @@ def _xa_fill(kv: torch.Tensor, n_kv: int, rows: int, C: int, idx: Optional[torch
     keys padded to whole 32-key tiles; with a per-frame gather list idx [F, nk] (audio segment mask) nb = n_kv * F blocks
     hold the visible keys of each frame.  Pure data movement, once per clip.  `old` is refreshed in place (a captured
     hipGraph holds its addresses).  None when more than 96 keys remain (the separate kernels handle that)."""
-    kv3 = kv.view(n_kv, rows, 2 * C)
-    if idx is not None:
-        kv3 = kv3[:, idx.long()].reshape(n_kv * idx.shape[0], idx.shape[1], 2 * C)
-    nb, lk = kv3.shape[:2]
+    nb, lk = (n_kv, rows) if idx is None else (n_kv * idx.shape[0], idx.shape[1])
     lkp = (lk + 31) // 32 * 32
     if lkp > 96:
         return None
     if old is None:
         old = _Pk(k=torch.zeros((nb, lkp, C), dtype=kv.dtype, device=kv.device),
                   vt=torch.zeros((nb, C, lkp), dtype=kv.dtype, device=kv.device), lk=lk)
-    old.k[:, :lk].copy_(kv3[..., :C])
-    old.vt[:, :, :lk].copy_(kv3[..., C:].transpose(1, 2))
+    ops.xattn_pack_kv(kv, n_kv, rows, C, idx, old.k, old.vt)
     return old
+
+
+_FRAME_INDEX: dict = {}
+_KEY_INDEX: dict = {}
+
+
+def key_index_for(mask: torch.Tensor, device) -> torch.Tensor:
+    """device copy of the per-frame list of visible audio keys of a (frames, keys) bool mask (conditioning.mask_to_key_index),
+    cached per mask: the same tensor for every clip of a geometry (a constant of a launch plan, asva_amd/plan.py)"""
+    key = (tuple(mask.shape), mask.numpy().tobytes(), str(device))
+    if key not in _KEY_INDEX:
+        if len(_KEY_INDEX) > 64:
+            _KEY_INDEX.clear()
+        _KEY_INDEX[key] = mask_to_key_index(mask).to(device)
+    return _KEY_INDEX[key]
+
+
+
+def frame_index(frames: int, device) -> torch.Tensor:
+    """[0, 1, .., frames-1] f32 on the device, kept alive: the input of the temporal position embedding (a constant a launch
+    plan ships with its bundle, asva_amd/plan.py)"""
+    key = (frames, str(device))
+    if key not in _FRAME_INDEX:
+        _FRAME_INDEX[key] = torch.arange(frames, dtype=torch.float32, device=device)
+    return _FRAME_INDEX[key]
 
 
 class FrozenConfig(dict):
@@ -777,7 +798,7 @@ class AudioUNet3DConditionModel(nn.Module):
                 else:
                     m = m.reshape(-1, m.shape[-1])          # per (b, f) lists; kernel indexes qb % (B*F)
             if not bool(m.all()):
-                key_index = mask_to_key_index(m).to(dev)
+                key_index = key_index_for(m, dev)
                 idx_frames = m.shape[0]
         sig = (tuple(text.shape), text_pf, None if audio is None else tuple(audio.shape), audio_pf,
                None if key_index is None else tuple(key_index.shape), idx_frames, Fr)
@@ -790,7 +811,7 @@ class AudioUNet3DConditionModel(nn.Module):
             # denoising step (which holds their addresses) stays valid
             tb = text.reshape(-1, text.shape[-1])
             ab = None if audio is None else audio.reshape(-1, audio.shape[-1])
-            if key_index is not None:
+            if key_index is not None and key_index is not old.key_index:
                 old.key_index.copy_(key_index)
             old.share = share
             for tp, c in zip(self._transformers(pk), old.blocks):
@@ -836,7 +857,7 @@ class AudioUNet3DConditionModel(nn.Module):
                 raise ValueError("audio_encoder_hidden_states is required by the audio cross-attention blocks")
             c.audio_kv = ops.gemm(audio.reshape(-1, audio.shape[-1]), tp.attn_audio.wkv)
             c.audio_len, c.audio_pf = audio.shape[1], audio_pf
-        ar = torch.arange(frames, dtype=torch.float32, device=text.device)
+        ar = frame_index(frames, text.device)
         emb = ops.timestep_embedding(ar, C)
         hid = ops.linear_small_m(emb, tp.pos1.w, tp.pos1.b, act_out=True)
         c.pos = ops.linear_small_m(hid, tp.pos2.w, tp.pos2.b)
@@ -1097,7 +1118,7 @@ def _transformer(st, x: _Act, p, hw, heads, split: int = 1) -> _Act:
         if fused:
             cur = stats[si]
             stats = [torch.empty((M, C // 32, 2), dtype=torch.float32, device=n.device) for _ in range(2)]
-            torch.cat([cur] * split, out=stats[si])
+            ops.copy(cur, stats[si], rep=split)
     # 2. audio cross-attention: cached K/V, segment mask as a key gather (:315-325)
     if p.audio:
         aa = p.attn_audio

@@ -390,17 +390,34 @@ class AutoencoderKL(nn.Module):
         """(b, 4, f, h, w) denoised latents -> (b, f, 3, H, W) f32 in [0, 1]: the whole post-processing of
         pipeline_audio_cond_animation.py:368-370 + :207-212 (1/scaling_factor, decode, x/2+0.5, clamp)."""
         b, c, f, h, w = latents.shape
-        z = latents.to(torch.float32).permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w) / self.config.scaling_factor
-        img = self.decode(z, postprocess=True).sample
+        img = self._decode_clip(latents, True)
+        if img is None:
+            z = latents.to(torch.float32).permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w) / self.config.scaling_factor
+            img = self.decode(z, postprocess=True).sample
         return img.reshape(b, f, *img.shape[1:])
 
     def decode_to_uint8_frames(self, latents: torch.Tensor) -> torch.Tensor:
         """(b, 4, f, h, w) denoised latents -> (b, f, H, W, 3) uint8 on the device (what generate_videos hands to
         the video writer, pipeline :448), without the f32 round trip."""
         b, c, f, h, w = latents.shape
-        z = latents.to(torch.float32).permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w) / self.config.scaling_factor
-        img = self.decode(z, postprocess="uint8").sample
+        img = self._decode_clip(latents, "uint8")
+        if img is None:
+            z = latents.to(torch.float32).permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w) / self.config.scaling_factor
+            img = self.decode(z, postprocess="uint8").sample
         return img.reshape(b, f, *img.shape[1:])
+
+    def _decode_clip(self, latents: torch.Tensor, postprocess):
+        """All frames of the clips in one pass, straight from the (b, 4, f, h, w) latents — every device operation is a
+        library launch (recordable as a launch plan, asva_amd/plan.py).  None when the frames need chunking."""
+        pk = self.pack()
+        b, c, f, h, w = latents.shape
+        up = 2 ** (len(self.config.block_out_channels) - 1)
+        mid_c = self.config.block_out_channels[-1]
+        per_frame = max((h * up) * (w * up) * 256 * 2, 0 if mid_c == 512 else (h * w) ** 2 * 4)
+        if b * f * per_frame > 2 ** 31 - 1:
+            return None
+        lat32 = latents.to(device=pk.blob.device, dtype=torch.float32).contiguous()
+        return self._decode_rows(pk, None, postprocess, latents5=lat32)
 
     def _res(self, x, p, n, hw, groups):
         L = hw[0] * hw[1]
@@ -429,10 +446,17 @@ class AutoencoderKL(nn.Module):
         o = ops.gemm_batched(p, vt, bias=a.bv).view(n * L, C)
         return ops.gemm(o, a.wo, bias=a.bo, res1=x)
 
-    def _decode_rows(self, pk, z32, postprocess=False):
-        n, c, h, w = z32.shape
+    def _decode_rows(self, pk, z32, postprocess=False, latents5=None):
+        """z32 (n, 4, h, w) f32, or latents5 (b, 4, f, h, w) f32 still multiplied by scaling_factor: the layout kernel then also
+        does the pipeline's permute + 1/scaling_factor (:207-209), and image b*f + i is frame i of clip b"""
         groups = self.config.norm_num_groups
-        x = ops.ncfhw_to_rows(z32.reshape(n, c, 1, h, w), cpad=8)
+        if latents5 is not None:
+            b, c, f, h, w = latents5.shape
+            n = b * f
+            x = ops.ncfhw_to_rows(latents5, cpad=8, scale=1.0 / self.config.scaling_factor)
+        else:
+            n, c, h, w = z32.shape
+            x = ops.ncfhw_to_rows(z32.reshape(n, c, 1, h, w), cpad=8)
         x = ops.gemm(x, pk.pq.w, bias=pk.pq.b)                                            # post_quant_conv 1x1
         hw = (h, w)
         x = ops.gemm(x, pk.conv_in.w, bias=pk.conv_in.b, mode=ops.CONV3, conv=(n, h, w, 1, 0))

@@ -33,7 +33,7 @@ extern "C" {
 #define AVSD_ELAUNCH (-2)  /* hipLaunch / runtime error                          */
 #define AVSD_ENODEV (-3)   /* no gfx950 device / wrong architecture              */
 
-#define AVSD_ABI_VERSION 3
+#define AVSD_ABI_VERSION 4
 
 /* ---- library ------------------------------------------------------------------------ */
 int avsd_abi_version(void);
@@ -82,7 +82,7 @@ int avsd_device_info(char* name_host, int len, int* num_cu_host);
 enum { AVSD_GEMM_PLAIN = 0, AVSD_GEMM_TMIX = 1, AVSD_GEMM_CONV3 = 2 };
 enum { AVSD_GEMM_GEGLU = 1, AVSD_GEMM_OUT_F32 = 2, AVSD_GEMM_GELU = 4, AVSD_GEMM_XCD_N = 8, AVSD_GEMM_ROWSTATS = 16,
        AVSD_GEMM_LNFUSE = 32, AVSD_GEMM_RES1_F32 = 64, AVSD_GEMM_RES2_F32 = 128 };
-#define AVSD_GEMM_MAX_TILE 31
+#define AVSD_GEMM_MAX_TILE 32
 
 typedef struct avsd_gemm_desc {
   const void* A;        /* bf16 */
@@ -299,6 +299,53 @@ int avsd_patchify(const float* src, void* dst, int B, int C, int H, int W, int k
  * tail rows = 0 (the add_bias_kv slot of the ImageBind audio trunk's attention).  cls [C], pos [1+n_patches][C] f32. */
 int avsd_vit_tokens(const void* patches, const float* cls, const float* pos, void* out, int B, int n_patches, int C,
                     int tail_rows, void* stream);
+
+/* ---- device copies: with these, everything a denoising step does on the device is an entry point of this library
+ *      (and therefore part of a launch plan, below) --------------------------------------------------------------------- */
+/* dst[r * bytes + i] = src[i] for r in [0, rep): a device-to-device copy (rep = 1), or the torch.cat([x] * rep) along the
+ * batch of guidance branches that are still identical (pipeline_audio_cond_animation.py:331-336).  bytes % 16 == 0. */
+int avsd_copy(const void* src, void* dst, int64_t bytes, int rep, void* stream);
+/* Cached cross-attention K|V rows  kv [n_kv * rows][2C] 16-bit  ->  the operand layout avsd_cross_attention_block stages:
+ * k_out [nb][lk_pad][C] and vt_out [nb][C][lk_pad].  Without a gather list (idx == NULL) nb = n_kv and block n holds keys
+ * 0..rows-1 of clip n; with idx [n_frames][nk] int32 (the visible keys of each frame under the audio segment mask,
+ * audio_attn_mask in segmask_imagebind.py:104-114) nb = n_kv * n_frames and block n * n_frames + f holds keys idx[f][:] of
+ * clip n.  Columns lk..lk_pad-1 (lk = nk or rows) are not written: the caller zero-fills the buffers once.  Once per clip. */
+int avsd_xattn_pack_kv(const void* kv, int n_kv, int rows, int C, const int32_t* idx, int n_frames, int nk,
+                       void* k_out, void* vt_out, int lk_pad, void* stream);
+
+/* ---- launch plans (a host without Python runs the path) ----------------------------------------------------
+ * A plan is the sequence of calls to the entry points above that one operation of the reference issues — the UNet forward
+ * of a denoising step (audio_cond_unet_3d_condition.py:598-798), the per-clip conditioning projections, the VAE decode
+ * (pipeline_audio_cond_animation.py:206-213) — for ONE geometry (network config, latent shape, guidance branches), with
+ * every device pointer expressed as (buffer, byte offset).  asva_amd/plan.py records plans from the Python host (which owns
+ * the network description) and writes a bundle: a buffer table shared by all its plans + the call lists.  Any host then
+ *   loads the bundle, allocates (or maps) the buffers, binds them, uploads weights and inputs, and calls avsd_plan_run:
+ * the same kernels with the same arguments as the recording run, so the results are bit-identical to the Python host's.
+ * tools/plan_host.cpp is such a host (C++, no Python, no torch).
+ * Memory model: the bundle's BUFFERS are the device allocations of the recording run (the caching allocator's segments, with
+ * their sizes); a replaying host allocates each one zero-filled and binds it.  Named REGIONS (buffer, offset, bytes, kind) say
+ * where in those buffers the things a host touches live: */
+enum { AVSD_REGION_CONST = 1,    /* weights and tables: contents ship with the bundle (<bundle>.d/<name>.bin); upload once */
+       AVSD_REGION_INPUT = 2,    /* written by the host before a run (latents, timestep, conditioning embeddings)         */
+       AVSD_REGION_OUTPUT = 3 }; /* read by the host after a run (noise prediction, decoded frames)                       */
+typedef struct avsd_plan_bundle avsd_plan_bundle;
+int avsd_plan_bundle_load(const char* path_host, avsd_plan_bundle** out_host);
+void avsd_plan_bundle_free(avsd_plan_bundle* b);
+int avsd_plan_bundle_num_buffers(const avsd_plan_bundle* b);
+int64_t avsd_plan_bundle_buffer_bytes(const avsd_plan_bundle* b, int i);                 /* -1 for a bad index */
+int avsd_plan_bundle_bind(avsd_plan_bundle* b, int i, void* device_ptr);               /* 256-byte aligned */
+int avsd_plan_bundle_num_regions(const avsd_plan_bundle* b);
+/* region j: its name (lives as long as the bundle), the buffer it is in, its byte offset and size, its kind */
+int avsd_plan_bundle_region(const avsd_plan_bundle* b, int j, const char** name_host, int* buffer_host, int64_t* offset_host,
+                            int64_t* bytes_host, int* kind_host);
+int avsd_plan_bundle_find_region(const avsd_plan_bundle* b, const char* name_host);    /* index, or -1 */
+int avsd_plan_bundle_num_plans(const avsd_plan_bundle* b);
+const char* avsd_plan_bundle_plan_name(const avsd_plan_bundle* b, int k);
+int avsd_plan_bundle_find_plan(const avsd_plan_bundle* b, const char* name_host);       /* index, or -1 */
+int avsd_plan_num_calls(const avsd_plan_bundle* b, int plan);
+/* Issues every call of plan `plan` on `stream`, in recording order.  All buffers the plan touches must be bound.
+ * Capturable in a hipGraph like the calls themselves. */
+int avsd_plan_run(avsd_plan_bundle* b, int plan, void* stream);
 
 #ifdef __cplusplus
 }

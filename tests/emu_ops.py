@@ -185,6 +185,23 @@ def ncfhw_to_rows(x, cpad, rep=1, scale=1.0):
     return out.repeat(rep, 1).to(P.ACT)
 
 
+def copy(src, dst=None, rep=1):
+    out = torch.cat([src] * rep) if rep > 1 else src.clone()
+    if dst is None:
+        return out
+    dst.copy_(out.reshape(dst.shape))
+    return dst
+
+
+def xattn_pack_kv(kv, n_kv, rows, C, idx, k_out, vt_out):
+    kv3 = kv.view(n_kv, rows, 2 * C)
+    if idx is not None:
+        kv3 = kv3[:, idx.long()].reshape(n_kv * idx.shape[0], idx.shape[1], 2 * C)
+    lk = kv3.shape[1]
+    k_out[:, :lk].copy_(kv3[..., :C])
+    vt_out[:, :, :lk].copy_(kv3[..., C:].transpose(1, 2))
+
+
 def rows_to_ncfhw(rows, B, C, Fr, H, W):
     return rows[:, :C].reshape(B, Fr, H, W, C).permute(0, 4, 1, 2, 3).contiguous()
 

@@ -27,7 +27,7 @@ def test_header_binding_and_library_agree():
             handle = _lib.lib()                                # raises if the .so is missing or a symbol is absent
             for name in declared:
                 assert hasattr(handle, name)
-            assert handle.avsd_abi_version() == 3
+            assert handle.avsd_abi_version() == 4
             assert handle.avsd_precision() == prec.encode()
             assert handle.avsd_sizeof_gemm_desc() == ctypes.sizeof(_lib.GemmDesc)
         finally:
@@ -56,3 +56,39 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 
     with pytest.raises(_lib.AvsdError, match="no fallback compute path"):
         _lib.lib()
+
+
+def test_plan_bundle_file_format_and_errors(tmp_path):
+    """The launch-plan loader (include/avsd.h "launch plans") without a device: a hand-written bundle parses, reports its
+    buffers and plans, refuses to run with an unbound buffer, and malformed / foreign files are rejected with a message."""
+    import struct
+
+    from asva_amd import _lib, plan
+
+    h = _lib.lib()
+
+    def s(b):
+        return struct.pack("<I", len(b)) + b
+
+    body = plan.MAGIC + struct.pack("<I", h.avsd_abi_version()) + b"bf16".ljust(8, b"\0")
+    body += struct.pack("<I", 2) + struct.pack("<q", 4096) + struct.pack("<q", 1 << 20)                      # two buffers
+    body += struct.pack("<I", 1) + s(b"weights") + struct.pack("<iqqI", 0, 256, 1024, plan.CONST)             # one region
+    call = s(b"avsd_copy") + struct.pack("<I", 5) + b"p" + struct.pack("<iq", 0, 256) + b"p" + struct.pack("<iq", 1, 512)
+    call += b"i" + struct.pack("<q", 1024) + b"i" + struct.pack("<q", 2) + b"S"
+    body += struct.pack("<I", 1) + s(b"forward") + struct.pack("<I", 1) + call
+    path = tmp_path / "t.plan"
+    path.write_bytes(body)
+    b = plan.Bundle(str(path))
+    assert b.buffer_sizes() == [4096, 1 << 20] and b.regions() == {"weights": (0, 256, 1024, plan.CONST)}
+    assert h.avsd_plan_bundle_find_region(b._h, b"weights") == 0 and h.avsd_plan_bundle_find_region(b._h, b"x") == -1
+    assert h.avsd_plan_bundle_num_plans(b._h) == 1 and h.avsd_plan_bundle_plan_name(b._h, 0) == b"forward"
+    assert h.avsd_plan_num_calls(b._h, 0) == 1 and h.avsd_plan_bundle_find_plan(b._h, b"decode") == -1
+    assert h.avsd_plan_run(b._h, 0, None) == -1 and b"buffer 0" in h.avsd_last_error() and b"not bound" in h.avsd_last_error()
+    b.close()
+    for bad, msg in ((b"garbage" * 8, b"not a plan bundle"), (body[:-3], b"truncated"),
+                     (body.replace(b"bf16", b"fp16", 1), b"other storage precision"),
+                     (body.replace(b"avsd_copy", b"avsd_nope"), b"does not record"),
+                     (body.replace(struct.pack("<iqqI", 0, 256, 1024, plan.CONST), struct.pack("<iqqI", 0, 4000, 1024, plan.CONST)), b"outside its buffer")):
+        path.write_bytes(bad)
+        out = ctypes.c_void_p()
+        assert h.avsd_plan_bundle_load(str(path).encode(), ctypes.byref(out)) == -1 and msg in h.avsd_last_error(), h.avsd_last_error()

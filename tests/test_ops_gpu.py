@@ -615,3 +615,39 @@ def test_splitk_in_launch_reduction_is_bit_identical_and_never_stale(ops, tile, 
             assert rel_l2(one, ref) < TOL_BF16
     torch.cuda.synchronize()
     assert int(ops._splitk_tickets(dev()).abs().sum()) == 0          # every ticket word is back to zero
+
+
+def test_copy_and_replicate(ops):
+    x = rnd(96, 40, seed=1)
+    assert torch.equal(ops.copy(x, rep=3), torch.cat([x] * 3))
+    f = rndf(24, 3, 8, seed=2)
+    dst = torch.empty(48, 3, 8, device=dev())
+    ops.copy(f, dst, rep=2)
+    assert torch.equal(dst, torch.cat([f, f]))
+    with pytest.raises(ValueError):
+        ops.copy(x[:, :8])                       # not contiguous
+    with pytest.raises(ValueError):
+        ops.copy(rnd(3, 3, seed=3))              # 18 bytes: not a multiple of 16
+
+
+@pytest.mark.parametrize("gather", [False, True])
+def test_xattn_pack_kv_matches_indexing(ops, gather):
+    """the K / V^T operand layout of the fused cross-attention block from cached K|V rows: plain (text, 77 keys) and through the
+    per-frame gather list of the audio segment mask"""
+    from asva_amd.conditioning import audio_segment_mask, mask_to_key_index
+
+    n_kv, C, Fr = 2, 320, 12
+    rows = 229 if gather else 77
+    kv = rnd(n_kv * rows, 2 * C, seed=5)
+    idx = mask_to_key_index(audio_segment_mask(Fr)).to(dev()) if gather else None
+    lk = idx.shape[1] if gather else rows
+    nb = n_kv * Fr if gather else n_kv
+    lkp = (lk + 31) // 32 * 32
+    k = torch.zeros(nb, lkp, C, dtype=kv.dtype, device=dev())
+    vt = torch.zeros(nb, C, lkp, dtype=kv.dtype, device=dev())
+    ops.xattn_pack_kv(kv, n_kv, rows, C, idx, k, vt)
+    kv3 = kv.view(n_kv, rows, 2 * C)
+    if gather:
+        kv3 = kv3[:, idx.long()].reshape(nb, lk, 2 * C)
+    assert torch.equal(k[:, :lk], kv3[..., :C]) and torch.equal(vt[:, :, :lk], kv3[..., C:].transpose(1, 2))
+    assert not k[:, lk:].any() and not vt[:, :, lk:].any()          # padding untouched

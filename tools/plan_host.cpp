@@ -11,6 +11,8 @@
 //                                              the loop of pipeline_audio_cond_animation.py:325-365 on buffer <latents>
 //                                              (f32, B x C x F x HW): per step  x <- latents, t <- steps[i].t, run "forward",
 //                                              guidance + scheduler update in place (avsd_guided_step), frame 0 pinned
+//                                              PLAN_HOST_GRAPH=1: the forward plan is captured once into a hipGraph and
+//                                              replayed (avsd_plan_run only issues launches on the stream it is given)
 //   copy <src> <dst> <bytes>                   device-to-device between regions
 //   save <region> <file>                       download a region to a file
 // <latents>, <x>, <t>, <noise> and the names after load / save / copy are REGION names of the bundle.
@@ -224,20 +226,41 @@ int main(int argc, char** argv) {
         return 1;
       }
       const int kf = plan("forward");
+      const char* genv = getenv("PLAN_HOST_GRAPH");
+      hipGraphExec_t gexec = nullptr;
+      if (genv && genv[0] == '1') {
+        AVSD_OK_OR_DIE(api.run(b, kf, stream));   // once eagerly: lazy module loading does not belong in a capture
+        HIP_OK(hipStreamSynchronize(stream));
+        hipGraph_t graph;
+        HIP_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        AVSD_OK_OR_DIE(api.run(b, kf, stream));
+        HIP_OK(hipStreamEndCapture(stream, &graph));
+        HIP_OK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+        HIP_OK(hipGraphDestroy(graph));
+      }
+      hipEvent_t e0, e1;
+      HIP_OK(hipEventCreate(&e0));
+      HIP_OK(hipEventCreate(&e1));
+      HIP_OK(hipEventRecord(e0, stream));
       for (size_t i = 0; i < n; ++i) {
         const Step& s = steps[i];
         AVSD_OK_OR_DIE(api.copy(latents, xp, lat_bytes, 1, stream));
         HIP_OK(hipMemcpyAsync(tp, &s.t, 4, hipMemcpyHostToDevice, stream));
-        AVSD_OK_OR_DIE(api.run(b, kf, stream));
+        if (gexec) HIP_OK(hipGraphLaunch(gexec, stream));
+        else AVSD_OK_OR_DIE(api.run(b, kf, stream));
         if (s.save_sample) AVSD_OK_OR_DIE(api.copy(latents, saved, lat_bytes, 1, stream));
         AVSD_OK_OR_DIE(api.guided_step(np_, n_branch, g, g2, hist, s.store_slot, s.w_cur,
                                        s.n_hist ? s.hist_idx : nullptr, s.n_hist ? s.hist_w : nullptr, s.n_hist,
                                        s.use_saved ? saved : latents, latents, s.ca, s.cb, B, Cc, Fr, HW, stream));
       }
+      HIP_OK(hipEventRecord(e1, stream));
       HIP_OK(hipStreamSynchronize(stream));
+      float ms = 0.f;
+      HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+      if (gexec) HIP_OK(hipGraphExecDestroy(gexec));
       HIP_OK(hipFree(hist));
       HIP_OK(hipFree(saved));
-      printf("plan_host: %zu denoising steps\n", n);
+      printf("plan_host: %zu denoising steps, %.3f ms per step (%s)\n", n, ms / (n ? n : 1), gexec ? "hipGraph replay" : "eager launches");
     } else if (cmd == "save") {
       std::string name, file;
       ss >> name >> file;

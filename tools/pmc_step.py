@@ -22,7 +22,7 @@ def fam(n):
     for key, name in (("gemm2", "gemm"), ("gemm1", "gemm"), ("splitk_reduce", "splitk_reduce"), ("xattn", "fused_cross_attention"),
                       ("mlp_", "fused_mlp"), ("attn_kernel", "attention"), ("attn_f8", "attention"), ("tattn", "temporal_attention"), ("gn_", "groupnorm"),
                       ("layernorm", "layernorm"), ("linear_small", "small"), ("guided", "small"), ("ncfhw", "small"),
-                      ("rows_to", "small"), ("timestep", "small")):
+                      ("rows_to", "small"), ("timestep", "small"), ("copy_rep", "small")):
         if key in k:
             return name
     return "other"

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Regenerates the round's measured evidence on the GPU box (run through gpurun from the repo root):
+#   bash tools/refresh_profiles.sh r2
+# Writes gpurun_out/<tag>_*; big rocprofv3 databases stay under /tmp on the box.  Copy the summaries into profiles/.
+set -x
+TAG=${1:-r2}
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+python bench.py > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/${TAG}_bench_n1.err
+cut -c1-300 gpurun_out/${TAG}_bench_n1.json
+BENCH="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-roofline --no-vae --also-clips 0"
+# kernel trace of the graph-replayed run
+(cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- $BENCH --steps 60 --warmup 5 > /tmp/kt.log 2>&1)
+KT=$(find /tmp/prof_kt -name "*.db" | head -1)
+python tools/prof_summary.py $KT > gpurun_out/${TAG}_kernel_trace_bench.md
+(cd tools && python step_timeline.py $KT --steps 50) > gpurun_out/${TAG}_step_timeline.md
+head -20 gpurun_out/${TAG}_step_timeline.md
+# PMC: three separate passes over eager steps
+for c in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
+  n=$(echo $c | cut -d' ' -f1)
+  (cd /tmp && rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$n -o p -- $BENCH --no-graph --steps 3 --warmup 1 > /tmp/pmc_$n.log 2>&1)
+done
+M=$(find /tmp/pmc_SQ_VALU_MFMA_BUSY_CYCLES -name "*.db" | head -1)
+F=$(find /tmp/pmc_FETCH_SIZE -name "*.db" | head -1)
+W=$(find /tmp/pmc_WRITE_SIZE -name "*.db" | head -1)
+python tools/pmc_step.py $M $F $W --skip 1 > gpurun_out/${TAG}_pmc_step.md
+cat gpurun_out/${TAG}_pmc_step.md
+python tools/pmc_traffic.py $F $W gpurun_out/pmc_traffic.json && cat gpurun_out/pmc_traffic.json

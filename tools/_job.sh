@@ -1,8 +1,6 @@
-set -x
 cd /root/repo
-python tools/export_plan.py --out /tmp/avsync15 --steps 50 2>&1 | tail -3
-ls -la /tmp/avsync15 /tmp/avsync15/clip.plan.d | head -30
-asva_amd/plan_host asva_amd/libavsd_hip.so /tmp/avsync15/clip.plan /tmp/avsync15/program.txt
-python tools/export_plan.py --check /tmp/avsync15
-PLAN_HOST_GRAPH=1 asva_amd/plan_host asva_amd/libavsd_hip.so /tmp/avsync15/clip.plan /tmp/avsync15/program.txt
-python tools/export_plan.py --check /tmp/avsync15
+python tools/tune_tiles.py --xcd-only --out gpurun_out/tiles_xcd.json > gpurun_out/tune_r2g.log 2>&1; tail -3 gpurun_out/tune_r2g.log
+for i in 1 2; do
+python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-vae --no-roofline --also-clips 4 | cut -c1-120
+AVSD_TILE_CACHE=gpurun_out/tiles_xcd.json python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-vae --no-roofline --also-clips 4 | cut -c1-120
+done

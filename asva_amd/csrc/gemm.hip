@@ -767,7 +767,10 @@ int dispatch_tile(const avsd_gemm_desc& d, int tile, hipStream_t s) {
     case 29: return launch2<128, 128, 2, 4, 5, MODE>(d, s);     // 160 KB, 4 tiles (128 KB) in flight
     case 30: return launch2<128, 128, 2, 4, 4, MODE>(d, s);     // 128 KB
     case 31: return launch2<128, 256, 2, 4, 3, MODE>(d, s);     // 144 KB, weight-heavy tile
-    case 32: return launch2<256, 256, 2, 2, 2, MODE>(d, s);     // 128 KB, 4 waves with 128x128 wave tiles: 0.5 KB of LDS reads per MFMA
+    // 96-row full-row tiles: the top-level layers (M = 24576 per clip, N = 320) are exactly ONE wave of 256 workgroups,
+    // each reads its activation rows once; 5 MFMA waves (96x64 each) + 2 loader waves
+    case 32: return launch2<96, 320, 1, 5, 3, MODE, 2>(d, s);   // 156 KB
+    case 33: return launch2<96, 320, 1, 5, 2, MODE, 2>(d, s);   // 104 KB
     // (measured and dropped: 128x64 with a 6-deep ring, 128x128 x 5 with loader waves — never the tuner's pick)
     default: return launch<64, 64, MODE>(d, s);
   }
@@ -866,7 +869,7 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
   if (d.split_k > 1) {
     AVSD_REQUIRE(d.splitk_ws != nullptr, "gemm: split_k needs a workspace");
     AVSD_REQUIRE(!(d.flags & AVSD_GEMM_GEGLU) && d.batch == 1, "gemm: split_k cannot be combined with GEGLU or batching");
-    AVSD_REQUIRE(d.tile >= 4 && d.tile <= AVSD_GEMM_MAX_TILE, "gemm: split_k needs an LDS-direct tile (4..31), got %d", d.tile);
+    AVSD_REQUIRE(d.tile >= 4 && d.tile <= AVSD_GEMM_MAX_TILE, "gemm: split_k needs an LDS-direct tile (4..33), got %d", d.tile);
     AVSD_REQUIRE(d.split_k <= (d.K + 63) / 64, "gemm: split_k (%d) exceeds the number of K tiles", d.split_k);
     AVSD_REQUIRE(!d.splitk_cnt || d.N % 32 == 0, "gemm: the in-launch split-K reduction needs N %% 32 == 0 (got %d)", d.N);
   }

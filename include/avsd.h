@@ -82,7 +82,7 @@ int avsd_device_info(char* name_host, int len, int* num_cu_host);
 enum { AVSD_GEMM_PLAIN = 0, AVSD_GEMM_TMIX = 1, AVSD_GEMM_CONV3 = 2 };
 enum { AVSD_GEMM_GEGLU = 1, AVSD_GEMM_OUT_F32 = 2, AVSD_GEMM_GELU = 4, AVSD_GEMM_XCD_N = 8, AVSD_GEMM_ROWSTATS = 16,
        AVSD_GEMM_LNFUSE = 32, AVSD_GEMM_RES1_F32 = 64, AVSD_GEMM_RES2_F32 = 128 };
-#define AVSD_GEMM_MAX_TILE 32
+#define AVSD_GEMM_MAX_TILE 33
 
 typedef struct avsd_gemm_desc {
   const void* A;        /* bf16 */

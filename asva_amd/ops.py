@@ -151,10 +151,18 @@ def _heuristic_tile(M: int, N: int, K: int, geglu: bool, splitk_ok: bool):
     def tiles(bm, bn):
         return ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
 
-    for tile, bm, bn in ((18, 256, 256), (20, 256, 128), (6, 128, 128), (24, 128, 64)):
-        if tiles(bm, bn) >= 224:
-            return tile, 1
     nk = (K + 63) // 64
+    # measured (profiles/r2_probes.md, tools/tile_probe.py): 256x128 wins once it fills the chip — with loader waves and a
+    # 3-deep ring for long K, the 2-stage form for short K; 256x256 only pays at K >= 4096 and is left to the tuned table;
+    # N = 320 layers lose 17 % of a 128-wide tile to padding and take 128x64 (or the 96x320 full-row tile for long K)
+    if N >= 512 and tiles(256, 128) >= 224:
+        return (20 if nk >= 16 else 14), 1
+    if N >= 512 and tiles(128, 128) >= 224:
+        return (30 if nk >= 8 else 11), 1
+    if N == 320 and M % 96 == 0 and M // 96 >= 224 and nk >= 30:
+        return 32, 1
+    if tiles(128, 64) >= 224:
+        return (24 if nk >= 16 else 12), 1
     t64 = tiles(64, 64)
     if t64 >= 160 or not splitk_ok or geglu or nk < 8:
         return (25 if nk >= 8 else 13), 1

@@ -55,7 +55,7 @@ def main():
     fwd(4, 12, 32)              # cfg 3 per-GPU forward
     fwd(1, 12, 32, branches=3)  # dual guidance
     fwd(1, 12, 32, branches=1)  # no guidance
-    from oracle.vae_ref import SD15_VAE_CONFIG
+    SD15_VAE_CONFIG = bench.SD15_VAE
     from asva_amd.vae import AutoencoderKL
 
     with torch.device(dev):

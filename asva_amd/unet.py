@@ -56,6 +56,7 @@ _SIDE_STREAM = os.environ.get("AVSD_SIDE_STREAM", "0") != "0"
 # first transformer's GroupNorm / proj_in / first-frame attention are computed once and replicated (the reference computes them
 # per branch on its torch.cat'ed batch).  14 launches run on half (a third) of the rows.
 _SHARE_PREFIX = os.environ.get("AVSD_SHARE_PREFIX", "1") != "0"
+_F32_CONV_Y = os.environ.get("AVSD_F32_CONV_Y", "1") != "0"      # with the f32 residual stream: also the conv output inside FFInflatedConv3d
 
 
 def _replicate(a: "_Act", r: int) -> "_Act":
@@ -1013,14 +1014,21 @@ def _ffconv(st, x: _Act, p, hw, stride=1, ups=0, temb=None, res: Optional[_Act] 
             x2: Optional[_Act] = None, master=True) -> _Act:
     n_img = st.B * st.F
     if p.k == 3:
-        y = ops.gemm(x.lo, p.w, bias=p.b, mode=ops.CONV3, conv=(n_img, hw[0], hw[1], stride, ups))
         ho = ((hw[0] << ups) + 2 - 3) // stride + 1
         wo = ((hw[1] << ups) + 2 - 3) // stride + 1
+        rows = n_img * ho * wo
     else:
-        y = ops.gemm(x.lo, p.w, a2=None if x2 is None else x2.lo, bias=p.b)
         ho, wo = hw
+        rows = x.lo.shape[0]
+    # f32 residual stream: the conv output y is itself a residual term (out = y + conv_temp(...), utils.py:53) — keep its
+    # un-rounded copy for that addition; the 16-bit copy feeds the temporal-mix product
+    ym = torch.empty((rows, p.cout), dtype=torch.float32, device=x.lo.device) if (st.f32_stream and _F32_CONV_Y) else None
+    if p.k == 3:
+        y = ops.gemm(x.lo, p.w, bias=p.b, mode=ops.CONV3, conv=(n_img, hw[0], hw[1], stride, ups), master=ym)
+    else:
+        y = ops.gemm(x.lo, p.w, a2=None if x2 is None else x2.lo, bias=p.b, master=ym)
     m = _master(st, y, p.cout) if (master and not out_f32) else None
-    out = ops.gemm(y, p.wt, bias=p.bt, res1=y, res2=None if res is None else res.res, rowvec=temb,
+    out = ops.gemm(y, p.wt, bias=p.bt, res1=y if ym is None else ym, res2=None if res is None else res.res, rowvec=temb,
                    rows_per_vec=(st.temb_rows * ho * wo) if temb is not None else 0,
                    mode=ops.TMIX, tmix=(ho * wo, st.F), out_f32=out_f32, master=m)
     return _Act(out, m)

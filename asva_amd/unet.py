@@ -828,7 +828,6 @@ class AudioUNet3DConditionModel(nn.Module):
         return self._cond
 
     @staticmethod
-    @staticmethod
     def _xa_caches(c, tp, key_index, idx_frames, frames):
         """(re)builds the padded K / V^T blocks of the fused cross-attention kernel from c.text_kv / c.audio_kv"""
         C = tp.dim

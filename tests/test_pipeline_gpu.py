@@ -106,3 +106,30 @@ def test_pipeline_matches_oracle_pipeline(kind):
     ref3 = pipeline_ref.denoise(unet_sd, dict(unet.config), x0, g["text"][:1], g["audio"][:1], g["audio"][1:2], g["mask"],
                                 steps, 4.0, kind)
     assert rel_l2(lat3, ref3) < 5e-2
+
+
+def test_generate_videos_batches_the_clips_of_a_video():
+    """generate_videos(clips_per_forward=k): k clips per denoising run instead of the reference's one-by-one loop (:431-458).  Each
+    clip starts from the noise the seed gives a single-clip call, so the frames equal the sequential ones up to the 16-bit
+    rounding that another batch size (other tiles, other f32 summation order) re-draws."""
+    from asva_amd.pipeline import AudioCondAnimationPipeline, generate_videos
+    from asva_amd.schedulers import PNDMScheduler
+
+    g = load_golden("unet_tiny_e2e.pt")
+    f, h, w = g["sample"].shape[2:]
+    pipe = AudioCondAnimationPipeline(unet=filled_unet(g["config"]), scheduler=PNDMScheduler(), vae=_filled_vae(TINY_VAE))
+    pipe.to("cuda")
+    pipe.set_progress_bar_config(disable=True)
+    pipe.generation_steps = 4
+    gen = torch.Generator().manual_seed(2)
+    clips = [dict(image_latents=torch.randn(4, h, w, generator=gen) * 0.18215, audio_encodings=torch.randn(229, g["audio"].shape[-1], generator=gen),
+                  null_audio_encodings=g["audio"][0]) for _ in range(3)]
+    kw = dict(category="x", category_text_encoding=g["text"][:1], image_size=(h * 8, w * 8), video_num_frame=f, seed=5,
+              device=torch.device("cuda"), clips=clips)
+    seq, _ = generate_videos(pipe, **kw)
+    bat, _ = generate_videos(pipe, **kw, clips_per_forward=3)
+    assert len(seq) == len(bat) == 3 and all(v.dtype == torch.uint8 and v.shape == (f, h * 8, w * 8, 3) for v in bat)
+    d = [float((a.float() - b.float()).abs().mean()) for a, b in zip(seq, bat)]
+    between = float((seq[0].float() - seq[1].float()).abs().mean())
+    print(f"batched vs sequential frames: mean |diff| {d} of 255; between two different clips {between:.1f}")
+    assert max(d) < 3.0 and between > 4 * max(d)

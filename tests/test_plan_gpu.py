@@ -22,6 +22,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.fixture
+def fp16_library():
+    from asva_amd import precision as P
+
+    P.set_precision("fp16")
+    yield
+    P.set_precision("bf16")
+
+
 def _setup(kind):
     from asva_amd import precision as P
     from asva_amd.engine import DenoiseEngine
@@ -151,3 +160,42 @@ def test_cpp_host_runs_the_denoising_loop_without_python(tmp_path, kind):
     assert torch.equal(got_lat, want_lat.cpu()), f"max |diff| {float((got_lat - want_lat.cpu()).abs().max()):.3e}"
     assert torch.equal(got_frames, want_frames.cpu())
     assert torch.equal(got_lat[:, :, 0], lat0[:, :, 0].cpu())                 # frame 0 pinned by the host's loop too
+
+
+def test_cpp_host_second_clip_and_fp16_library(tmp_path, fp16_library):
+    """The same bundle serves every clip of its geometry (the conditioning plan recomputes the per-clip caches from the
+    text / audio regions), and a bundle recorded with the fp16 library replays through libavsd_hip_f16.so — and is refused by
+    the bf16 one."""
+    from asva_amd import _lib, build
+    from asva_amd import precision as P
+
+    r = _record(tmp_path, "ddim", steps=3)
+    eng, lat0, g = r["eng"], r["lat0"], r["g"]
+    dev = lat0.device
+    gen = torch.Generator().manual_seed(9)
+    audio2 = torch.randn(1, 229, g["audio"].shape[-1], generator=gen)
+    lat2 = torch.randn(lat0.shape, generator=gen).to(dev)
+    eng.set_conditioning(g["text"][:1].cuda(), audio2.cuda(), g["audio"][:1].cuda(), g["mask"], lat0.shape[2])
+    want2 = eng.run(lat2, r["steps"])
+    eng.set_conditioning(g["text"][:1].cuda(), g["audio"][1:2].cuda(), g["audio"][:1].cuda(), g["mask"], lat0.shape[2])
+    want1 = eng.run(lat0, r["steps"])
+    torch.cuda.synchronize()
+    audio2_cfg = torch.cat([g["audio"][:1], audio2]).to(dev, P.ACT).contiguous()
+    for name, tns in (("text", r["text"]), ("audio1", r["audio"]), ("audio2", audio2_cfg), ("lat1", lat0), ("lat2", lat2)):
+        _bytes(tns).cpu().numpy().tofile(str(tmp_path / f"{name}.in"))
+    b, c, f, h, w = r["shape"]
+    den = f"denoise {tmp_path}/steps.bin latents x t noise_pred 2 4.0 0.0 {b} {c} {f} {h * w}\n"
+    prog = tmp_path / "program.txt"
+    prog.write_text(f"load text {tmp_path}/text.in\n"
+                    f"load audio {tmp_path}/audio2.in\nload latents {tmp_path}/lat2.in\nrun set_conditioning\n" + den +
+                    f"save latents {tmp_path}/lat2.out\n"
+                    f"load audio {tmp_path}/audio1.in\nload latents {tmp_path}/lat1.in\nrun set_conditioning\n" + den +
+                    f"save latents {tmp_path}/lat1.out\n")
+    out = subprocess.run([build.PLAN_HOST, _lib.LIB_PATHS["fp16"], r["path"], str(prog)], capture_output=True, text=True, timeout=300)
+    print(out.stdout[-400:], out.stderr[-400:])
+    assert out.returncode == 0
+    for name, want in (("lat2", want2), ("lat1", want1)):
+        got = torch.from_numpy(np.fromfile(str(tmp_path / f"{name}.out"), dtype=np.float32)).reshape(r["shape"])
+        assert torch.equal(got, want.cpu()), name
+    bad = subprocess.run([build.PLAN_HOST, _lib.LIB_PATHS["bf16"], r["path"], str(prog)], capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "other storage precision" in bad.stderr

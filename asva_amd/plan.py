@@ -244,6 +244,12 @@ class Bundle:
             _lib.lib().avsd_plan_bundle_free(self._h)
             self._h = C.c_void_p()
 
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 — interpreter shutdown
+            pass
+
     def buffer_sizes(self) -> List[int]:
         L = _lib.lib()
         return [L.avsd_plan_bundle_buffer_bytes(self._h, i) for i in range(L.avsd_plan_bundle_num_buffers(self._h))]

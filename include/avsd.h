@@ -344,7 +344,8 @@ const char* avsd_plan_bundle_plan_name(const avsd_plan_bundle* b, int k);
 int avsd_plan_bundle_find_plan(const avsd_plan_bundle* b, const char* name_host);       /* index, or -1 */
 int avsd_plan_num_calls(const avsd_plan_bundle* b, int plan);
 /* Issues every call of plan `plan` on `stream`, in recording order.  All buffers the plan touches must be bound.
- * Capturable in a hipGraph like the calls themselves. */
+ * Capturable in a hipGraph like the calls themselves.  A bundle is not thread-safe (run patches the stream into its
+ * argument lists): one bundle per host thread; bundles on distinct streams are independent. */
 int avsd_plan_run(avsd_plan_bundle* b, int plan, void* stream);
 
 #ifdef __cplusplus

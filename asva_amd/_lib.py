@@ -114,6 +114,10 @@ SIGNATURES = {
     "avsd_plan_bundle_find_plan": (c_int, [c_void_p, C.c_char_p]),
     "avsd_plan_num_calls": (c_int, [c_void_p, c_int]),
     "avsd_plan_run": (c_int, [c_void_p, c_int, c_void_p]),
+    "avsd_unet_set_conditioning": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "avsd_unet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "avsd_vae_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "avsd_plan_region_ptr": (c_void_p, [c_void_p, C.c_char_p, C.POINTER(c_int64)]),
 }
 
 _libs = {}

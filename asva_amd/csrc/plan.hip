@@ -331,3 +331,84 @@ extern "C" int avsd_plan_run(avsd_plan_bundle* b, int plan, void* stream) {
   }
   return AVSD_OK;
 }
+
+// ---- the operation-level surface SURVEY 8(b)-3 proposed, on top of a bundle recorded with the conventional region names
+//      (tools/export_plan.py): "text", "audio" -> plan "set_conditioning";  "x", "t" -> plan "forward" -> "noise_pred";
+//      "latents" -> plan "decode" -> "frames" -----------------------------------------------------------------------------
+namespace {
+
+int region_ptr(avsd_plan_bundle* b, const char* name, int kind, unsigned char** ptr, int64_t* bytes) {
+  const int j = avsd_plan_bundle_find_region(b, name);
+  AVSD_REQUIRE(j >= 0, "plan: the bundle has no region '%s' (record it with the conventional names, tools/export_plan.py)", name);
+  const Region& r = b->regions[j];
+  AVSD_REQUIRE(kind == 0 || r.kind == kind, "plan: region '%s' has kind %d, expected %d", name, r.kind, kind);
+  AVSD_REQUIRE(b->buffers[r.buf].ptr != nullptr, "plan: buffer %d (holding region '%s') is not bound", r.buf, name);
+  *ptr = static_cast<unsigned char*>(b->buffers[r.buf].ptr) + r.off;
+  *bytes = r.bytes;
+  return AVSD_OK;
+}
+
+int run_named(avsd_plan_bundle* b, const char* plan, void* stream) {
+  const int k = avsd_plan_bundle_find_plan(b, plan);
+  AVSD_REQUIRE(k >= 0, "plan: the bundle has no plan '%s'", plan);
+  return avsd_plan_run(b, k, stream);
+}
+
+int copy_in(avsd_plan_bundle* b, const char* name, const void* src, void* stream) {
+  unsigned char* dst;
+  int64_t bytes;
+  const int rc = region_ptr(b, name, AVSD_REGION_INPUT, &dst, &bytes);
+  if (rc != AVSD_OK) return rc;
+  return src == dst ? AVSD_OK : avsd_copy(src, dst, bytes, 1, stream);
+}
+
+}  // namespace
+
+extern "C" int avsd_unet_set_conditioning(avsd_plan_bundle* b, const void* text, const void* audio, void* stream) {
+  AVSD_REQUIRE(b && text && audio, "unet_set_conditioning: null argument");
+  int rc = copy_in(b, "text", text, stream);
+  if (rc == AVSD_OK) rc = copy_in(b, "audio", audio, stream);
+  if (rc == AVSD_OK) rc = run_named(b, "set_conditioning", stream);
+  return rc;
+}
+
+extern "C" int avsd_unet_forward(avsd_plan_bundle* b, const float* sample, const float* timestep, float* noise_pred, void* stream) {
+  AVSD_REQUIRE(b && sample && timestep, "unet_forward: null argument");
+  int rc = copy_in(b, "x", sample, stream);
+  if (rc != AVSD_OK) return rc;
+  unsigned char* t;
+  int64_t tb;
+  rc = region_ptr(b, "t", AVSD_REGION_INPUT, &t, &tb);
+  if (rc != AVSD_OK) return rc;
+  if (reinterpret_cast<const float*>(t) != timestep) {   // 4 bytes: below avsd_copy's 16-byte granule
+    const hipError_t e = hipMemcpyAsync(t, timestep, 4, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream));
+    AVSD_REQUIRE(e == hipSuccess, "unet_forward: timestep copy: %s", hipGetErrorString(e));
+  }
+  rc = run_named(b, "forward", stream);
+  if (rc != AVSD_OK || !noise_pred) return rc;
+  unsigned char* np;
+  int64_t nb;
+  rc = region_ptr(b, "noise_pred", AVSD_REGION_OUTPUT, &np, &nb);
+  if (rc != AVSD_OK) return rc;
+  return avsd_copy(np, noise_pred, nb, 1, stream);
+}
+
+extern "C" int avsd_vae_decode(avsd_plan_bundle* b, const float* latents, void* frames_u8, void* stream) {
+  AVSD_REQUIRE(b && latents, "vae_decode: null argument");
+  int rc = copy_in(b, "latents", latents, stream);
+  if (rc == AVSD_OK) rc = run_named(b, "decode", stream);
+  if (rc != AVSD_OK || !frames_u8) return rc;
+  unsigned char* fp;
+  int64_t fb;
+  rc = region_ptr(b, "frames", AVSD_REGION_OUTPUT, &fp, &fb);
+  if (rc != AVSD_OK) return rc;
+  return avsd_copy(fp, frames_u8, fb, 1, stream);
+}
+
+extern "C" const void* avsd_plan_region_ptr(avsd_plan_bundle* b, const char* name, int64_t* bytes) {
+  unsigned char* p = nullptr;
+  int64_t nb = 0;
+  if (!b || !name || region_ptr(b, name, 0, &p, &nb) != AVSD_OK) return nullptr;
+  if (bytes) *bytes = nb;
+  return p;
+}

@@ -348,6 +348,20 @@ int avsd_plan_num_calls(const avsd_plan_bundle* b, int plan);
  * argument lists): one bundle per host thread; bundles on distinct streams are independent. */
 int avsd_plan_run(avsd_plan_bundle* b, int plan, void* stream);
 
+/* Operation-level calls on a bundle recorded with the conventional region names (tools/export_plan.py) — the surface
+ * SURVEY 8(b)-3 sketched, for hosts that do not want to handle regions themselves.  All pointers are DEVICE pointers of the
+ * regions' sizes (the 16-bit CFG-batched text / audio encodings, f32 latents, one f32 timestep); every call only enqueues
+ * work on `stream`.  avsd_unet_set_conditioning: audio_cond_unet_3d_condition.py:598-798's step-invariant part, once per clip
+ * ("text", "audio" -> plan "set_conditioning").  avsd_unet_forward: one UNet evaluation of the CFG batch ("x", "t" -> plan
+ * "forward" -> "noise_pred"; noise_pred_out may be NULL: read the region instead).  avsd_vae_decode:
+ * pipeline_audio_cond_animation.py:206-213 + :448 ("latents" -> plan "decode" -> uint8 "frames").  The guidance + scheduler
+ * update between two forwards is avsd_guided_step.  avsd_plan_region_ptr: device address (and size) of a region in the
+ * bound buffers, NULL if absent or unbound. */
+int avsd_unet_set_conditioning(avsd_plan_bundle* b, const void* text, const void* audio, void* stream);
+int avsd_unet_forward(avsd_plan_bundle* b, const float* sample, const float* timestep, float* noise_pred_out, void* stream);
+int avsd_vae_decode(avsd_plan_bundle* b, const float* latents, void* frames_u8_out, void* stream);
+const void* avsd_plan_region_ptr(avsd_plan_bundle* b, const char* name_host, int64_t* bytes_host);
+
 #ifdef __cplusplus
 }
 #endif

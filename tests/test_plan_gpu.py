@@ -101,6 +101,23 @@ def test_plans_replay_bit_identically_from_fresh_buffers(tmp_path):
     torch.cuda.synchronize()
     assert torch.equal(b.view("noise_pred"), _bytes(r["noise"])), "replayed UNet forward differs from the recording run"
     assert torch.equal(b.view("frames"), _bytes(r["frames"])), "replayed VAE decode differs from the recording run"
+    # the operation-level calls (avsd_unet_set_conditioning / avsd_unet_forward / avsd_vae_decode) on a second fresh binding:
+    # inputs and outputs are plain device pointers of the caller
+    from asva_amd import _lib
+
+    L, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
+    b4 = type(b)(r["path"])
+    b4.bind_fresh(r["lat0"].device)
+    noise_out, frames_out = torch.zeros_like(r["noise"]), torch.zeros_like(r["frames"])
+    _lib.check(L.avsd_unet_set_conditioning(b4._h, r["text"].data_ptr(), r["audio"].data_ptr(), st), "avsd_unet_set_conditioning")
+    _lib.check(L.avsd_unet_forward(b4._h, r["lat0"].data_ptr(), r["t"].data_ptr(), noise_out.data_ptr(), st), "avsd_unet_forward")
+    _lib.check(L.avsd_vae_decode(b4._h, r["lat0"].data_ptr(), frames_out.data_ptr(), st), "avsd_vae_decode")
+    torch.cuda.synchronize()
+    assert torch.equal(noise_out, r["noise"]) and torch.equal(frames_out, r["frames"])
+    nb = __import__("ctypes").c_int64()
+    assert L.avsd_plan_region_ptr(b4._h, b"noise_pred", nb) and nb.value == r["noise"].numel() * 4
+    assert not L.avsd_plan_region_ptr(b4._h, b"no_such_region", nb)
+    b4.close()
     # an unbound buffer is an error, not a wild launch
     b2 = type(b)(r["path"])
     with pytest.raises(Exception, match="not bound"):

@@ -167,14 +167,22 @@ __global__ void copy_rep_kernel(const uint4* src, uint4* dst, int64_t nvec, int 
   }
 }
 
-// one thread per (block b, key slot j, 8-channel chunk): K rows copied as they are, V written transposed
+// one thread per (block b, key slot j < lk_pad, 8-channel chunk): K rows copied as they are, V written transposed; the
+// padding slots j >= lk are written as zeros on every call (the fused kernel multiplies p = 0 by the V^T padding, so it
+// must be finite whatever the allocator handed out — a replaying host binds fresh memory)
 __global__ void xattn_pack_kv_kernel(const h16_t* kv, int rows, int C, const int32_t* idx, int n_frames, int nk, int lk,
                                      h16_t* k_out, h16_t* vt_out, int lk_pad, int64_t total) {
   const int c8n = C / 8;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int c8 = (int)(t % c8n);
-    const int j = (int)((t / c8n) % lk);
-    const int b = (int)(t / ((int64_t)c8n * lk));
+    const int j = (int)((t / c8n) % lk_pad);
+    const int b = (int)(t / ((int64_t)c8n * lk_pad));
+    if (j >= lk) {
+      *reinterpret_cast<uint4*>(k_out + ((int64_t)b * lk_pad + j) * C + c8 * 8) = make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vt_out[((int64_t)b * C + c8 * 8 + e) * lk_pad + j] = 0;
+      continue;
+    }
     const int n = idx ? b / n_frames : b;
     const int key = idx ? idx[(b % n_frames) * nk + j] : j;
     const h16_t* src = kv + ((int64_t)n * rows + key) * 2 * C + c8 * 8;
@@ -283,7 +291,7 @@ extern "C" int avsd_xattn_pack_kv(const void* kv, int n_kv, int rows, int C, con
   const int lk = idx ? nk : rows;
   AVSD_REQUIRE(lk_pad >= lk, "xattn_pack_kv: lk_pad (%d) < keys per block (%d)", lk_pad, lk);
   const int nb = idx ? n_kv * n_frames : n_kv;
-  const int64_t total = (int64_t)nb * lk * (C / 8);
+  const int64_t total = (int64_t)nb * lk_pad * (C / 8);
   hipLaunchKernelGGL(xattn_pack_kv_kernel, dim3(grid_for(total, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      (const h16_t*)kv, rows, C, idx, n_frames, nk, lk, (h16_t*)k_out, (h16_t*)vt_out, lk_pad, total);
   AVSD_CHECK_LAUNCH("xattn_pack_kv launch");

@@ -52,11 +52,13 @@ typedef int (*thunk_t)(const RArg*, int);
 struct Entry {
   const char* name;
   thunk_t thunk;
+  size_t desc_bytes;   // size every 's' (descriptor) argument of this entry point must have; 0 = takes none
 };
-#define AVSD_PLAN_ENTRY(fn) {#fn, [](const RArg* a, int n) { return call(&fn, a, n, #fn); }}
+#define AVSD_PLAN_ENTRY(fn) {#fn, [](const RArg* a, int n) { return call(&fn, a, n, #fn); }, 0}
+#define AVSD_PLAN_ENTRY_DESC(fn, T) {#fn, [](const RArg* a, int n) { return call(&fn, a, n, #fn); }, sizeof(T)}
 // every entry point that launches work (the queries and the plan API itself are not recordable)
 const Entry kEntries[] = {
-    AVSD_PLAN_ENTRY(avsd_gemm_bf16),        AVSD_PLAN_ENTRY(avsd_cross_attention_block), AVSD_PLAN_ENTRY(avsd_linear_small_m),
+    AVSD_PLAN_ENTRY_DESC(avsd_gemm_bf16, avsd_gemm_desc), AVSD_PLAN_ENTRY_DESC(avsd_cross_attention_block, avsd_xattn_desc), AVSD_PLAN_ENTRY(avsd_linear_small_m),
     AVSD_PLAN_ENTRY(avsd_groupnorm_stats),  AVSD_PLAN_ENTRY(avsd_groupnorm_apply),       AVSD_PLAN_ENTRY(avsd_layernorm),
     AVSD_PLAN_ENTRY(avsd_softmax_rows),     AVSD_PLAN_ENTRY(avsd_attention),             AVSD_PLAN_ENTRY(avsd_attention_fp8),
     AVSD_PLAN_ENTRY(avsd_temporal_attention), AVSD_PLAN_ENTRY(avsd_ncfhw_to_rows),       AVSD_PLAN_ENTRY(avsd_rows_to_ncfhw),
@@ -181,7 +183,19 @@ int resolve(avsd_plan_bundle& b, Plan& p) {
 
 }  // namespace
 
+static int plan_bundle_load_impl(const char* path, avsd_plan_bundle** out);
+
 extern "C" int avsd_plan_bundle_load(const char* path, avsd_plan_bundle** out) {
+  try {                         // nothing may propagate across the C boundary (std::bad_alloc on a hostile count)
+    return plan_bundle_load_impl(path, out);
+  } catch (...) {
+    if (out) *out = nullptr;
+    avsd_set_error("plan_bundle_load: %s: out of memory or corrupt file", path ? path : "(null)");
+    return AVSD_EINVAL;
+  }
+}
+
+static int plan_bundle_load_impl(const char* path, avsd_plan_bundle** out) {
   AVSD_REQUIRE(path && out, "plan_bundle_load: null argument");
   *out = nullptr;
   FILE* f = fopen(path, "rb");
@@ -193,11 +207,13 @@ extern "C" int avsd_plan_bundle_load(const char* path, avsd_plan_bundle** out) {
   char prec[8];
   rd.raw(prec, 8);
   prec[7] = 0;
-  avsd_plan_bundle* b = new avsd_plan_bundle();
+  struct Guard {            // closes the file / frees the bundle on every exit path, exceptions included
+    FILE* f; avsd_plan_bundle* b;
+    ~Guard() { if (f) fclose(f); delete b; }
+  } guard{f, new avsd_plan_bundle()};
+  avsd_plan_bundle* b = guard.b;
   auto fail = [&](const char* why) {
     avsd_set_error("plan_bundle_load: %s: %s", path, why);
-    fclose(f);
-    delete b;
     return AVSD_EINVAL;
   };
   if (!rd.ok || memcmp(magic, "AVSDPLN1", 8) != 0) return fail("not a plan bundle");
@@ -216,7 +232,8 @@ extern "C" int avsd_plan_bundle_load(const char* path, avsd_plan_bundle** out) {
     r.off = rd.get<int64_t>();
     r.bytes = rd.get<int64_t>();
     r.kind = (int)rd.get<uint32_t>();
-    if (!rd.ok || r.buf < 0 || r.buf >= (int)nb || r.off < 0 || r.bytes < 0 || r.off + r.bytes > b->buffers[r.buf].bytes)
+    if (!rd.ok || r.buf < 0 || r.buf >= (int)nb || r.off < 0 || r.bytes < 0 || r.off > b->buffers[r.buf].bytes ||
+        r.bytes > b->buffers[r.buf].bytes - r.off)
       return fail("a region lies outside its buffer");
   }
   const uint32_t np = rd.get<uint32_t>();
@@ -225,12 +242,13 @@ extern "C" int avsd_plan_bundle_load(const char* path, avsd_plan_bundle** out) {
   for (Plan& p : b->plans) {
     p.name = rd.str();
     const uint32_t nc = rd.get<uint32_t>();
-    if (!rd.ok || nc > (1u << 24)) return fail("bad call count");
+    if (!rd.ok || nc > (1u << 20)) return fail("bad call count");
     p.calls.resize(nc);
     for (Call& c : p.calls) {
       c.fn = rd.str();
+      size_t desc_bytes = 0;
       for (const Entry& e : kEntries)
-        if (c.fn == e.name) c.thunk = e.thunk;
+        if (c.fn == e.name) { c.thunk = e.thunk; desc_bytes = e.desc_bytes; }
       if (!rd.ok || !c.thunk) return fail("a call names an entry point this library does not record");
       const uint32_t na = rd.get<uint32_t>();
       if (!rd.ok || na > 64) return fail("bad argument count");
@@ -247,17 +265,23 @@ extern "C" int avsd_plan_bundle_load(const char* path, avsd_plan_bundle** out) {
           a.blob.resize(n);
           rd.raw(a.blob.data(), n);
           if (a.tag == 's') {
+            if (n != desc_bytes) return fail("a descriptor argument does not have the size its entry point reads");
             const uint32_t nr = rd.get<uint32_t>();
             if (!rd.ok || nr > 256) return fail("bad relocation count");
             a.relocs.resize(nr);
-            for (Reloc& rl : a.relocs) { rl.field_off = rd.get<uint32_t>(); rl.buf = rd.get<int32_t>(); rl.off = rd.get<int64_t>(); }
+            for (Reloc& rl : a.relocs) {
+              rl.field_off = rd.get<uint32_t>(); rl.buf = rd.get<int32_t>(); rl.off = rd.get<int64_t>();
+              if (!rd.ok || (size_t)rl.field_off + sizeof(void*) > (size_t)n) return fail("a descriptor relocation lies outside the descriptor");
+            }
+          } else if (c.fn == "avsd_guided_step" && n != 0 && n != 16) {
+            return fail("avsd_guided_step history tables are 4 entries of 4 bytes");   // the entry point reads up to n_hist <= 4
           }
         } else if (a.tag != 'S') return fail("unknown argument tag");
       }
     }
   }
   if (!rd.ok) return fail("truncated file");
-  fclose(f);
+  guard.b = nullptr;
   *out = b;
   return AVSD_OK;
 }

@@ -675,7 +675,7 @@ def copy(src: torch.Tensor, dst: Optional[torch.Tensor] = None, rep: int = 1) ->
 def xattn_pack_kv(kv: torch.Tensor, n_kv: int, rows: int, Cc: int, idx: Optional[torch.Tensor], k_out: torch.Tensor,
                   vt_out: torch.Tensor) -> None:
     """kv [n_kv*rows, 2C] -> k_out [nb, lk_pad, C], vt_out [nb, C, lk_pad] (operands of cross_attention_block); idx [F, nk]
-    int32 gathers the visible keys of each frame (nb = n_kv * F).  Padding columns are left as they are (zero-filled once)."""
+    int32 gathers the visible keys of each frame (nb = n_kv * F).  The padding slots lk..lk_pad are zero-filled by the same launch."""
     _req(kv, P.ACT, "kv")
     _req(k_out, P.ACT, "k_out")
     _req(vt_out, P.ACT, "vt_out")

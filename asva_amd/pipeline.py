@@ -267,10 +267,15 @@ def write_video(filename, video_array, fps, audio_array=None, audio_fps=16000, a
     and writes `<stem>.avi` (this image has no H.264 encoder)."""
     try:
         import torchvision.io as tvio  # type: ignore
-    except ImportError:
+    except Exception as e:             # absent, or present but unusable (operator / ABI mismatch raises RuntimeError)
+        import warnings
+
         from .video_io import write_mjpeg_avi
 
-        return write_mjpeg_avi(os.path.splitext(filename)[0] + ".avi", video_array, fps, audio_array, audio_fps)
+        path = os.path.splitext(filename)[0] + ".avi"
+        warnings.warn(f"torchvision.io is unavailable ({type(e).__name__}): writing Motion-JPEG {path} instead of {filename}; "
+                      "tools that glob *.mp4 must read it with asva_amd.video_io.read_mjpeg_avi", RuntimeWarning, stacklevel=2)
+        return write_mjpeg_avi(path, video_array, fps, audio_array, audio_fps)
     tvio.write_video(filename=filename, video_array=video_array, fps=fps, audio_array=audio_array, audio_fps=audio_fps,
                      audio_codec=audio_codec)
     return filename
@@ -304,12 +309,19 @@ def generate_videos(pipeline, image_path: str = "", audio_path: str = "", video_
     generator = torch.Generator(device=device)
     # clips_per_forward > 1 (AVSD_CLIPS_PER_FORWARD, default 1 = the reference's loop): that many clips of the video go through
     # ONE batched denoising run — 115 instead of 77 clip-steps/s on an MI355X (bench.py "batched").  Every clip still starts from
-    # the noise the seed gives a single-clip call (:433 re-seeds per clip), so only the kernels' tile choice differs.
+    # the noise the seed gives a single-clip call (:433 re-seeds per clip).  What differs from the one-clip-at-a-time loop: the
+    # kernels' tile choice, and — when the image latents come from `images` rather than `image_latents` — the VAE posterior sample:
+    # latent_dist.sample() draws for all clips of the group in one call from the global RNG, so clip k > 0 sees other draws.
     group = max(1, int(clips_per_forward if clips_per_forward is not None else os.environ.get("AVSD_CLIPS_PER_FORWARD", "1")))
     for k0 in range(0, len(clips), group):
         chunk = clips[k0:k0 + group]
         generator.manual_seed(seed)                       # every clip restarts from the same seed (:433)
         kw = {}
+        for key in ("image_latents", "image", "audio_encodings"):      # a batched group must be homogeneous
+            have = [key in c for c in chunk]
+            if any(have) and not all(have):
+                raise ValueError(f"generate_videos: clips {k0}..{k0 + len(chunk) - 1} are batched into one forward "
+                                 f"(clips_per_forward={group}) but only some of them carry '{key}'")
         if all("image_latents" in c for c in chunk):
             kw["image_latents"] = torch.stack([c["image_latents"] for c in chunk])
         if all("audio_encodings" in c for c in chunk):

@@ -106,8 +106,8 @@ def _xa_fill(kv: torch.Tensor, n_kv: int, rows: int, C: int, idx: Optional[torch
     if lkp > 96:
         return None
     if old is None:
-        old = _Pk(k=torch.zeros((nb, lkp, C), dtype=kv.dtype, device=kv.device),
-                  vt=torch.zeros((nb, C, lkp), dtype=kv.dtype, device=kv.device), lk=lk)
+        old = _Pk(k=torch.empty((nb, lkp, C), dtype=kv.dtype, device=kv.device),         # avsd_xattn_pack_kv writes the padding too
+                  vt=torch.empty((nb, C, lkp), dtype=kv.dtype, device=kv.device), lk=lk)
     ops.xattn_pack_kv(kv, n_kv, rows, C, idx, old.k, old.vt)
     return old
 

@@ -309,7 +309,7 @@ int avsd_copy(const void* src, void* dst, int64_t bytes, int rep, void* stream);
  * k_out [nb][lk_pad][C] and vt_out [nb][C][lk_pad].  Without a gather list (idx == NULL) nb = n_kv and block n holds keys
  * 0..rows-1 of clip n; with idx [n_frames][nk] int32 (the visible keys of each frame under the audio segment mask,
  * audio_attn_mask in segmask_imagebind.py:104-114) nb = n_kv * n_frames and block n * n_frames + f holds keys idx[f][:] of
- * clip n.  Columns lk..lk_pad-1 (lk = nk or rows) are not written: the caller zero-fills the buffers once.  Once per clip. */
+ * clip n.  The padding slots lk..lk_pad-1 (lk = nk or rows) are written as zeros by the same launch.  Once per clip. */
 int avsd_xattn_pack_kv(const void* kv, int n_kv, int rows, int C, const int32_t* idx, int n_frames, int nk,
                        void* k_out, void* vt_out, int lk_pad, void* stream);
 
@@ -356,7 +356,12 @@ int avsd_plan_run(avsd_plan_bundle* b, int plan, void* stream);
  * "forward" -> "noise_pred"; noise_pred_out may be NULL: read the region instead).  avsd_vae_decode:
  * pipeline_audio_cond_animation.py:206-213 + :448 ("latents" -> plan "decode" -> uint8 "frames").  The guidance + scheduler
  * update between two forwards is avsd_guided_step.  avsd_plan_region_ptr: device address (and size) of a region in the
- * bound buffers, NULL if absent or unbound. */
+ * bound buffers, NULL if absent or unbound.
+ * A "forward" plan bakes in the launch sequence of its recording run, including the shared guidance prefix: when the recording
+ * host saw the SAME text rows in every guidance branch (audio-only guidance, text [t, t], pipeline_audio_cond_animation.py:155)
+ * the layers in front of the first audio cross-attention were recorded once for all branches.  Such a bundle is valid only for
+ * text inputs with that property; record with AVSD_SHARE_PREFIX=0 for per-branch text (text or dual guidance).  The region
+ * "share_prefix" (4 bytes, CONST: 1 = the prefix is shared) states which kind a bundle is. */
 int avsd_unet_set_conditioning(avsd_plan_bundle* b, const void* text, const void* audio, void* stream);
 int avsd_unet_forward(avsd_plan_bundle* b, const float* sample, const float* timestep, float* noise_pred_out, void* stream);
 int avsd_vae_decode(avsd_plan_bundle* b, const float* latents, void* frames_u8_out, void* stream);

@@ -198,6 +198,8 @@ def xattn_pack_kv(kv, n_kv, rows, C, idx, k_out, vt_out):
     if idx is not None:
         kv3 = kv3[:, idx.long()].reshape(n_kv * idx.shape[0], idx.shape[1], 2 * C)
     lk = kv3.shape[1]
+    k_out.zero_()
+    vt_out.zero_()
     k_out[:, :lk].copy_(kv3[..., :C])
     vt_out[:, :, :lk].copy_(kv3[..., C:].transpose(1, 2))
 

@@ -643,11 +643,11 @@ def test_xattn_pack_kv_matches_indexing(ops, gather):
     lk = idx.shape[1] if gather else rows
     nb = n_kv * Fr if gather else n_kv
     lkp = (lk + 31) // 32 * 32
-    k = torch.zeros(nb, lkp, C, dtype=kv.dtype, device=dev())
-    vt = torch.zeros(nb, C, lkp, dtype=kv.dtype, device=dev())
+    k = torch.full((nb, lkp, C), float("nan"), dtype=kv.dtype, device=dev())      # poisoned: the launch owns the padding too
+    vt = torch.full((nb, C, lkp), float("nan"), dtype=kv.dtype, device=dev())
     ops.xattn_pack_kv(kv, n_kv, rows, C, idx, k, vt)
     kv3 = kv.view(n_kv, rows, 2 * C)
     if gather:
         kv3 = kv3[:, idx.long()].reshape(nb, lk, 2 * C)
     assert torch.equal(k[:, :lk], kv3[..., :C]) and torch.equal(vt[:, :, :lk], kv3[..., C:].transpose(1, 2))
-    assert not k[:, lk:].any() and not vt[:, :, lk:].any()          # padding untouched
+    assert not k[:, lk:].any() and not vt[:, :, lk:].any()          # padding zero-filled by the launch

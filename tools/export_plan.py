@@ -66,6 +66,10 @@ def main():
     rec.region("audio_key_index", U.key_index_for(mask, dev), plan.CONST)
     if vae is not None:
         rec.region("vae_weights", vae.pack().blob, plan.CONST)
+    # which kind of "forward" plan this is (include/avsd.h): text is [t, t] here, so with AVSD_SHARE_PREFIX on (default) the
+    # layers in front of the first audio cross-attention are recorded once for both guidance branches
+    share_flag = torch.tensor([int(U._SHARE_PREFIX), 0, 0, 0], dtype=torch.int32, device=dev)
+    rec.region("share_prefix", share_flag, plan.CONST)
     for name, tns in (("text", text), ("audio", audio), ("x", x), ("t", t), ("latents", latents)):
         rec.region(name, tns, plan.INPUT)
     with rec.record("set_conditioning"):

@@ -40,6 +40,8 @@ class GemmDesc(C.Structure):
         ("split_k", C.c_int32), ("splitk_ws", c_void_p), ("splitk_cnt", c_void_p),
         ("rowstats", c_void_p), ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("ln_nblk", C.c_int32), ("ln_eps", C.c_float),
         ("out_master", c_void_p), ("ldm", C.c_int32), ("reserved0", C.c_int32),
+        ("a_lo", C.c_int64), ("a2_lo", C.c_int64), ("w_lo", C.c_int64), ("out_lo", C.c_int64), ("res1_lo", C.c_int64),
+        ("res2_lo", C.c_int64),
     ]
 
 
@@ -99,6 +101,22 @@ SIGNATURES = {
     "avsd_vit_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "avsd_copy": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "avsd_xattn_pack_kv": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    # split-precision ("x2") storage: main + rest planes, three-pass MFMA products
+    "avsd_linear_small_m_x2": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "avsd_groupnorm_stats_x2": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_int, c_void_p,
+                                        c_int, c_void_p]),
+    "avsd_groupnorm_apply_x2": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_int, c_void_p,
+                                        c_void_p, c_float, c_void_p, c_int, c_int, c_void_p, c_int, c_int64, c_void_p]),
+    "avsd_layernorm_x2": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p,
+                                  c_int, c_int, c_void_p]),
+    "avsd_attention_x2": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_void_p, c_int, c_int64,
+                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float, c_void_p]),
+    "avsd_temporal_attention_x2": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_float,
+                                           c_void_p]),
+    "avsd_ncfhw_to_rows_x2": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "avsd_split_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "avsd_vae_postprocess_x2": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_void_p]),
+    "avsd_vae_postprocess_u8_x2": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_void_p]),
     # launch plans (asva_amd/plan.py records them; any host replays them)
     "avsd_plan_bundle_load": (c_int, [C.c_char_p, C.POINTER(c_void_p)]),
     "avsd_plan_bundle_free": (None, [c_void_p]),

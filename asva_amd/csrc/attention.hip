@@ -568,6 +568,7 @@ int launch_attn_wide(const AttnArgs& a, int Bq, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------
 struct TAttnArgs {
   const h16_t* QKV; h16_t* O;
+  int64_t qkv_lo, o_lo;   // split-precision planes (avsd_common.h): offsets to the rest planes, 0 = single plane
   int ldqkv, ldo, frames, hw, heads;
   int hpb;    // heads per workgroup (blockIdx.y = head group): low-resolution layers have too few pixels to fill the chip
   float scale;
@@ -575,7 +576,7 @@ struct TAttnArgs {
 
 // One thread per (head, query frame, d-slice): the head dimension is cut into DS slices of SL channels held by DS
 // adjacent lanes (partial dot products are summed with 1-2 shuffles), so d = 160 runs 4x the threads of d = 40.
-template <int D, int FMAX>
+template <int D, int FMAX, bool X2>
 __global__ __launch_bounds__(1024) void tattn_kernel(const TAttnArgs p) {
   constexpr int SL = (D % 40 == 0) ? 40 : 32;   // slice length
   constexpr int DS = D / SL;                    // 1, 2 or 4 lanes per (head, frame)
@@ -601,20 +602,25 @@ __global__ __launch_bounds__(1024) void tattn_kernel(const TAttnArgs p) {
 
   // this thread's query slice is requested first, so its round trip overlaps the K/V staging below instead of
   // following the barrier
-  uint4 qv[NV];
+  uint4 qv[NV], qr[X2 ? NV : 1];
   {
     const h16_t* qrow = p.QKV + (row0 + (int64_t)i * p.hw) * p.ldqkv + coff;
 #pragma unroll
-    for (int d = 0; d < NV; ++d) qv[d] = *reinterpret_cast<const uint4*>(qrow + d * 8);
+    for (int d = 0; d < NV; ++d) {
+      qv[d] = *reinterpret_cast<const uint4*>(qrow + d * 8);
+      if constexpr (X2) qr[d] = *reinterpret_cast<const uint4*>(qrow + p.qkv_lo + d * 8);
+    }
   }
 
   const int vec_per_row = 2 * Cg / 8;   // [k slice | v slice] of the group
+  h16_t* sKVr = sKV + F * 2 * Cg;       // X2: the rest planes of the same rows
   for (int v = tid; v < F * vec_per_row; v += blockDim.x) {
     const int f = v / vec_per_row;
     const int cv = (v - f * vec_per_row) * 8;
     const int src = cv < Cg ? C + c0g + cv : 2 * C + c0g + (cv - Cg);
-    *reinterpret_cast<uint4*>(sKV + f * 2 * Cg + cv) =
-        *reinterpret_cast<const uint4*>(p.QKV + (row0 + (int64_t)f * p.hw) * p.ldqkv + src);
+    const h16_t* g = p.QKV + (row0 + (int64_t)f * p.hw) * p.ldqkv + src;
+    *reinterpret_cast<uint4*>(sKV + f * 2 * Cg + cv) = *reinterpret_cast<const uint4*>(g);
+    if constexpr (X2) *reinterpret_cast<uint4*>(sKVr + f * 2 * Cg + cv) = *reinterpret_cast<const uint4*>(g + p.qkv_lo);
   }
   __syncthreads();
 
@@ -630,6 +636,13 @@ __global__ __launch_bounds__(1024) void tattn_kernel(const TAttnArgs p) {
         float a[8], k[8];
         unpack8(qv[d], a);
         unpack8(*reinterpret_cast<const uint4*>(krow + d * 8), k);
+        if constexpr (X2) {
+          float a2[8], k2[8];
+          unpack8(qr[d], a2);
+          unpack8(*reinterpret_cast<const uint4*>(krow + (sKVr - sKV) + d * 8), k2);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { a[e] += a2[e]; k[e] += k2[e]; }
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) dot = fmaf(a[e], k[e], dot);
       }
@@ -661,27 +674,36 @@ __global__ __launch_bounds__(1024) void tattn_kernel(const TAttnArgs p) {
       if (j < F) {
         float vv[8];
         unpack8(*reinterpret_cast<const uint4*>(sKV + j * 2 * Cg + Cg + loff + d * 8), vv);
+        if constexpr (X2) {
+          float v2[8];
+          unpack8(*reinterpret_cast<const uint4*>(sKVr + j * 2 * Cg + Cg + loff + d * 8), v2);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) vv[e] += v2[e];
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = fmaf(sc[j], vv[e], o[e]);
       }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] *= inv;
-    *reinterpret_cast<uint4*>(orow + d * 8) = pack8(o);
+    store8<X2>(orow + d * 8, p.o_lo, o);
   }
 }
 
-template <int D, int FMAX>
+template <int D, int FMAX, bool X2>
 int launch_tattn(const TAttnArgs& a0, int B, hipStream_t s) {
   constexpr int DS = D / ((D % 40 == 0) ? 40 : 32);
   TAttnArgs a = a0;
   // one workgroup per (clip branch, pixel, head group): split the heads until ~1024 workgroups exist
   a.hpb = a.heads;
   while (a.hpb > 1 && a.hpb % 2 == 0 && (long)B * a.hw * (a.heads / a.hpb) < 1024) a.hpb /= 2;
-  const size_t lds = (size_t)a.frames * 2 * a.hpb * D * sizeof(h16_t);
+  if (X2) {
+    while (a.hpb > 1 && a.hpb % 2 == 0 && (size_t)a.frames * 2 * a.hpb * D * sizeof(h16_t) * 2 > 160 * 1024) a.hpb /= 2;
+  }
+  const size_t lds = (size_t)a.frames * 2 * a.hpb * D * sizeof(h16_t) * (X2 ? 2 : 1);
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tattn_kernel<D, FMAX>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tattn_kernel<D, FMAX, X2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       avsd_set_error("temporal attention: %zu B LDS: %s", lds, hipGetErrorString(e));
@@ -694,16 +716,21 @@ int launch_tattn(const TAttnArgs& a0, int B, hipStream_t s) {
     avsd_set_error("temporal attention: heads*frames*%d = %d threads exceeds 1024", DS, a.hpb * a.frames * DS);
     return AVSD_EINVAL;
   }
-  hipLaunchKernelGGL((tattn_kernel<D, FMAX>), dim3((unsigned)(B * a.hw), (unsigned)(a.heads / a.hpb)), dim3(threads), lds, s, a);
+  hipLaunchKernelGGL((tattn_kernel<D, FMAX, X2>), dim3((unsigned)(B * a.hw), (unsigned)(a.heads / a.hpb)), dim3(threads), lds, s, a);
   AVSD_CHECK_LAUNCH("temporal attention launch");
   return AVSD_OK;
 }
 
 template <int D>
 int dispatch_tattn(const TAttnArgs& a, int B, hipStream_t s) {
-  if (a.frames <= 12) return launch_tattn<D, 12>(a, B, s);
-  if (a.frames <= 24) return launch_tattn<D, 24>(a, B, s);
-  return launch_tattn<D, 32>(a, B, s);
+  if (a.qkv_lo != 0) {
+    if (a.frames <= 12) return launch_tattn<D, 12, true>(a, B, s);
+    if (a.frames <= 24) return launch_tattn<D, 24, true>(a, B, s);
+    return launch_tattn<D, 32, true>(a, B, s);
+  }
+  if (a.frames <= 12) return launch_tattn<D, 12, false>(a, B, s);
+  if (a.frames <= 24) return launch_tattn<D, 24, false>(a, B, s);
+  return launch_tattn<D, 32, false>(a, B, s);
 }
 
 }  // namespace
@@ -740,13 +767,19 @@ extern "C" int avsd_attention(const void* Q, int ldq, const void* K, int ldk, co
 
 extern "C" int avsd_temporal_attention(const void* QKV, int ldqkv, void* O, int ldo, int B, int frames,
                                        int hw, int heads, int d, float scale, void* stream) {
+  return avsd_temporal_attention_x2(QKV, ldqkv, 0, O, ldo, 0, B, frames, hw, heads, d, scale, stream);
+}
+
+extern "C" int avsd_temporal_attention_x2(const void* QKV, int ldqkv, int64_t qkv_lo, void* O, int ldo, int64_t o_lo, int B, int frames,
+                                          int hw, int heads, int d, float scale, void* stream) {
   AVSD_REQUIRE(QKV && O, "temporal attention: null pointer");
+  AVSD_REQUIRE(qkv_lo % 8 == 0 && o_lo % 8 == 0 && (qkv_lo != 0) == (o_lo != 0), "temporal attention: plane offsets must be multiples of 8, both tensors split or neither");
   AVSD_REQUIRE(B > 0 && frames > 0 && frames <= 32 && hw > 0 && heads > 0, "temporal attention: bad sizes (frames <= 32)");
   AVSD_REQUIRE(heads * frames <= 256, "temporal attention: heads*frames (%d) must be <= 256", heads * frames);
   AVSD_REQUIRE(ldqkv % 8 == 0 && ldo % 8 == 0, "temporal attention: strides must be multiples of 8");
   AVSD_REQUIRE((size_t)frames * 2 * heads * d * 2 <= 160 * 1024, "temporal attention: K/V slab exceeds LDS");
   TAttnArgs a;
-  a.QKV = (const h16_t*)QKV; a.O = (h16_t*)O; a.ldqkv = ldqkv; a.ldo = ldo;
+  a.QKV = (const h16_t*)QKV; a.O = (h16_t*)O; a.ldqkv = ldqkv; a.ldo = ldo; a.qkv_lo = qkv_lo; a.o_lo = o_lo;
   a.frames = frames; a.hw = hw; a.heads = heads; a.scale = scale;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (d) {

@@ -85,6 +85,37 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
   return v;
 }
 
+// ---- split-precision ("x2") storage: a tensor is a PAIR of 16-bit planes with identical strides, main = round16(v) and
+// rest = round16(v - main), `lo` = element offset from the main to the rest plane.  main + rest carries 16 (bf16) / 22 (fp16)
+// significant bits; every kernel reconstructs v = main + rest in f32 (exact) and writes both planes back. ------------------
+template <bool X2>
+__device__ __forceinline__ void load8(const h16_t* p, int64_t lo, float* f) {
+  unpack8(*reinterpret_cast<const uint4*>(p), f);
+  if constexpr (X2) {
+    float g[8];
+    unpack8(*reinterpret_cast<const uint4*>(p + lo), g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] += g[e];
+  }
+}
+template <bool X2>
+__device__ __forceinline__ void store8(h16_t* p, int64_t lo, const float* f) {
+  const uint4 h = pack8(f);
+  *reinterpret_cast<uint4*>(p) = h;
+  if constexpr (X2) {
+    float hf[8], r[8];
+    unpack8(h, hf);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = f[e] - hf[e];
+    *reinterpret_cast<uint4*>(p + lo) = pack8(r);
+  }
+}
+// one value: main plane word and the rest that rounding left
+__device__ __forceinline__ void split2(float a, float b, uint32_t& main, uint32_t& rest) {
+  main = pack2h(a, b);
+  rest = pack2h(a - lo2f(main), b - hi2f(main));
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // erf-GELU (torch F.gelu default; diffusers GEGLU): 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz & Stegun 7.1.26
 // (|error| <= 1.5e-7 — two orders below the 16-bit rounding of the result; libm's erff costs ~3x the instructions, and a

@@ -11,7 +11,8 @@
 
 namespace {
 
-__global__ void ncfhw_to_rows_kernel(const float* src, h16_t* dst, int B, int C, int F, int HW, int cpad,
+// dst_lo != 0: split-precision planes (main + rest, avsd_common.h)
+__global__ void ncfhw_to_rows_kernel(const float* src, h16_t* dst, int64_t dst_lo, int B, int C, int F, int HW, int cpad,
                                      int rep, float scale) {
   // one thread per (rep, b, f, p); writes cpad channels
   const int64_t n = (int64_t)rep * B * F * HW;
@@ -23,7 +24,9 @@ __global__ void ncfhw_to_rows_kernel(const float* src, h16_t* dst, int B, int C,
     for (int c = 0; c < cpad; ++c) {
       float v = 0.f;
       if (c < C) v = src[(((int64_t)b * C + c) * F + f) * HW + p] * scale;
-      o[c] = f2h(v);
+      const h16_t m = f2h(v);
+      o[c] = m;
+      if (dst_lo) o[dst_lo + c] = f2h(v - h2f(m));
     }
   }
 }
@@ -52,7 +55,17 @@ __global__ void timestep_embedding_kernel(const float* t, float* out, int n, int
 }
 
 // out[m, n] = act_out(sum_k act_in(x[m, k]) * W[n, k] + bias[n]); one wave per n, 8 rows per block.y
-__global__ __launch_bounds__(256) void linear_small_m_kernel(const float* x, const h16_t* W, const float* bias,
+__global__ void split_f32_kernel(const float* src, h16_t* dst, int64_t dst_lo, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = src[i];
+    const h16_t m = f2h(v);
+    dst[i] = m;
+    if (dst_lo) dst[dst_lo + i] = f2h(v - h2f(m));
+  }
+}
+
+template <bool X2>
+__global__ __launch_bounds__(256) void linear_small_m_kernel(const float* x, const h16_t* W, int64_t w_lo, const float* bias,
                                                              float* out, int M, int N, int K, int ldw, int act_in,
                                                              int act_out) {
   const int lane = threadIdx.x & 63;
@@ -66,7 +79,7 @@ __global__ __launch_bounds__(256) void linear_small_m_kernel(const float* x, con
   const h16_t* wrow = W + (int64_t)n * ldw;
   for (int k = lane * 8; k < K; k += 512) {
     float w[8];
-    unpack8(*reinterpret_cast<const uint4*>(wrow + k), w);
+    load8<X2>(wrow + k, w_lo, w);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       if (i < mcount) {
@@ -128,25 +141,28 @@ __global__ void guided_step_kernel(const GuidedArgs a) {
   }
 }
 
-__global__ void vae_postprocess_kernel(const h16_t* src, int ld, float* dst, int N, int HW) {
+__global__ void vae_postprocess_kernel(const h16_t* src, int ld, int64_t src_lo, float* dst, int N, int HW) {
   const int64_t n = (int64_t)N * 3 * HW;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int p = (int)(i % HW);
     const int c = (int)((i / HW) % 3);
     const int im = (int)(i / ((int64_t)3 * HW));
-    const float v = h2f(src[((int64_t)im * HW + p) * ld + c]) * 0.5f + 0.5f;
+    const int64_t o = ((int64_t)im * HW + p) * ld + c;
+    const float x = h2f(src[o]) + (src_lo ? h2f(src[src_lo + o]) : 0.f);
+    const float v = x * 0.5f + 0.5f;
     dst[i] = fminf(fmaxf(v, 0.f), 1.f);
   }
 }
 
 // channels-last bf16 rows [N*HW][ld] -> uint8 frames (N, H, W, 3): (clamp(x/2+0.5, 0, 1) * 255) truncated, i.e. the
 // pipeline's post-processing (:212) followed by generate_videos' `(video.permute(0,2,3,1) * 255).byte()` (:448)
-__global__ void vae_postprocess_u8_kernel(const h16_t* src, int ld, uint8_t* dst, int64_t npix) {
+__global__ void vae_postprocess_u8_kernel(const h16_t* src, int ld, int64_t src_lo, uint8_t* dst, int64_t npix) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
     const h16_t* s = src + i * ld;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float v = fminf(fmaxf(h2f(s[c]) * 0.5f + 0.5f, 0.f), 1.f);
+      const float x = h2f(s[c]) + (src_lo ? h2f(s[src_lo + c]) : 0.f);
+      const float v = fminf(fmaxf(x * 0.5f + 0.5f, 0.f), 1.f);
       dst[i * 3 + c] = (uint8_t)(v * 255.0f);
     }
   }
@@ -196,13 +212,26 @@ __global__ void xattn_pack_kv_kernel(const h16_t* kv, int rows, int C, const int
 
 }  // namespace
 
-extern "C" int avsd_ncfhw_to_rows(const float* src, void* dst, int B, int C, int F, int HW, int cpad, int rep,
-                                  float scale, void* stream) {
+extern "C" int avsd_ncfhw_to_rows_x2(const float* src, void* dst, int64_t dst_lo, int B, int C, int F, int HW, int cpad, int rep,
+                                     float scale, void* stream) {
   AVSD_REQUIRE(src && dst && B > 0 && C > 0 && F > 0 && HW > 0 && cpad >= C && rep >= 1, "ncfhw_to_rows: bad arguments");
   const int64_t n = (int64_t)rep * B * F * HW;
   hipLaunchKernelGGL(ncfhw_to_rows_kernel, dim3(grid_for(n, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     src, (h16_t*)dst, B, C, F, HW, cpad, rep, scale);
+                     src, (h16_t*)dst, dst_lo, B, C, F, HW, cpad, rep, scale);
   AVSD_CHECK_LAUNCH("ncfhw_to_rows launch");
+  return AVSD_OK;
+}
+
+extern "C" int avsd_ncfhw_to_rows(const float* src, void* dst, int B, int C, int F, int HW, int cpad, int rep,
+                                  float scale, void* stream) {
+  return avsd_ncfhw_to_rows_x2(src, dst, 0, B, C, F, HW, cpad, rep, scale, stream);
+}
+
+extern "C" int avsd_split_f32(const float* src, void* dst, int64_t dst_lo, int64_t n, void* stream) {
+  AVSD_REQUIRE(src && dst && n > 0, "split_f32: bad arguments");
+  hipLaunchKernelGGL(split_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src,
+                     (h16_t*)dst, dst_lo, n);
+  AVSD_CHECK_LAUNCH("split_f32 launch");
   return AVSD_OK;
 }
 
@@ -223,16 +252,25 @@ extern "C" int avsd_timestep_embedding(const float* t, float* out, int n, int di
   return AVSD_OK;
 }
 
-extern "C" int avsd_linear_small_m(const float* x, const void* W, const float* bias, float* out, int M, int N, int K,
-                                   int ldw, int act_in, int act_out, void* stream) {
+extern "C" int avsd_linear_small_m_x2(const float* x, const void* W, int64_t w_lo, const float* bias, float* out, int M, int N, int K,
+                                      int ldw, int act_in, int act_out, void* stream) {
   AVSD_REQUIRE(x && W && out, "linear_small_m: null pointer");
-  AVSD_REQUIRE(M > 0 && M <= 64 && N > 0 && K > 0 && K % 8 == 0 && ldw % 8 == 0 && ldw >= K,
+  AVSD_REQUIRE(M > 0 && M <= 64 && N > 0 && K > 0 && K % 8 == 0 && ldw % 8 == 0 && ldw >= K && w_lo % 8 == 0,
                "linear_small_m: need 0 < M <= 64, K %% 8 == 0, ldw %% 8 == 0 (M=%d N=%d K=%d ldw=%d)", M, N, K, ldw);
   dim3 grid((unsigned)((N + 3) / 4), (unsigned)((M + 7) / 8));
-  hipLaunchKernelGGL(linear_small_m_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
-                     (const h16_t*)W, bias, out, M, N, K, ldw, act_in, act_out);
+  if (w_lo != 0)
+    hipLaunchKernelGGL(linear_small_m_kernel<true>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+                       (const h16_t*)W, w_lo, bias, out, M, N, K, ldw, act_in, act_out);
+  else
+    hipLaunchKernelGGL(linear_small_m_kernel<false>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+                       (const h16_t*)W, w_lo, bias, out, M, N, K, ldw, act_in, act_out);
   AVSD_CHECK_LAUNCH("linear_small_m launch");
   return AVSD_OK;
+}
+
+extern "C" int avsd_linear_small_m(const float* x, const void* W, const float* bias, float* out, int M, int N, int K,
+                                   int ldw, int act_in, int act_out, void* stream) {
+  return avsd_linear_small_m_x2(x, W, 0, bias, out, M, N, K, ldw, act_in, act_out, stream);
 }
 
 extern "C" int avsd_guided_step(const float* noise_pred, int n_branch, float g, float g2, float* eps_hist, int store_slot,
@@ -256,22 +294,30 @@ extern "C" int avsd_guided_step(const float* noise_pred, int n_branch, float g, 
   return AVSD_OK;
 }
 
-extern "C" int avsd_vae_postprocess(const void* src, int ld, float* dst, int N, int HW, void* stream) {
+extern "C" int avsd_vae_postprocess_x2(const void* src, int ld, int64_t src_lo, float* dst, int N, int HW, void* stream) {
   AVSD_REQUIRE(src && dst && N > 0 && HW > 0 && ld >= 3, "vae_postprocess: bad arguments");
   const int64_t n = (int64_t)N * 3 * HW;
   hipLaunchKernelGGL(vae_postprocess_kernel, dim3(grid_for(n, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     (const h16_t*)src, ld, dst, N, HW);
+                     (const h16_t*)src, ld, src_lo, dst, N, HW);
   AVSD_CHECK_LAUNCH("vae_postprocess launch");
   return AVSD_OK;
 }
 
-extern "C" int avsd_vae_postprocess_u8(const void* src, int ld, void* dst, int N, int HW, void* stream) {
+extern "C" int avsd_vae_postprocess(const void* src, int ld, float* dst, int N, int HW, void* stream) {
+  return avsd_vae_postprocess_x2(src, ld, 0, dst, N, HW, stream);
+}
+
+extern "C" int avsd_vae_postprocess_u8_x2(const void* src, int ld, int64_t src_lo, void* dst, int N, int HW, void* stream) {
   AVSD_REQUIRE(src && dst && N > 0 && HW > 0 && ld >= 3, "vae_postprocess_u8: bad arguments");
   const int64_t n = (int64_t)N * HW;
   hipLaunchKernelGGL(vae_postprocess_u8_kernel, dim3(grid_for(n, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     (const h16_t*)src, ld, (uint8_t*)dst, n);
+                     (const h16_t*)src, ld, src_lo, (uint8_t*)dst, n);
   AVSD_CHECK_LAUNCH("vae_postprocess_u8 launch");
   return AVSD_OK;
+}
+
+extern "C" int avsd_vae_postprocess_u8(const void* src, int ld, void* dst, int N, int HW, void* stream) {
+  return avsd_vae_postprocess_u8_x2(src, ld, 0, dst, N, HW, stream);
 }
 
 extern "C" int avsd_copy(const void* src, void* dst, int64_t bytes, int rep, void* stream) {

@@ -295,18 +295,23 @@ __device__ __forceinline__ unsigned a_voffset(const avsd_gemm_desc& p, const Row
 // per-piece address state), so the ~100-cycle issue cost of each 1-KiB LDS-DMA piece (every wave of the block pushing
 // its pieces into the texture path right after the barrier) no longer sits in front of the MFMA waves' matrix work.
 // All waves meet at the one barrier per K tile; loaders wait for their loads to land before it.
-template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int LW = 0>
+// X2 (AVSD_GEMM_X2, split precision): every operand is a (main, rest) pair of planes.  A stage holds both planes of both
+// operands ([A | W | A rest | W rest]; the rest planes are fetched with the same per-lane offsets through a second buffer
+// descriptor), and every fragment pair contributes three MFMAs: W.A + Wr.A + W.Ar.
+template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int LW = 0, bool X2 = false>
 __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm2_kernel(const avsd_gemm_desc p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem2[];
   constexpr int NC = WM * WN;               // MFMA waves
   constexpr int NWAVES = LW > 0 ? LW : NC;  // waves that issue loads
   constexpr int A_BYTES = BM * 128;
   constexpr int W_BYTES = BN * 128;
-  constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
+  constexpr int PLANE_BYTES = A_BYTES + W_BYTES;
+  constexpr int STAGE_BYTES = PLANE_BYTES * (X2 ? 2 : 1);
   constexpr int PA = (BM / 8) / NWAVES;   // 1-KiB pieces of the A tile per loading wave
   constexpr int PW = (BN / 8) / NWAVES;
   static_assert(PA * NWAVES * 8 == BM && PW * NWAVES * 8 == BN, "tile rows must split evenly into 1-KiB pieces per wave");
-  constexpr int LPT = PA + PW;            // loads per tile per loading wave
+  constexpr int LPT = (PA + PW) * (X2 ? 2 : 1);   // loads per tile per loading wave
+  static_assert((STAGES - 2) * LPT < 64, "vmcnt is a 6-bit counter");
   constexpr int FM = BM / WM / 32;
   constexpr int FN = BN / WN / 32;
 
@@ -354,6 +359,10 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm2_kernel(const avsd_g
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)A2b, 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, 0x7fffffff, 0x00020000);
+  // rest planes (X2): same offsets, other base
+  const __amdgpu_buffer_rsrc_t rsAr = __builtin_amdgcn_make_buffer_rsrc((void*)(Ab + (X2 ? p.a_lo : 0)), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA2r = __builtin_amdgcn_make_buffer_rsrc((void*)(A2b + (X2 ? (p.A2 ? p.a2_lo : p.a_lo) : 0)), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsWr = __builtin_amdgcn_make_buffer_rsrc((void*)(Wb + (X2 ? p.w_lo : 0)), 0, 0x7fffffff, 0x00020000);
 
   // ---- this lane's (row, k-chunk) for each of its pieces: line L = piece*4 + lane/16, slot = lane%16 ----
   // (scalars in separate statically-indexed arrays: a struct array selected by a runtime field goes to scratch)
@@ -443,12 +452,21 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm2_kernel(const avsd_g
       lds_ptr_t dst = (lds_ptr_t)(sb + (wave + j * NWAVES) * 1024);
       if (i_second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, dst, 16, (int)vo, 0, 0, 0);
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, dst, 16, (int)vo, 0, 0, 0);
+      if constexpr (X2) {
+        lds_ptr_t dr = (lds_ptr_t)(sb + PLANE_BYTES + (wave + j * NWAVES) * 1024);
+        if (i_second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2r, dr, 16, (int)vo, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsAr, dr, 16, (int)vo, 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int j = 0; j < PW; ++j) {
       const unsigned vo = (wv[j] && kbase + kcw[j] < p.K) ? (unsigned)(wo[j] + kbase) * 2u : OOB;
       lds_ptr_t dst = (lds_ptr_t)(sb + A_BYTES + (wave + j * NWAVES) * 1024);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, dst, 16, (int)vo, 0, 0, 0);
+      if constexpr (X2) {
+        lds_ptr_t dr = (lds_ptr_t)(sb + PLANE_BYTES + A_BYTES + (wave + j * NWAVES) * 1024);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsWr, dr, 16, (int)vo, 0, 0, 0);
+      }
     }
     // advance the decode state to the next K tile
     i_kbase += BK;
@@ -542,6 +560,25 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm2_kernel(const avsd_g
 #pragma unroll
       for (int a = 0; a < FN; ++a)
         wf[a] = *reinterpret_cast<const h16x8*>(sW + w_line[a] + (((w_hi[a] | c) ^ w_sw[a]) << 4));
+      if constexpr (X2) {
+        h16x8 xr[FM], wr[FN];
+#pragma unroll
+        for (int b = 0; b < FM; ++b)
+          xr[b] = *reinterpret_cast<const h16x8*>(sA + PLANE_BYTES + a_line[b] + (((a_hi[b] | c) ^ a_sw[b]) << 4));
+#pragma unroll
+        for (int a = 0; a < FN; ++a)
+          wr[a] = *reinterpret_cast<const h16x8*>(sW + PLANE_BYTES + w_line[a] + (((w_hi[a] | c) ^ w_sw[a]) << 4));
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int a = 0; a < FN; ++a)
+#pragma unroll
+          for (int b = 0; b < FM; ++b) {
+            acc[a][b] = mfma32x32x16(wr[a], xf[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = mfma32x32x16(wf[a], xr[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = mfma32x32x16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+          }
+        __builtin_amdgcn_s_setprio(0);
+      } else {
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int a = 0; a < FN; ++a)
@@ -549,6 +586,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm2_kernel(const avsd_g
         for (int b = 0; b < FM; ++b)
           acc[a][b] = mfma32x32x16(wf[a], xf[b], acc[a][b], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
+      }
     }
   }
 
@@ -614,7 +652,8 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm2_kernel(const avsd_g
       }
     }
   }
-  epilogue<FN, FM, (64 * (WM * WN + LW) > 512)>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
+  if constexpr (X2) epilogue_x2<FN, FM>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
+  else epilogue<FN, FM, (64 * (WM * WN + LW) > 512)>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
 }
 
 // out = epilogue(sum_s ws[s]) for split-K launches: one thread per 4 consecutive columns
@@ -623,6 +662,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const avsd_gemm_desc
   const int64_t total = (int64_t)p.M * nq;
   const h16_t* R1 = reinterpret_cast<const h16_t*>(p.res1);
   const h16_t* R2 = reinterpret_cast<const h16_t*>(p.res2);
+  const bool x2 = (p.flags & AVSD_GEMM_X2) != 0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int m = (int)(i / nq);
     const int n = (int)(i - (int64_t)m * nq) * 4;
@@ -661,6 +701,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const avsd_gemm_desc
       } else {
         const uint2 rr = *reinterpret_cast<const uint2*>(R1 + (int64_t)m * p.ldr1 + n);
         v[0] += lo2f(rr.x); v[1] += hi2f(rr.x); v[2] += lo2f(rr.y); v[3] += hi2f(rr.y);
+        if (x2) {
+          const uint2 r2 = *reinterpret_cast<const uint2*>(R1 + p.res1_lo + (int64_t)m * p.ldr1 + n);
+          v[0] += lo2f(r2.x); v[1] += hi2f(r2.x); v[2] += lo2f(r2.y); v[3] += hi2f(r2.y);
+        }
       }
     }
     if (R2) {
@@ -670,6 +714,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const avsd_gemm_desc
       } else {
         const uint2 rr = *reinterpret_cast<const uint2*>(R2 + (int64_t)m * p.ldr2 + n);
         v[0] += lo2f(rr.x); v[1] += hi2f(rr.x); v[2] += lo2f(rr.y); v[3] += hi2f(rr.y);
+        if (x2) {
+          const uint2 r2 = *reinterpret_cast<const uint2*>(R2 + p.res2_lo + (int64_t)m * p.ldr2 + n);
+          v[0] += lo2f(r2.x); v[1] += hi2f(r2.x); v[2] += lo2f(r2.y); v[3] += hi2f(r2.y);
+        }
       }
     }
     if (p.out_master) *reinterpret_cast<float4*>(p.out_master + (int64_t)m * p.ldm + n) = make_float4(v[0], v[1], v[2], v[3]);
@@ -681,10 +729,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const avsd_gemm_desc
       st.x = pack2h(v[0], v[1]);
       st.y = pack2h(v[2], v[3]);
       *reinterpret_cast<uint2*>(reinterpret_cast<h16_t*>(p.out) + o) = st;
+      float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;     // x2: what the rest plane adds to the stored value
+      if (x2) {
+        uint2 sr;
+        sr.x = pack2h(v[0] - lo2f(st.x), v[1] - hi2f(st.x));
+        sr.y = pack2h(v[2] - lo2f(st.y), v[3] - hi2f(st.y));
+        *reinterpret_cast<uint2*>(reinterpret_cast<h16_t*>(p.out) + p.out_lo + o) = sr;
+        e0 = lo2f(sr.x); e1 = hi2f(sr.x); e2 = lo2f(sr.y); e3 = hi2f(sr.y);
+      }
       if (p.flags & AVSD_GEMM_ROWSTATS) {
         // 8 consecutive threads hold one 32-column block of row m (N % 32 == 0, 256 % 8 == 0): fold in a fixed order
-        const float a0 = lo2f(st.x), a1 = hi2f(st.x);
-        const float a2 = lo2f(st.y), a3 = hi2f(st.y);
+        const float a0 = lo2f(st.x) + e0, a1 = hi2f(st.x) + e1;
+        const float a2 = lo2f(st.y) + e2, a3 = hi2f(st.y) + e3;
         float sm = (a0 + a1) + (a2 + a3);
         float sq = fmaf(a0, a0, fmaf(a1, a1, fmaf(a2, a2, a3 * a3)));
 #pragma unroll
@@ -699,12 +755,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const avsd_gemm_desc
   }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int LW = 0>
+template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int LW = 0, bool X2 = false>
 int launch2(const avsd_gemm_desc& d, hipStream_t s) {
-  constexpr size_t lds = (size_t)STAGES * (BM + BN) * 128;
+  constexpr size_t lds = (size_t)STAGES * (BM + BN) * 128 * (X2 ? 2 : 1);
+  static_assert(lds <= 160 * 1024, "tile does not fit the 160 KB of LDS");
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<BM, BN, WM, WN, STAGES, MODE, LW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<BM, BN, WM, WN, STAGES, MODE, LW, X2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       avsd_set_error("gemm2: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
@@ -715,7 +772,7 @@ int launch2(const avsd_gemm_desc& d, hipStream_t s) {
   const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
   const int nsplit = d.split_k > 1 ? d.split_k : 1;
   dim3 grid((unsigned)(ntm * ntn), (unsigned)nsplit, (unsigned)d.batch);
-  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM, WN, STAGES, MODE, LW>), grid, dim3(64 * (WM * WN + LW)), lds, s, d);
+  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM, WN, STAGES, MODE, LW, X2>), grid, dim3(64 * (WM * WN + LW)), lds, s, d);
   AVSD_CHECK_LAUNCH("gemm2 launch");
   if (nsplit > 1 && d.splitk_cnt == nullptr) {
     const int64_t total = (int64_t)d.M * (d.N / 4);
@@ -776,6 +833,23 @@ int dispatch_tile(const avsd_gemm_desc& d, int tile, hipStream_t s) {
   }
 }
 
+// split-precision tiles: the subset whose doubled stage still fits LDS
+template <int MODE>
+int dispatch_tile_x2(const avsd_gemm_desc& d, int tile, hipStream_t s) {
+  switch (tile) {
+    case 4: return launch2<128, 64, 2, 2, 3, MODE, 0, true>(d, s);     // 144 KB
+    case 7: return launch2<64, 64, 2, 2, 4, MODE, 0, true>(d, s);      // 128 KB
+    case 11: return launch2<128, 128, 2, 2, 2, MODE, 0, true>(d, s);   // 128 KB
+    case 12: return launch2<128, 64, 2, 2, 2, MODE, 0, true>(d, s);    // 96 KB
+    case 13: return launch2<64, 64, 2, 2, 2, MODE, 0, true>(d, s);     // 64 KB: two blocks per CU
+    case 24: return launch2<128, 64, 2, 2, 3, MODE, 2, true>(d, s);    // 144 KB, loader waves
+    case 25: return launch2<64, 64, 2, 2, 4, MODE, 2, true>(d, s);     // 128 KB, loader waves
+    default:
+      avsd_set_error("gemm: AVSD_GEMM_X2 runs on tiles 4, 7, 11, 12, 13, 24, 25 (got %d)", tile);
+      return AVSD_EINVAL;
+  }
+}
+
 // Wave-quantised cost model: 2 resident blocks per CU, relative per-tile MFMA efficiency.
 int pick_tile(int M, int N, int batch) {
   static int num_cu = 0;
@@ -817,6 +891,17 @@ int avsd_gemm_dispatch_tmix(const avsd_gemm_desc& d, int tile, hipStream_t s) { 
 #endif
 #if !defined(AVSD_GEMM_TU) || AVSD_GEMM_TU == 2
 int avsd_gemm_dispatch_conv3(const avsd_gemm_desc& d, int tile, hipStream_t s) { return dispatch_tile<AVSD_GEMM_CONV3>(d, tile, s); }
+#endif
+
+int avsd_gemm_dispatch_x2_plain(const avsd_gemm_desc& d, int tile, hipStream_t s);
+int avsd_gemm_dispatch_x2_tmix(const avsd_gemm_desc& d, int tile, hipStream_t s);
+int avsd_gemm_dispatch_x2_conv3(const avsd_gemm_desc& d, int tile, hipStream_t s);
+#if !defined(AVSD_GEMM_TU) || AVSD_GEMM_TU == 4
+int avsd_gemm_dispatch_x2_plain(const avsd_gemm_desc& d, int tile, hipStream_t s) { return dispatch_tile_x2<AVSD_GEMM_PLAIN>(d, tile, s); }
+int avsd_gemm_dispatch_x2_tmix(const avsd_gemm_desc& d, int tile, hipStream_t s) { return dispatch_tile_x2<AVSD_GEMM_TMIX>(d, tile, s); }
+#endif
+#if !defined(AVSD_GEMM_TU) || AVSD_GEMM_TU == 5
+int avsd_gemm_dispatch_x2_conv3(const avsd_gemm_desc& d, int tile, hipStream_t s) { return dispatch_tile_x2<AVSD_GEMM_CONV3>(d, tile, s); }
 #endif
 
 #if !defined(AVSD_GEMM_TU) || AVSD_GEMM_TU == 3
@@ -872,6 +957,23 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
     AVSD_REQUIRE(d.tile >= 4 && d.tile <= AVSD_GEMM_MAX_TILE, "gemm: split_k needs an LDS-direct tile (4..33), got %d", d.tile);
     AVSD_REQUIRE(d.split_k <= (d.K + 63) / 64, "gemm: split_k (%d) exceeds the number of K tiles", d.split_k);
     AVSD_REQUIRE(!d.splitk_cnt || d.N % 32 == 0, "gemm: the in-launch split-K reduction needs N %% 32 == 0 (got %d)", d.N);
+  }
+  if (d.flags & AVSD_GEMM_X2) {
+    AVSD_REQUIRE(d.a_lo != 0 && d.w_lo != 0 && (!d.A2 || d.a2_lo != 0), "gemm/x2: A, A2 and W need their rest-plane offsets");
+    AVSD_REQUIRE((d.flags & AVSD_GEMM_OUT_F32) || d.out_lo != 0, "gemm/x2: a 16-bit output needs out_lo");
+    AVSD_REQUIRE(!d.res1 || (d.flags & AVSD_GEMM_RES1_F32) || d.res1_lo != 0, "gemm/x2: a 16-bit res1 needs res1_lo");
+    AVSD_REQUIRE(!d.res2 || (d.flags & AVSD_GEMM_RES2_F32) || d.res2_lo != 0, "gemm/x2: a 16-bit res2 needs res2_lo");
+    AVSD_REQUIRE(((d.a_lo | d.a2_lo | d.w_lo | d.out_lo | d.res1_lo | d.res2_lo) & 7) == 0, "gemm/x2: plane offsets must be multiples of 8 elements");
+    AVSD_REQUIRE(!d.out_master && !d.splitk_cnt && d.batch_stride_w == 0, "gemm/x2: no f32 master, in-launch split-K reduction or batched weights");
+    AVSD_REQUIRE(d.mode != AVSD_GEMM_PLAIN || !d.A2 || d.k_split % 64 == 0, "gemm/x2: a two-source A needs k_split %% 64 == 0 (got %d)", d.k_split);
+    const double a_rows = d.mode == AVSD_GEMM_CONV3 ? (double)(d.M / (d.ho * d.wo)) * d.hs * d.ws : (double)d.M;
+    AVSD_REQUIRE(a_rows * d.lda * 2.0 < 2147483648.0 && (double)d.N * d.ldw * 2.0 < 2147483648.0, "gemm/x2: operands must be < 2 GiB per plane");
+    hipStream_t sx = reinterpret_cast<hipStream_t>(stream);
+    switch (d.mode) {
+      case AVSD_GEMM_PLAIN: return avsd_gemm_dispatch_x2_plain(d, d.tile, sx);
+      case AVSD_GEMM_TMIX: return avsd_gemm_dispatch_x2_tmix(d, d.tile, sx);
+      default: return avsd_gemm_dispatch_x2_conv3(d, d.tile, sx);
+    }
   }
   int tile = d.tile;
   // v2 tiles (>= 4) address A/W with 32-bit byte offsets: fall back to v1 for tensors >= 2 GiB

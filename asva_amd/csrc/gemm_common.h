@@ -518,6 +518,122 @@ __device__ __forceinline__ void epilogue(const avsd_gemm_desc& p, f32x16 (&acc)[
   else epilogue_by_fragment<FN, FM>(p, acc, m_base, n_base, lane, bz, pre_ln, have_pre);
 }
 
+// ---- AVSD_GEMM_X2 epilogue: same terms and f32 order as above; 16-bit residuals are read as main + rest, the result is
+// written as main = round16(v), rest = round16(v - main); LayerNorm row statistics are taken from main + rest (what the
+// consumer reconstructs).  Fragment-at-a-time, 8-byte stores (the precise tier trades the wide-store form for one code path).
+template <int FN, int FM>
+__device__ __forceinline__ void epilogue_x2(const avsd_gemm_desc& p, f32x16 (&acc)[FN][FM], int m_base, int n_base,
+                                            int lane, int64_t bz, const float (&pre_ln)[2 * FM], bool have_pre) {
+  const int frow = lane & 31;
+  const bool geglu = (p.flags & AVSD_GEMM_GEGLU) != 0;
+  const bool out_f32 = (p.flags & AVSD_GEMM_OUT_F32) != 0;
+  const bool gelu = (p.flags & AVSD_GEMM_GELU) != 0;
+  const bool lnfuse = (p.flags & AVSD_GEMM_LNFUSE) != 0;
+  const bool rowstats = (p.flags & AVSD_GEMM_ROWSTATS) != 0;
+  const bool r1f = (p.flags & AVSD_GEMM_RES1_F32) != 0, r2f = (p.flags & AVSD_GEMM_RES2_F32) != 0;
+  const h16_t* R1 = reinterpret_cast<const h16_t*>(p.res1);
+  const h16_t* R2 = reinterpret_cast<const h16_t*>(p.res2);
+  h16_t* O = reinterpret_cast<h16_t*>(p.out);
+  const int hsel = (lane >> 5) * 4;
+  const int64_t bo = bz * p.batch_stride_out;
+#pragma unroll
+  for (int b = 0; b < FM; ++b) {
+    const int m = m_base + b * 32 + frow;
+    if (m >= p.M) continue;
+    const float* rv = p.rowvec ? p.rowvec + (int64_t)(m / p.rows_per_vec) * p.ldv : nullptr;
+    float ln_rstd = 1.f, ln_mr = 0.f;
+    if (lnfuse) {
+      if (have_pre) { ln_rstd = pre_ln[2 * b]; ln_mr = pre_ln[2 * b + 1]; }
+      else ln_row_stats(p, m, bz, ln_rstd, ln_mr);
+    }
+    float2* rs_out = rowstats ? reinterpret_cast<float2*>(p.rowstats) + ((int64_t)bz * p.M + m) * (p.N >> 5) : nullptr;
+    const int64_t orow = bo + (int64_t)m * p.ldc;
+    auto head = [&](int a, int q, int n, float (&v)[4]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = p.alpha * acc[a][b][4 * q + i];
+      if (lnfuse) {
+        const float4 cs = *reinterpret_cast<const float4*>(p.ln_colsum + n);
+        v[0] = fmaf(v[0], ln_rstd, -ln_mr * cs.x); v[1] = fmaf(v[1], ln_rstd, -ln_mr * cs.y);
+        v[2] = fmaf(v[2], ln_rstd, -ln_mr * cs.z); v[3] = fmaf(v[3], ln_rstd, -ln_mr * cs.w);
+      }
+      if (p.bias) {
+        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+      }
+      if (rv) {
+        const float4 bb = *reinterpret_cast<const float4*>(rv + n);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+      }
+    };
+    auto add_res = [&](const h16_t* R, int64_t rlo, int ldr, bool f32, int n, float (&v)[4]) {
+      if (f32) {
+        const float4 rr = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(R) + bo + (int64_t)m * ldr + n);
+        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+      } else {
+        const h16_t* rp = R + bo + (int64_t)m * ldr + n;
+        const uint2 a = *reinterpret_cast<const uint2*>(rp);
+        const uint2 r = *reinterpret_cast<const uint2*>(rp + rlo);
+        v[0] += lo2f(a.x) + lo2f(r.x); v[1] += hi2f(a.x) + hi2f(r.x);
+        v[2] += lo2f(a.y) + lo2f(r.y); v[3] += hi2f(a.y) + hi2f(r.y);
+      }
+    };
+    // main / rest words of 4 values -> the two planes; returns (sum, sum of squares) of the values as the consumer sees them
+    auto store4 = [&](int64_t o, const float (&v)[4], float& sm, float& sq) {
+      uint2 st, sr;
+      split2(v[0], v[1], st.x, sr.x);
+      split2(v[2], v[3], st.y, sr.y);
+      *reinterpret_cast<uint2*>(O + o) = st;
+      *reinterpret_cast<uint2*>(O + p.out_lo + o) = sr;
+      const float w[4] = {lo2f(st.x) + lo2f(sr.x), hi2f(st.x) + hi2f(sr.x), lo2f(st.y) + lo2f(sr.y), hi2f(st.y) + hi2f(sr.y)};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { sm += w[i]; sq = fmaf(w[i], w[i], sq); }
+    };
+#pragma unroll
+    for (int a = 0; a < FN; ++a) {
+      const int nb = n_base + a * 32;
+      if (nb >= p.N) continue;
+      if (!geglu) {
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = nb + 8 * q + hsel;
+          if (n >= p.N) continue;
+          float v[4];
+          head(a, q, n, v);
+          if (gelu) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = gelu_erf_f(v[i]);
+          }
+          if (R1) add_res(R1, p.res1_lo, p.ldr1, r1f, n, v);
+          if (R2) add_res(R2, p.res2_lo, p.ldr2, r2f, n, v);
+          if (out_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow + n) = make_float4(v[0], v[1], v[2], v[3]);
+          else store4(orow + n, v, sm, sq);
+        }
+        if (rs_out) {        // ROWSTATS: N % 32 == 0, so the fragment is whole; this lane's 16 values + the partner lane's 16
+          const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(sm), __float_as_uint(sm), false, false);
+          const auto u = __builtin_amdgcn_permlane32_swap(__float_as_uint(sq), __float_as_uint(sq), false, false);
+          if (hsel == 0) rs_out[nb >> 5] = make_float2(__uint_as_float(t[0]) + __uint_as_float(t[1]),
+                                                       __uint_as_float(u[0]) + __uint_as_float(u[1]));
+        }
+      } else {
+        // GEGLU: packed 32-row block = [16 value rows | 16 gate rows]; quads 0,1 hold values, 2,3 their gates
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          float v[4], gate[4];
+          head(a, q, nb + 8 * q + hsel, v);
+          head(a, q + 2, nb + 8 * q + hsel + 16, gate);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] *= gelu_erf_f(gate[i]);
+          const int64_t o = orow + (nb >> 1) + hsel + 8 * q;
+          float sm = 0.f, sq = 0.f;
+          if (out_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) = make_float4(v[0], v[1], v[2], v[3]);
+          else store4(o, v, sm, sq);
+        }
+      }
+    }
+  }
+}
+
 // s_waitcnt vmcnt(N) with N a compile-time constant (0..63), everything else unconstrained.  gfx9 encoding of the
 // immediate: vmcnt[3:0] in bits 3:0, vmcnt[5:4] in bits 15:14, expcnt (7 = no wait) in 6:4, lgkmcnt (15) in 11:8.
 template <int N>

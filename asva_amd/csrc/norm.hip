@@ -16,7 +16,9 @@ namespace {
 //                      first `groups` threads fold (positions x channels-of-group) -> partial[nb][nchunks][g][2]
 //   gn_apply_kernel    every block folds the chunk partials of its batch in double -> (mean, rstd) per group ->
 //                      scale/shift per channel in LDS, then streams its rows: y = act(x * scale[c] + shift[c])
-__global__ void gn_stats_kernel(const h16_t* x1, int ld1, int c1, const h16_t* x2, int ld2, int c2,
+// X2: split-precision planes (avsd_common.h): values are main + rest, lo1 / lo2 the offsets to the rest planes
+template <bool X2>
+__global__ void gn_stats_kernel(const h16_t* x1, int ld1, int c1, int64_t lo1, const h16_t* x2, int ld2, int c2, int64_t lo2,
                                 int rows_per_batch, int groups, float* partial, int nchunks, int nvec,
                                 int ppb) {
   extern __shared__ float sgn[];  // [ppb][2*C]: sums | sums of squares
@@ -37,24 +39,34 @@ __global__ void gn_stats_kernel(const h16_t* x1, int ld1, int c1, const h16_t* x
     for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
     const h16_t* base;
     int ld;
-    if (c0 < c1) { base = x1 + c0; ld = ld1; } else { base = x2 + (c0 - c1); ld = ld2; }
+    int64_t lo;
+    if (c0 < c1) { base = x1 + c0; ld = ld1; lo = lo1; } else { base = x2 + (c0 - c1); ld = ld2; lo = lo2; }
     base += (int64_t)b * rows_per_batch * ld;
     int r = r0 + pos0;
     for (; r + 3 * ppb < r1; r += 4 * ppb) {          // 4 independent loads in flight
-      uint4 v[4];
+      uint4 v[4], w[X2 ? 4 : 1];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4*>(base + (int64_t)(r + u * ppb) * ld);
+      for (int u = 0; u < 4; ++u) {
+        v[u] = *reinterpret_cast<const uint4*>(base + (int64_t)(r + u * ppb) * ld);
+        if constexpr (X2) w[u] = *reinterpret_cast<const uint4*>(base + lo + (int64_t)(r + u * ppb) * ld);
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         float f[8];
         unpack8(v[u], f);
+        if constexpr (X2) {
+          float g[8];
+          unpack8(w[u], g);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] += g[e];
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s[e] += f[e]; ss[e] = fmaf(f[e], f[e], ss[e]); }
       }
     }
     for (; r < r1; r += ppb) {
       float f[8];
-      unpack8(*reinterpret_cast<const uint4*>(base + (int64_t)r * ld), f);
+      load8<X2>(base + (int64_t)r * ld, lo, f);
 #pragma unroll
       for (int e = 0; e < 8; ++e) { s[e] += f[e]; ss[e] = fmaf(f[e], f[e], ss[e]); }
     }
@@ -81,10 +93,11 @@ __global__ void gn_stats_kernel(const h16_t* x1, int ld1, int c1, const h16_t* x
 // up to 64 lanes per group, double accumulation, fixed order — and builds scale[c] = rstd * gamma, shift[c] =
 // beta - mean * scale in LDS (a separate finalize launch cost a full ~5 us kernel boundary for a few KB of work), then
 // streams its share of the batch's rows: y = act(x * scale + shift), 2 vectors in flight per thread.
-__global__ __launch_bounds__(1024) void gn_apply_kernel(const h16_t* x1, int ld1, int c1, const h16_t* x2, int ld2, int c2,
-                                                       int rows_per_batch, const float* partial, int nchunks, int groups,
+template <bool X2>
+__global__ __launch_bounds__(1024) void gn_apply_kernel(const h16_t* x1, int ld1, int c1, int64_t lo1, const h16_t* x2, int ld2, int c2,
+                                                       int64_t lo2, int rows_per_batch, const float* partial, int nchunks, int groups,
                                                        float eps, const float* gamma, const float* beta, int act,
-                                                       h16_t* y, int ldy) {
+                                                       h16_t* y, int ldy, int64_t loy) {
   extern __shared__ float gn_ss[];   // [C] scale | [C] shift
   __shared__ float smean[64], srstd[64];
   const int C = c1 + c2;
@@ -147,7 +160,7 @@ __global__ __launch_bounds__(1024) void gn_apply_kernel(const h16_t* x1, int ld1
   const int total = max(r1 - r0, 0) * nvec;
   constexpr int NV = 2;                 // vectors in flight per thread
   for (int i0 = tid; i0 < total; i0 += NV * 1024) {
-    uint4 v[NV];
+    uint4 v[NV], w[X2 ? NV : 1];
     int cc[NV];
     int64_t gr[NV];
     bool ok[NV];
@@ -160,6 +173,7 @@ __global__ __launch_bounds__(1024) void gn_apply_kernel(const h16_t* x1, int ld1
       cc[u] = ok[u] ? (i - r * nvec) * 8 : 0;
       const h16_t* src = (cc[u] < c1) ? x1 + gr[u] * ld1 + cc[u] : x2 + gr[u] * ld2 + (cc[u] - c1);
       v[u] = ok[u] ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
+      if constexpr (X2) w[u] = ok[u] ? *reinterpret_cast<const uint4*>(src + ((cc[u] < c1) ? lo1 : lo2)) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
@@ -171,20 +185,26 @@ __global__ __launch_bounds__(1024) void gn_apply_kernel(const h16_t* x1, int ld1
       const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
       float f[8];
       unpack8(v[u], f);
+      if constexpr (X2) {
+        float g[8];
+        unpack8(w[u], g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] += g[e];
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float t = fmaf(f[e], sc[e], sh[e]);
         f[e] = act ? silu_f(t) : t;
       }
-      *reinterpret_cast<uint4*>(y + gr[u] * ldy + cc[u]) = pack8(f);
+      store8<X2>(y + gr[u] * ldy + cc[u], loy, f);
     }
   }
 }
 
 // ---- LayerNorm: LPR lanes per row (power of two), 64/LPR rows per wave, up to 8 vectors per lane in registers.
 // C = 320/640/1280 -> LPR = 8/16/32 with exactly 5 vectors per lane: every lane busy, 5 loads in flight per lane.
-template <int LPR>
-__global__ __launch_bounds__(256) void layernorm_kernel(const h16_t* x, int ldx, h16_t* y, int ldy, int M,
+template <int LPR, bool X2>
+__global__ __launch_bounds__(256) void layernorm_kernel(const h16_t* x, int ldx, int64_t lox, h16_t* y, int ldy, int64_t loy, int M,
                                                         int C, const float* gamma, const float* beta,
                                                         float eps, const float* pos, int hw, int frames) {
   constexpr int RPW = 64 / LPR;                 // rows per wave
@@ -200,7 +220,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const h16_t* x, int ldx,
   for (int i = 0; i < 8; ++i) {
     const int v = sub + LPR * i;
     if (rvalid && v < nvec) {
-      unpack8(*reinterpret_cast<const uint4*>(x + (int64_t)row * ldx + v * 8), f[i]);
+      load8<X2>(x + (int64_t)row * ldx + v * 8, lox, f[i]);
       if (prow) {
         const float4 p0 = *reinterpret_cast<const float4*>(prow + v * 8);
         const float4 p1 = *reinterpret_cast<const float4*>(prow + v * 8 + 4);
@@ -239,17 +259,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const h16_t* x, int ldx,
       float o[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = fmaf((f[i][e] - mean) * rstd, g[e], bb[e]);
-      *reinterpret_cast<uint4*>(y + (int64_t)row * ldy + v * 8) = pack8(o);
+      store8<X2>(y + (int64_t)row * ldy + v * 8, loy, o);
     }
   }
 }
 
 template <int LPR>
-void launch_layernorm(const h16_t* x, int ldx, h16_t* y, int ldy, int M, int C, const float* gamma, const float* beta,
-                      float eps, const float* pos, int hw, int frames, hipStream_t s) {
+void launch_layernorm(const h16_t* x, int ldx, int64_t lox, h16_t* y, int ldy, int64_t loy, int M, int C, const float* gamma,
+                      const float* beta, float eps, const float* pos, int hw, int frames, hipStream_t s) {
   const int rows_per_block = 4 * (64 / LPR);
-  hipLaunchKernelGGL(layernorm_kernel<LPR>, dim3((unsigned)((M + rows_per_block - 1) / rows_per_block)), dim3(256), 0, s, x, ldx,
-                     y, ldy, M, C, gamma, beta, eps, pos, hw, frames);
+  const dim3 grid((unsigned)((M + rows_per_block - 1) / rows_per_block));
+  if (lox != 0)
+    hipLaunchKernelGGL((layernorm_kernel<LPR, true>), grid, dim3(256), 0, s, x, ldx, lox, y, ldy, loy, M, C, gamma, beta, eps, pos, hw, frames);
+  else
+    hipLaunchKernelGGL((layernorm_kernel<LPR, false>), grid, dim3(256), 0, s, x, ldx, lox, y, ldy, loy, M, C, gamma, beta, eps, pos, hw, frames);
 }
 
 // ---- row softmax: S f32 -> P bf16, one wave per row ---------------------------------------------
@@ -321,27 +344,46 @@ static int gn_check(const void* x1, int ld1, int c1, const void* x2, int ld2, in
   return AVSD_OK;
 }
 
-extern "C" int avsd_groupnorm_stats(const void* x1, int ld1, int c1, const void* x2, int ld2, int c2, int nb,
-                                    int rows_per_batch, int groups, float* scratch, int nchunks, void* stream) {
+extern "C" int avsd_groupnorm_stats_x2(const void* x1, int ld1, int c1, int64_t lo1, const void* x2, int ld2, int c2, int64_t lo2,
+                                       int nb, int rows_per_batch, int groups, float* scratch, int nchunks, void* stream) {
   int rc = gn_check(x1, ld1, c1, x2, ld2, c2, nb, rows_per_batch, groups, nchunks);
   if (rc) return rc;
   AVSD_REQUIRE(scratch, "groupnorm_stats: null pointer");
+  AVSD_REQUIRE(lo1 % 8 == 0 && lo2 % 8 == 0 && (c2 == 0 || (lo1 != 0) == (lo2 != 0)), "groupnorm_stats: plane offsets must be multiples of 8, both sources split or neither");
   const int C = c1 + c2;
   int nvec, ppb, threads;
   gn_geometry(C, &nvec, &ppb, &threads);
   const size_t lds = (size_t)ppb * 2 * C * sizeof(float);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)nchunks, (unsigned)nb), dim3((unsigned)threads), lds, s,
-                     (const h16_t*)x1, ld1, c1, (const h16_t*)x2, ld2, c2, rows_per_batch, groups, scratch, nchunks, nvec, ppb);
+  if (lo1 != 0)
+    hipLaunchKernelGGL(gn_stats_kernel<true>, dim3((unsigned)nchunks, (unsigned)nb), dim3((unsigned)threads), lds, s, (const h16_t*)x1,
+                       ld1, c1, lo1, (const h16_t*)x2, ld2, c2, lo2, rows_per_batch, groups, scratch, nchunks, nvec, ppb);
+  else
+    hipLaunchKernelGGL(gn_stats_kernel<false>, dim3((unsigned)nchunks, (unsigned)nb), dim3((unsigned)threads), lds, s, (const h16_t*)x1,
+                       ld1, c1, lo1, (const h16_t*)x2, ld2, c2, lo2, rows_per_batch, groups, scratch, nchunks, nvec, ppb);
   AVSD_CHECK_LAUNCH("groupnorm_stats launch");
   return AVSD_OK;
+}
+
+extern "C" int avsd_groupnorm_stats(const void* x1, int ld1, int c1, const void* x2, int ld2, int c2, int nb,
+                                    int rows_per_batch, int groups, float* scratch, int nchunks, void* stream) {
+  return avsd_groupnorm_stats_x2(x1, ld1, c1, 0, x2, ld2, c2, 0, nb, rows_per_batch, groups, scratch, nchunks, stream);
 }
 
 extern "C" int avsd_groupnorm_apply(const void* x1, int ld1, int c1, const void* x2, int ld2, int c2, int nb,
                                     int rows_per_batch, int groups, const float* gamma, const float* beta, float eps,
                                     const float* scratch, int nchunks, int act, void* y, int ldy, void* stream) {
+  return avsd_groupnorm_apply_x2(x1, ld1, c1, 0, x2, ld2, c2, 0, nb, rows_per_batch, groups, gamma, beta, eps, scratch, nchunks, act,
+                                 y, ldy, 0, stream);
+}
+
+extern "C" int avsd_groupnorm_apply_x2(const void* x1, int ld1, int c1, int64_t lo1, const void* x2, int ld2, int c2, int64_t lo2,
+                                       int nb, int rows_per_batch, int groups, const float* gamma, const float* beta, float eps,
+                                       const float* scratch, int nchunks, int act, void* y, int ldy, int64_t loy, void* stream) {
   int rc = gn_check(x1, ld1, c1, x2, ld2, c2, nb, rows_per_batch, groups, nchunks);
   if (rc) return rc;
+  AVSD_REQUIRE(lo1 % 8 == 0 && lo2 % 8 == 0 && loy % 8 == 0 && (lo1 != 0) == (loy != 0) && (c2 == 0 || (lo1 != 0) == (lo2 != 0)),
+               "groupnorm_apply: plane offsets must be multiples of 8; sources and output all split or none");
   AVSD_REQUIRE(scratch && y && gamma && beta, "groupnorm_apply: null pointer");
   const int C = c1 + c2;
   AVSD_REQUIRE(ldy % 8 == 0 && ldy >= C, "groupnorm_apply: bad ldy %d", ldy);
@@ -353,16 +395,27 @@ extern "C" int avsd_groupnorm_apply(const void* x1, int ld1, int c1, const void*
   const int64_t cap = (vec_per_batch + 2047) / 2048;
   if (bpb > cap) bpb = (int)cap;
   if (bpb > rows_per_batch) bpb = rows_per_batch;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)bpb, (unsigned)nb), dim3(1024), (size_t)2 * C * sizeof(float),
-                     reinterpret_cast<hipStream_t>(stream), (const h16_t*)x1, ld1, c1, (const h16_t*)x2, ld2, c2,
-                     rows_per_batch, scratch, nchunks, groups, eps, gamma, beta, act, (h16_t*)y, ldy);
+  if (lo1 != 0)
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3((unsigned)bpb, (unsigned)nb), dim3(1024), (size_t)2 * C * sizeof(float),
+                       reinterpret_cast<hipStream_t>(stream), (const h16_t*)x1, ld1, c1, lo1, (const h16_t*)x2, ld2, c2, lo2,
+                       rows_per_batch, scratch, nchunks, groups, eps, gamma, beta, act, (h16_t*)y, ldy, loy);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3((unsigned)bpb, (unsigned)nb), dim3(1024), (size_t)2 * C * sizeof(float),
+                       reinterpret_cast<hipStream_t>(stream), (const h16_t*)x1, ld1, c1, lo1, (const h16_t*)x2, ld2, c2, lo2,
+                       rows_per_batch, scratch, nchunks, groups, eps, gamma, beta, act, (h16_t*)y, ldy, loy);
   AVSD_CHECK_LAUNCH("groupnorm_apply launch");
   return AVSD_OK;
 }
 
 extern "C" int avsd_layernorm(const void* x, int ldx, void* y, int ldy, int M, int C, const float* gamma,
                               const float* beta, float eps, const float* pos, int hw, int frames, void* stream) {
+  return avsd_layernorm_x2(x, ldx, 0, y, ldy, 0, M, C, gamma, beta, eps, pos, hw, frames, stream);
+}
+
+extern "C" int avsd_layernorm_x2(const void* x, int ldx, int64_t lox, void* y, int ldy, int64_t loy, int M, int C, const float* gamma,
+                                 const float* beta, float eps, const float* pos, int hw, int frames, void* stream) {
   AVSD_REQUIRE(x && y && gamma && beta, "layernorm: null pointer");
+  AVSD_REQUIRE(lox % 8 == 0 && loy % 8 == 0 && (lox != 0) == (loy != 0), "layernorm: plane offsets must be multiples of 8, input and output both split or neither");
   AVSD_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= 4096, "layernorm: C (%d) must be a multiple of 8, <= 4096", C);
   AVSD_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C, "layernorm: bad strides");
   if (pos) AVSD_REQUIRE(hw > 0 && frames > 0, "layernorm: pos needs hw and frames");
@@ -371,13 +424,13 @@ extern "C" int avsd_layernorm(const void* x, int ldx, void* y, int ldy, int M, i
   const int nvec = C / 8;
   const h16_t* xi = (const h16_t*)x;
   h16_t* yo = (h16_t*)y;
-  if (nvec <= 8) launch_layernorm<1>(xi, ldx, yo, ldy, M, C, gamma, beta, eps, pos, hw, frames, s);
-  else if (nvec <= 16) launch_layernorm<2>(xi, ldx, yo, ldy, M, C, gamma, beta, eps, pos, hw, frames, s);
-  else if (nvec <= 32) launch_layernorm<4>(xi, ldx, yo, ldy, M, C, gamma, beta, eps, pos, hw, frames, s);
-  else if (nvec <= 64) launch_layernorm<8>(xi, ldx, yo, ldy, M, C, gamma, beta, eps, pos, hw, frames, s);
-  else if (nvec <= 128) launch_layernorm<16>(xi, ldx, yo, ldy, M, C, gamma, beta, eps, pos, hw, frames, s);
-  else if (nvec <= 256) launch_layernorm<32>(xi, ldx, yo, ldy, M, C, gamma, beta, eps, pos, hw, frames, s);
-  else launch_layernorm<64>(xi, ldx, yo, ldy, M, C, gamma, beta, eps, pos, hw, frames, s);
+  if (nvec <= 8) launch_layernorm<1>(xi, ldx, lox, yo, ldy, loy, M, C, gamma, beta, eps, pos, hw, frames, s);
+  else if (nvec <= 16) launch_layernorm<2>(xi, ldx, lox, yo, ldy, loy, M, C, gamma, beta, eps, pos, hw, frames, s);
+  else if (nvec <= 32) launch_layernorm<4>(xi, ldx, lox, yo, ldy, loy, M, C, gamma, beta, eps, pos, hw, frames, s);
+  else if (nvec <= 64) launch_layernorm<8>(xi, ldx, lox, yo, ldy, loy, M, C, gamma, beta, eps, pos, hw, frames, s);
+  else if (nvec <= 128) launch_layernorm<16>(xi, ldx, lox, yo, ldy, loy, M, C, gamma, beta, eps, pos, hw, frames, s);
+  else if (nvec <= 256) launch_layernorm<32>(xi, ldx, lox, yo, ldy, loy, M, C, gamma, beta, eps, pos, hw, frames, s);
+  else launch_layernorm<64>(xi, ldx, lox, yo, ldy, loy, M, C, gamma, beta, eps, pos, hw, frames, s);
   AVSD_CHECK_LAUNCH("layernorm launch");
   return AVSD_OK;
 }

@@ -65,6 +65,11 @@ const Entry kEntries[] = {
     AVSD_PLAN_ENTRY(avsd_timestep_embedding), AVSD_PLAN_ENTRY(avsd_guided_step),         AVSD_PLAN_ENTRY(avsd_vae_postprocess),
     AVSD_PLAN_ENTRY(avsd_vae_postprocess_u8), AVSD_PLAN_ENTRY(avsd_kaldi_fbank),         AVSD_PLAN_ENTRY(avsd_patchify),
     AVSD_PLAN_ENTRY(avsd_vit_tokens),       AVSD_PLAN_ENTRY(avsd_copy),                  AVSD_PLAN_ENTRY(avsd_xattn_pack_kv),
+    // split-precision ("x2") entry points
+    AVSD_PLAN_ENTRY(avsd_linear_small_m_x2), AVSD_PLAN_ENTRY(avsd_groupnorm_stats_x2),   AVSD_PLAN_ENTRY(avsd_groupnorm_apply_x2),
+    AVSD_PLAN_ENTRY(avsd_layernorm_x2),     AVSD_PLAN_ENTRY(avsd_attention_x2),          AVSD_PLAN_ENTRY(avsd_temporal_attention_x2),
+    AVSD_PLAN_ENTRY(avsd_ncfhw_to_rows_x2), AVSD_PLAN_ENTRY(avsd_split_f32),             AVSD_PLAN_ENTRY(avsd_vae_postprocess_x2),
+    AVSD_PLAN_ENTRY(avsd_vae_postprocess_u8_x2),
 };
 
 struct Reloc {

@@ -17,7 +17,7 @@ from . import precision as P
 from ._lib import GemmDesc, XAttnDesc, check
 
 PLAIN, TMIX, CONV3 = 0, 1, 2
-GEGLU, OUT_F32, GELU, XCD_N, ROWSTATS, LNFUSE, RES1_F32, RES2_F32 = 1, 2, 4, 8, 16, 32, 64, 128
+GEGLU, OUT_F32, GELU, XCD_N, ROWSTATS, LNFUSE, RES1_F32, RES2_F32, X2 = 1, 2, 4, 8, 16, 32, 64, 128, 256
 _XCD_MODE = os.environ.get("AVSD_XCD_MODE", "auto")     # auto | m | n  (which operand each XCD's L2 fetches once)
 F32 = torch.float32      # (16-bit storage dtype: P.ACT, asva_amd/precision.py)
 
@@ -106,6 +106,9 @@ TILE_CANDIDATES = ((4, 1), (6, 1), (7, 1), (8, 1), (9, 1), (3, 1), (11, 1), (12,
 SPLITK_CANDIDATES = ((6, 2), (6, 4), (6, 8), (9, 2), (9, 4), (4, 2), (4, 4), (4, 8), (7, 2), (7, 4),
                      (20, 2), (20, 4), (24, 2), (24, 4), (24, 8), (25, 2), (25, 4), (26, 2), (26, 4), (26, 8),
                      (29, 2), (29, 4), (29, 8), (30, 2), (30, 4), (30, 8), (31, 2), (31, 4), (31, 8))
+# split precision (AVSD_GEMM_X2): the tiles whose doubled LDS stage fits (gemm.hip dispatch_tile_x2)
+X2_TILE_CANDIDATES = ((4, 1), (7, 1), (11, 1), (12, 1), (13, 1), (24, 1), (25, 1))
+X2_SPLITK_CANDIDATES = ((4, 2), (4, 4), (4, 8), (7, 2), (7, 4), (7, 8), (11, 2), (11, 4), (24, 2), (24, 4), (24, 8), (25, 2), (25, 4), (25, 8))
 _TILE_CACHE: dict = {}
 _AUTOTUNE = os.environ.get("AVSD_AUTOTUNE", "0") == "1"
 
@@ -161,6 +164,25 @@ def _heuristic_tile(M: int, N: int, K: int, geglu: bool, splitk_ok: bool):
         return (30 if nk >= 8 else 11), 1
     if N == 320 and M % 96 == 0 and M // 96 >= 224 and nk >= 30:
         return 32, 1
+    if tiles(128, 64) >= 224:
+        return (24 if nk >= 16 else 12), 1
+    t64 = tiles(64, 64)
+    if t64 >= 160 or not splitk_ok or geglu or nk < 8:
+        return (25 if nk >= 8 else 13), 1
+    sk = 1
+    while sk < 8 and t64 * sk < 224 and nk // (2 * sk) >= 4:
+        sk *= 2
+    return 25, sk
+
+
+def _heuristic_tile_x2(M: int, N: int, K: int, geglu: bool, splitk_ok: bool):
+    """the same rule over the split-precision tile set: 128x128 (2-stage), 128x64, 64x64, split-K for the small outputs"""
+    def tiles(bm, bn):
+        return ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
+
+    nk = (K + 63) // 64
+    if N >= 128 and tiles(128, 128) >= 224:
+        return 11, 1
     if tiles(128, 64) >= 224:
         return (24 if nk >= 16 else 12), 1
     t64 = tiles(64, 64)
@@ -267,6 +289,51 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+# ---- split-precision storage (asva_amd/precision.py): a 16-bit tensor is a view into the FIRST half of its storage, its rest
+# plane lies at the same offset in the second half ------------------------------------------------------------------------
+def alloc16(shape, device) -> torch.Tensor:
+    """uninitialised 16-bit activation tensor; in split mode the main plane of a twin allocation"""
+    if not P.SPLIT:
+        return torch.empty(shape, dtype=P.ACT, device=device)
+    n = 1
+    for d in shape:
+        n *= int(d)
+    npad = (n + 7) // 8 * 8
+    return torch.empty((2, npad), dtype=P.ACT, device=device)[0, :n].view(tuple(shape))
+
+
+def _lo(t: Optional[torch.Tensor]) -> int:
+    """element offset from `t` to its rest plane (0 outside split mode / for None)"""
+    if t is None or not P.SPLIT:
+        return 0
+    if t.dtype != P.ACT:
+        raise TypeError(f"split precision: expected a {P.ACT} tensor, got {t.dtype}")
+    nb = t.untyped_storage().nbytes()
+    last = sum((s - 1) * st for s, st in zip(t.shape, t.stride()))
+    if nb % 32 or (t.storage_offset() + last + 1) * 2 > nb // 2:
+        raise ValueError("split precision: tensor is not a view into the first half of a twin allocation "
+                         "(allocate with ops.alloc16 / ops.to_act / weights.to_act)")
+    return nb // 4
+
+
+def to_act(x: torch.Tensor) -> torch.Tensor:
+    """any float device tensor -> the 16-bit storage type (one launch in split mode: main and rest planes)"""
+    if not P.SPLIT:
+        return x.to(P.ACT).contiguous()
+    x = x.to(F32).contiguous()
+    out = alloc16(tuple(x.shape), x.device)
+    check(_lib.lib().avsd_split_f32(_p(x), _p(out), _lo(out), x.numel(), _stream()), "avsd_split_f32")
+    return out
+
+
+def from_act(t: torch.Tensor) -> torch.Tensor:
+    """f32 values of a 16-bit activation (main + rest in split mode); for tests and host-side checks"""
+    if not P.SPLIT:
+        return t.float()
+    half = _lo(t)
+    return t.float() + torch.as_strided(t, t.shape, t.stride(), t.storage_offset() + half).float()
+
+
 def _req(t: torch.Tensor, dtype, name: str):
     if t.dtype != dtype:
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
@@ -310,6 +377,16 @@ def gemm(
     """out = epilogue(alpha * A' . W^T); see avsd_gemm_bf16 in include/avsd.h."""
     _req(a, P.ACT, "a")
     _req(w, P.ACT, "w")
+    if P.SPLIT and mode == PLAIN and a2 is not None and a.shape[1] % 64 != 0:
+        # the LDS-direct loader switches source buffers per 64-wide K tile and the register-staged tiles have no split form:
+        # a concat split inside a K tile (tiny test networks: 160-channel skips) runs as two launches, the first leaving its
+        # un-rounded f32 partial for the second's epilogue — the same sum
+        if res1 is not None and res2 is not None:
+            raise ValueError("gemm: split precision with an unaligned two-source A supports one residual")
+        k1 = a.shape[1]
+        part = gemm(a, w[:, :k1], alpha=alpha, out_f32=True)
+        return gemm(a2, w[:, k1:], bias=bias, rowvec=rowvec, rows_per_vec=rows_per_vec, res1=part, res2=res1 if res1 is not None else res2,
+                    alpha=alpha, gelu=gelu, out_f32=out_f32, out=out)
     d = GemmDesc()
     N = w.shape[0] if n is None else n
     lda = _ld(a)
@@ -343,7 +420,7 @@ def gemm(
         raise ValueError(f"unknown gemm mode {mode}")
     n_out = N // 2 if geglu else N
     if out is None:
-        out = torch.empty((M, n_out), dtype=F32 if out_f32 else P.ACT, device=a.device)
+        out = torch.empty((M, n_out), dtype=F32, device=a.device) if out_f32 else alloc16((M, n_out), a.device)
     else:
         _req(out, F32 if out_f32 else P.ACT, "out")
     d.A, d.W, d.out = _p(a), _p(w), _p(out)
@@ -391,6 +468,14 @@ def gemm(
         d.flags |= XCD_N
     d.batch = 1
     ws = None
+    if P.SPLIT:
+        if master is not None:
+            raise ValueError("gemm: split precision has no f32 master (the planes carry 16 bits)")
+        d.flags |= X2
+        d.a_lo, d.a2_lo, d.w_lo = _lo(a), _lo(a2), _lo(w)
+        d.out_lo = 0 if out_f32 else _lo(out)
+        d.res1_lo = _lo(res1) if (res1 is not None and res1.dtype != F32) else 0
+        d.res2_lo = _lo(res2) if (res2 is not None and res2.dtype != F32) else 0
 
     def _set(t, sk):
         nonlocal ws
@@ -400,7 +485,7 @@ def gemm(
                 ws = torch.empty((sk * M * N,), dtype=F32, device=a.device)
             d.splitk_ws = _p(ws)
             tiles = ((M + 63) // 64) * ((N + 63) // 64)
-            d.splitk_cnt = _p(_splitk_tickets(a.device)) if (_SPLITK_INLAUNCH and N % 32 == 0 and tiles <= _SPLITK_MAX_TILES) else None
+            d.splitk_cnt = _p(_splitk_tickets(a.device)) if (_SPLITK_INLAUNCH and not P.SPLIT and N % 32 == 0 and tiles <= _SPLITK_MAX_TILES) else None
         else:
             d.splitk_cnt = None
 
@@ -409,15 +494,16 @@ def gemm(
             _set(t, sk)
             check(_lib.lib().avsd_gemm_bf16(C.byref(d), _stream()), "avsd_gemm_bf16")
 
-        cands = TILE_CANDIDATES
+        cands = X2_TILE_CANDIDATES if P.SPLIT else TILE_CANDIDATES
         nk = (K + 63) // 64
         two_src_unaligned = a2 is not None and (a.shape[1] % 64 != 0)     # C falls back to register-staged tiles
         if not geglu and not two_src_unaligned and ((M + 127) // 128) * ((N + 127) // 128) < 256 and nk >= 16:
-            cands = cands + tuple(c for c in SPLITK_CANDIDATES if nk // c[1] >= 4)
+            cands = cands + tuple(c for c in (X2_SPLITK_CANDIDATES if P.SPLIT else SPLITK_CANDIDATES) if nk // c[1] >= 4)
         splitk_ok = not geglu and not two_src_unaligned
         picked = _pick_tile((mode, M, N, K, d.flags, d.stride, d.ups, d.pad, int(master is not None)), _launch, cands,
                             warm=(a, a2, res1, res2))
-        tile, split_k = picked if picked is not None else _heuristic_tile(M, N, K, geglu, splitk_ok)
+        heur = _heuristic_tile_x2 if P.SPLIT else _heuristic_tile
+        tile, split_k = picked if picked is not None else heur(M, N, K, geglu, splitk_ok)
     _set(tile, split_k)
     ev = _TIMER.start() if _TIMER is not None else None
     check(_lib.lib().avsd_gemm_bf16(C.byref(d), _stream()), "avsd_gemm_bf16")
@@ -426,7 +512,7 @@ def gemm(
         dc = GemmDesc.from_buffer_copy(d)
         _TIMER.add_replay(fam, lambda dc=dc: check(_lib.lib().avsd_gemm_bf16(C.byref(dc), _stream()), "avsd_gemm_bf16"),
                           (a, a2, w, out, bias, rowvec, res1, res2, ws, rowstats, ln, master))
-        _TIMER.stop(ev, fam, 2.0 * M * N * K, 2.0 * M * K * (1.0 / 9 if mode == CONV3 else 1.0 / 3 if mode == TMIX else 1.0)
+        _TIMER.stop(ev, fam, 2.0 * M * N * K * (3 if P.SPLIT else 1), 2.0 * M * K * (1.0 / 9 if mode == CONV3 else 1.0 / 3 if mode == TMIX else 1.0)
                     + 2.0 * N * K + _nbytes(out, res1, res2))
     return out
 
@@ -438,7 +524,7 @@ def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, alpha: float = 1.0, out_f3
     _req(w, P.ACT, "w")
     B, M, K = a.shape
     N = w.shape[1]
-    out = torch.empty((B, M, N), dtype=F32 if out_f32 else P.ACT, device=a.device)
+    out = torch.empty((B, M, N), dtype=F32, device=a.device) if out_f32 else alloc16((B, M, N), a.device)
     d = GemmDesc()
     d.A, d.W, d.out = _p(a), _p(w), _p(out)
     d.M, d.N, d.K, d.k_split = M, N, K, K
@@ -454,13 +540,19 @@ def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, alpha: float = 1.0, out_f3
         _req(colsum, F32, "ln colsum")
         d.ln_stats, d.ln_colsum, d.ln_nblk, d.ln_eps = _p(st), _p(colsum), K // 32, float(eps)
         d.flags |= LNFUSE
+    if P.SPLIT:
+        if B > 1 and w.stride(0) != 0:
+            raise ValueError("gemm_batched: split precision needs one weight shared by the batches (w.stride(0) == 0)")
+        d.flags |= X2
+        d.batch_stride_w = 0
+        d.a_lo, d.w_lo, d.out_lo = _lo(a), _lo(w), (0 if out_f32 else _lo(out))
     if tile == 0:
         def _launch(t):
             d.tile = t
             check(_lib.lib().avsd_gemm_bf16(C.byref(d), _stream()), "avsd_gemm_bf16(batched)")
 
-        picked = _pick_tile(("batched", B, M, N, K, d.flags), lambda t, sk: _launch(t))
-        d.tile = picked[0] if picked is not None else _heuristic_tile(B * M, N, K, False, False)[0]
+        picked = _pick_tile(("batched", B, M, N, K, d.flags), lambda t, sk: _launch(t), X2_TILE_CANDIDATES if P.SPLIT else TILE_CANDIDATES)
+        d.tile = picked[0] if picked is not None else (_heuristic_tile_x2 if P.SPLIT else _heuristic_tile)(B * M, N, K, False, False)[0]
     ev = _TIMER.start() if _TIMER is not None else None
     check(_lib.lib().avsd_gemm_bf16(C.byref(d), _stream()), "avsd_gemm_bf16(batched)")
     if ev is not None:
@@ -478,6 +570,10 @@ def linear_small_m(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
         raise ValueError("linear_small_m: x must be contiguous")
     if out is None:
         out = torch.empty((M, N), dtype=F32, device=x.device)
+    if P.SPLIT:
+        check(_lib.lib().avsd_linear_small_m_x2(_p(x), _p(w), _lo(w), _p(bias), _p(out), M, N, K, _ld(w), int(act_in), int(act_out),
+                                                _stream()), "avsd_linear_small_m_x2")
+        return out
     check(_lib.lib().avsd_linear_small_m(_p(x), _p(w), _p(bias), _p(out), M, N, K, _ld(w), int(act_in), int(act_out),
                                          _stream()), "avsd_linear_small_m")
     return out
@@ -501,14 +597,21 @@ def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], nb: int, rows_per_ba
     nchunks = L.avsd_groupnorm_nchunks(nb, rows_per_batch, c1 + c2)
     partial = torch.empty((L.avsd_groupnorm_scratch_floats(nb, nchunks, groups, c1 + c2),), dtype=F32, device=x1.device)
     if out is None:
-        out = torch.empty((rows, c1 + c2), dtype=P.ACT, device=x1.device)
+        out = alloc16((rows, c1 + c2), x1.device)
     s = _stream()
     ev = _TIMER.start() if _TIMER is not None else None
-    check(L.avsd_groupnorm_stats(_p(x1), _ld(x1), c1, _p(x2), _ld(x2) if x2 is not None else 0, c2, nb, rows_per_batch,
-                                 groups, _p(partial), nchunks, s), "avsd_groupnorm_stats")
-    check(L.avsd_groupnorm_apply(_p(x1), _ld(x1), c1, _p(x2), _ld(x2) if x2 is not None else 0, c2, nb, rows_per_batch,
-                                 groups, _p(gamma), _p(beta), float(eps), _p(partial), nchunks, int(act), _p(out), _ld(out), s),
-          "avsd_groupnorm_apply")
+    if P.SPLIT:
+        check(L.avsd_groupnorm_stats_x2(_p(x1), _ld(x1), c1, _lo(x1), _p(x2), _ld(x2) if x2 is not None else 0, c2, _lo(x2), nb,
+                                        rows_per_batch, groups, _p(partial), nchunks, s), "avsd_groupnorm_stats_x2")
+        check(L.avsd_groupnorm_apply_x2(_p(x1), _ld(x1), c1, _lo(x1), _p(x2), _ld(x2) if x2 is not None else 0, c2, _lo(x2), nb,
+                                        rows_per_batch, groups, _p(gamma), _p(beta), float(eps), _p(partial), nchunks, int(act),
+                                        _p(out), _ld(out), _lo(out), s), "avsd_groupnorm_apply_x2")
+    else:
+        check(L.avsd_groupnorm_stats(_p(x1), _ld(x1), c1, _p(x2), _ld(x2) if x2 is not None else 0, c2, nb, rows_per_batch,
+                                     groups, _p(partial), nchunks, s), "avsd_groupnorm_stats")
+        check(L.avsd_groupnorm_apply(_p(x1), _ld(x1), c1, _p(x2), _ld(x2) if x2 is not None else 0, c2, nb, rows_per_batch,
+                                     groups, _p(gamma), _p(beta), float(eps), _p(partial), nchunks, int(act), _p(out), _ld(out), s),
+              "avsd_groupnorm_apply")
     if ev is not None:
         _TIMER.stop(ev, "groupnorm", 0.0, 2.0 * _nbytes(x1, x2) + _nbytes(out))
     return out
@@ -526,10 +629,14 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
         if not pos.is_contiguous() or pos.shape != (frames, Cc):
             raise ValueError("layernorm: pos must be contiguous [frames, C]")
     if out is None:
-        out = torch.empty((M, Cc), dtype=P.ACT, device=x.device)
+        out = alloc16((M, Cc), x.device)
     ev = _TIMER.start() if _TIMER is not None else None
-    check(_lib.lib().avsd_layernorm(_p(x), _ld(x), _p(out), _ld(out), M, Cc, _p(gamma), _p(beta), float(eps), _p(pos),
-                                    hw, frames, _stream()), "avsd_layernorm")
+    if P.SPLIT:
+        check(_lib.lib().avsd_layernorm_x2(_p(x), _ld(x), _lo(x), _p(out), _ld(out), _lo(out), M, Cc, _p(gamma), _p(beta), float(eps),
+                                           _p(pos), hw, frames, _stream()), "avsd_layernorm_x2")
+    else:
+        check(_lib.lib().avsd_layernorm(_p(x), _ld(x), _p(out), _ld(out), M, Cc, _p(gamma), _p(beta), float(eps), _p(pos),
+                                        hw, frames, _stream()), "avsd_layernorm")
     if ev is not None:
         _TIMER.stop(ev, "layernorm", 0.0, _nbytes(x, out))
     return out
@@ -557,11 +664,17 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, bq: int, lq:
         if key_index.dtype != torch.int32 or not key_index.is_contiguous() or key_index.shape != (frames, lk):
             raise ValueError("attention: key_index must be contiguous int32 [frames, lk]")
     if out is None:
-        out = torch.empty((bq * lq, Cc), dtype=P.ACT, device=q.device)
+        out = alloc16((bq * lq, Cc), q.device)
     if scale is None:
         scale = float(d) ** -0.5
     ev = _TIMER.start() if _TIMER is not None else None
-    if fp8 is not None:
+    if P.SPLIT:
+        if fp8 is not None:
+            raise ValueError("attention: fp8 Q/K/V and split precision are exclusive")
+        check(_lib.lib().avsd_attention_x2(_p(q), _ld(q), _lo(q), _p(k), _ld(k), _lo(k), _p(v), _ld(v), _lo(v), _p(out), _ld(out),
+                                           _lo(out), bq, lq, lk, kv_rows, heads, d, q_per_kv, _p(key_index), frames, float(scale),
+                                           _stream()), "avsd_attention_x2")
+    elif fp8 is not None:
         qs, ks, vs = (float(x) for x in fp8)
         check(_lib.lib().avsd_attention_fp8(_p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(out), _ld(out), bq, lq, lk, kv_rows,
                                             heads, d, q_per_kv, _p(key_index), frames, float(scale), qs, ks, vs, _stream()),
@@ -576,7 +689,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, bq: int, lq:
 
 
 def cross_attention_block_supported(C: int, heads: int, lk_pad: int, M: int, L: int) -> bool:
-    return bool(_lib.lib().avsd_cross_attention_block_supported(C, heads, lk_pad)) and M % 128 == 0 and L % 128 == 0
+    return not P.SPLIT and bool(_lib.lib().avsd_cross_attention_block_supported(C, heads, lk_pad)) and M % 128 == 0 and L % 128 == 0
 
 
 def cross_attention_block(h: torch.Tensor, stats: torch.Tensor, wq: torch.Tensor, q_colsum: torch.Tensor, q_bias: torch.Tensor,
@@ -586,6 +699,8 @@ def cross_attention_block(h: torch.Tensor, stats: torch.Tensor, wq: torch.Tensor
                           out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = res + to_out(softmax((LN(h) Wq^T) K^T scale) V) in one launch; see avsd_cross_attention_block (include/avsd.h).
     k [nkv, lk_pad, C], vt [nkv, C, lk_pad] are the cached, padded (and for audio mask-gathered) K / V^T."""
+    if P.SPLIT:
+        raise ValueError("cross_attention_block: not built for split precision (use the separate kernels)")
     _req(h, P.ACT, "h")
     _req(wq, P.ACT, "wq")
     _req(wo, P.ACT, "wo")
@@ -636,12 +751,16 @@ def temporal_attention(qkv: torch.Tensor, *, b: int, frames: int, hw: int, heads
     Cc = qkv.shape[1] // 3
     d = Cc // heads
     if out is None:
-        out = torch.empty((qkv.shape[0], Cc), dtype=P.ACT, device=qkv.device)
+        out = alloc16((qkv.shape[0], Cc), qkv.device)
     if scale is None:
         scale = float(d) ** -0.5
     ev = _TIMER.start() if _TIMER is not None else None
-    check(_lib.lib().avsd_temporal_attention(_p(qkv), _ld(qkv), _p(out), _ld(out), b, frames, hw, heads, d, float(scale),
-                                             _stream()), "avsd_temporal_attention")
+    if P.SPLIT:
+        check(_lib.lib().avsd_temporal_attention_x2(_p(qkv), _ld(qkv), _lo(qkv), _p(out), _ld(out), _lo(out), b, frames, hw, heads, d,
+                                                    float(scale), _stream()), "avsd_temporal_attention_x2")
+    else:
+        check(_lib.lib().avsd_temporal_attention(_p(qkv), _ld(qkv), _p(out), _ld(out), b, frames, hw, heads, d, float(scale),
+                                                 _stream()), "avsd_temporal_attention")
     if ev is not None:
         _TIMER.stop(ev, "temporal_attention", 4.0 * b * hw * heads * frames * frames * d, _nbytes(qkv, out))
     return out
@@ -652,7 +771,11 @@ def ncfhw_to_rows(x: torch.Tensor, cpad: int, rep: int = 1, scale: float = 1.0) 
     if not x.is_contiguous():
         raise ValueError("ncfhw_to_rows: x must be contiguous")
     B, Cc, Fr, H, W = x.shape
-    out = torch.empty((rep * B * Fr * H * W, cpad), dtype=P.ACT, device=x.device)
+    out = alloc16((rep * B * Fr * H * W, cpad), x.device)
+    if P.SPLIT:
+        check(_lib.lib().avsd_ncfhw_to_rows_x2(_p(x), _p(out), _lo(out), B, Cc, Fr, H * W, cpad, rep, float(scale), _stream()),
+              "avsd_ncfhw_to_rows_x2")
+        return out
     check(_lib.lib().avsd_ncfhw_to_rows(_p(x), _p(out), B, Cc, Fr, H * W, cpad, rep, float(scale), _stream()),
           "avsd_ncfhw_to_rows")
     return out
@@ -663,12 +786,16 @@ def copy(src: torch.Tensor, dst: Optional[torch.Tensor] = None, rep: int = 1) ->
     it.  A library launch instead of a torch op, so that it is part of a recorded launch plan (asva_amd/plan.py)."""
     if not (src.is_cuda and src.is_contiguous()):
         raise ValueError("copy: src must be a contiguous device tensor")
+    split = P.SPLIT and src.dtype == P.ACT          # a split tensor: both planes move
     if dst is None:
-        dst = torch.empty((rep * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        shape = (rep * src.shape[0],) + tuple(src.shape[1:])
+        dst = alloc16(shape, src.device) if split else torch.empty(shape, dtype=src.dtype, device=src.device)
     nbytes = src.numel() * src.element_size()
     if not dst.is_contiguous() or dst.numel() * dst.element_size() != rep * nbytes or nbytes % 16:
         raise ValueError("copy: dst must be contiguous and hold rep x src (a multiple of 16 bytes)")
     check(_lib.lib().avsd_copy(_p(src), _p(dst), nbytes, rep, _stream()), "avsd_copy")
+    if split:
+        check(_lib.lib().avsd_copy(_p(src) + 2 * _lo(src), _p(dst) + 2 * _lo(dst), nbytes, rep, _stream()), "avsd_copy")
     return dst
 
 
@@ -723,6 +850,9 @@ def guided_step(noise_pred: torch.Tensor, n_branch: int, g: float, x_in: torch.T
 def vae_postprocess(rows: torch.Tensor, n_img: int, H: int, W: int) -> torch.Tensor:
     _req(rows, P.ACT, "rows")
     out = torch.empty((n_img, 3, H, W), dtype=F32, device=rows.device)
+    if P.SPLIT:
+        check(_lib.lib().avsd_vae_postprocess_x2(_p(rows), _ld(rows), _lo(rows), _p(out), n_img, H * W, _stream()), "avsd_vae_postprocess_x2")
+        return out
     check(_lib.lib().avsd_vae_postprocess(_p(rows), _ld(rows), _p(out), n_img, H * W, _stream()), "avsd_vae_postprocess")
     return out
 
@@ -730,6 +860,10 @@ def vae_postprocess(rows: torch.Tensor, n_img: int, H: int, W: int) -> torch.Ten
 def vae_postprocess_u8(rows: torch.Tensor, n_img: int, H: int, W: int) -> torch.Tensor:
     _req(rows, P.ACT, "rows")
     out = torch.empty((n_img, H, W, 3), dtype=torch.uint8, device=rows.device)
+    if P.SPLIT:
+        check(_lib.lib().avsd_vae_postprocess_u8_x2(_p(rows), _ld(rows), _lo(rows), _p(out), n_img, H * W, _stream()),
+              "avsd_vae_postprocess_u8_x2")
+        return out
     check(_lib.lib().avsd_vae_postprocess_u8(_p(rows), _ld(rows), _p(out), n_img, H * W, _stream()), "avsd_vae_postprocess_u8")
     return out
 

@@ -7,6 +7,14 @@
                     sources compiled with -DAVSD_F16=1 (asva_amd/build.py).
 
 `set_precision` switches the whole process: models must be (re)packed after a switch (pack() keys its cache on it).
+
+Split precision ("x2", `set_split(True)`; the mode that meets BASELINE.json's 1e-3 against the reference's fp32 pipeline,
+scripts/animation_gen.py:43-44): every 16-bit tensor — activations and matrix weights alike — becomes a PAIR of planes,
+main = round16(v) and rest = round16(v - main), i.e. 16 significant bits in bf16 with f32's range.  Matrix products run as
+three MFMA passes (main.main + rest.main + main.rest) into the same f32 accumulator, everything else reconstructs main + rest
+in f32.  Storage convention on the host: a split tensor is a view into the FIRST half of its storage and its rest plane sits
+at the same offset in the second half (ops.alloc16 / weights.to_act / the packed blob are laid out that way), so views and
+slices carry their rest plane along and the kernels get it as one element offset.
 """
 from __future__ import annotations
 
@@ -19,6 +27,15 @@ NAME = "bf16"
 ACT = torch.bfloat16
 
 
+SPLIT = False
+
+
+def set_split(on: bool) -> None:
+    """switches split-precision storage on / off for the whole process (models are repacked on next use)"""
+    global SPLIT
+    SPLIT = bool(on)
+
+
 def set_precision(name: str) -> None:
     global NAME, ACT
     if name not in _NAMES:
@@ -28,3 +45,5 @@ def set_precision(name: str) -> None:
 
 if os.environ.get("AVSD_PRECISION"):
     set_precision(os.environ["AVSD_PRECISION"])
+if os.environ.get("AVSD_SPLIT", "0") != "0":
+    set_split(True)

@@ -24,7 +24,7 @@ from . import precision as P
 
 from . import ops
 from .conditioning import mask_to_key_index
-from .weights import pack_conv1x1, pack_conv3x3, pack_geglu, pack_linear
+from .weights import from_act, is_twin, pack_conv1x1, pack_conv3x3, pack_geglu, pack_linear, rest_of, to_act
 
 CONFIG_NAME = "config.json"
 SAFETENSORS_NAME = "diffusion_pytorch_model.safetensors"
@@ -61,7 +61,7 @@ _F32_CONV_Y = os.environ.get("AVSD_F32_CONV_Y", "1") != "0"      # with the f32 
 
 def _replicate(a: "_Act", r: int) -> "_Act":
     """rows of all branches = r copies of the shared rows, branch-major like torch.cat([latents] * r) (pure data movement)"""
-    return _Act(ops.copy(a.lo, rep=r), None if a.hi is None else ops.copy(a.hi, rep=r))
+    return _Act(ops.copy(a.lo, rep=r), None if a.hi is None else ops.copy(a.hi, rep=r))     # (ops.copy moves both planes of a split tensor)
 
 
 class _Side:
@@ -103,7 +103,7 @@ def _xa_fill(kv: torch.Tensor, n_kv: int, rows: int, C: int, idx: Optional[torch
     hipGraph holds its addresses).  None when more than 96 keys remain (the separate kernels handle that)."""
     nb, lk = (n_kv, rows) if idx is None else (n_kv * idx.shape[0], idx.shape[1])
     lkp = (lk + 31) // 32 * 32
-    if lkp > 96:
+    if lkp > 96 or P.SPLIT:        # (split precision runs the three separate kernels)
         return None
     if old is None:
         old = _Pk(k=torch.empty((nb, lkp, C), dtype=kv.dtype, device=kv.device),         # avsd_xattn_pack_kv writes the padding too
@@ -355,15 +355,16 @@ class Packer:
         if m.kernel == 3:
             wp = pack_conv3x3(w, cip, cop)
         else:
-            wp = torch.zeros(cop, cip, dtype=P.ACT, device=w.device)
-            wp[:cout, :cin] = pack_conv1x1(w)
+            wp = torch.zeros(cop, cip, device=w.device)
+            wp[:cout, :cin] = w.reshape(cout, cin)
+            wp = to_act(wp)
         b = torch.zeros(cop, device=w.device)
         b[:cout] = m.bias.detach().float()
         wt = torch.zeros(cop, 3, cop, device=w.device)
         wt[:cout, :, :cout] = m.conv_temp.weight.detach().float().reshape(cout, 3, cout)
         bt = torch.zeros(cop, device=w.device)
         bt[:cout] = m.conv_temp.bias.detach().float()
-        return _Pk(w=reg(wp), b=reg(b), wt=reg(wt.reshape(cop, 3 * cop).to(P.ACT)), bt=reg(bt),
+        return _Pk(w=reg(wp), b=reg(b), wt=reg(to_act(wt.reshape(cop, 3 * cop))), bt=reg(bt),
                    cout=cop, cin=cip, k=m.kernel)
 
     def conv1(self, m: _Conv):
@@ -378,7 +379,7 @@ class Packer:
         cb = w @ be
         if bias is not None:
             cb = cb + bias
-        return wf, wf.float().sum(1), cb
+        return wf, from_act(wf).sum(1), cb
 
     def attn(self, m: _Attention, fuse_qkv: bool, norm: Optional[_Affine] = None, fold_kv: bool = False):
         """norm: the LayerNorm in front of this attention; when given, its affine is folded into to_q (and, for the
@@ -419,7 +420,7 @@ class Packer:
         p = _Pk(norm=self.aff(m.norm), proj_in=self.conv1(m.proj_in), proj_out=self.conv1(m.proj_out),
                 norm1=self.aff(b.norm1), attn1=self.attn(b.attn1, False, b.norm1, fold_kv=True),
                 norm2=self.aff(b.norm2), attn2=self.attn(b.attn2, False, b.norm2),
-                w1_ln=reg(w1_ln), b1_ln=reg(b1_ln), s1_ln=reg(w1_ln.float().sum(1)),
+                w1_ln=reg(w1_ln), b1_ln=reg(b1_ln), s1_ln=reg(from_act(w1_ln).sum(1)),
                 norm_temp=self.aff(b.norm_temp), attn_temp=self.attn(b.attn_temp, True),
                 pos1=self.lin(b.pos_embedding_temp.linear_1), pos2=self.lin(b.pos_embedding_temp.linear_2),
                 norm3=self.aff(b.norm3), w1=reg(w1), b1=reg(b1), ff2=self.lin(b.ff.net[2]),
@@ -446,11 +447,17 @@ class Packer:
         for t in self.items:
             offs.append(total)
             total += (t.numel() * t.element_size() + 255) // 256 * 256
-        blob = torch.zeros(total, dtype=torch.uint8, device=device)
+        # split precision: the blob is a twin allocation like every split tensor — the rest plane of item i sits at the
+        # same offset in the second half, so every view below carries it along (precision.py)
+        blob = torch.zeros(total * (2 if P.SPLIT else 1), dtype=torch.uint8, device=device)
         if not meta:   # meta parameters: layout only — the bytes arrive by broadcast (asva_amd.dist)
             for t, o in zip(self.items, offs):
                 nb = t.numel() * t.element_size()
                 blob[o:o + nb].copy_(t.reshape(-1).view(torch.uint8))
+                if P.SPLIT and t.dtype == P.ACT:
+                    if not is_twin(t):
+                        raise RuntimeError("split-precision packing: a 16-bit item was not produced by weights.to_act")
+                    blob[total + o:total + o + nb].copy_(rest_of(t).reshape(-1).view(torch.uint8))
         views = []
         for t, o in zip(self.items, offs):
             nb = t.numel() * t.element_size()
@@ -470,6 +477,7 @@ class Packer:
         resolve(pk)
         pk.blob = blob
         pk.act_dtype = P.ACT
+        pk.split = P.SPLIT
         return pk
 
 
@@ -742,7 +750,8 @@ class AudioUNet3DConditionModel(nn.Module):
             device = torch.device(device)
             if device.type == "cuda" and device.index is None:
                 device = torch.device("cuda", torch.cuda.current_device())
-        if self._packed is not None and self._packed.act_dtype == P.ACT and (device is None or self._packed.blob.device == device):
+        if (self._packed is not None and self._packed.act_dtype == P.ACT and getattr(self._packed, "split", False) == P.SPLIT
+                and (device is None or self._packed.blob.device == device)):
             return self._packed
         device = device if device is not None else self.device
         if device.type == "meta":
@@ -786,7 +795,7 @@ class AudioUNet3DConditionModel(nn.Module):
                 else:
                     per_frame = x.shape[1]
                     x = x.reshape(x.shape[0] * x.shape[1], *x.shape[2:])
-            return x.to(device=dev, dtype=P.ACT).contiguous(), per_frame
+            return ops.to_act(x.to(device=dev)), per_frame
 
         text, text_pf = rows(encoder_hidden_states)
         audio, audio_pf = rows(audio_encoder_hidden_states)
@@ -961,7 +970,7 @@ class AudioUNet3DConditionModel(nn.Module):
         st = _Pk(B=B, F=Fr, side=side, temb=temb, temb_rows=(Fr if (t.numel() == B and B > 1) else B * Fr), cond=cond, tr_i=0,
                  groups=self.config.norm_num_groups, eps=float(self.config.norm_eps),
                  heads=_per_block(self.config.attention_head_dim, nblk), fuse_ln=getattr(self, "fuse_layernorm", _FUSE_LN),
-                 f32_stream=getattr(self, "f32_residual", _F32_RES),
+                 f32_stream=getattr(self, "f32_residual", _F32_RES) and not P.SPLIT,     # split planes already carry 16 bits
                  fp8=(tuple(getattr(self, "fp8_scales", (1.0, 1.0, 1.0))) if getattr(self, "fp8_attention", _ATTN_FP8) else None))
 
         # branches that are still identical (see _SHARE_PREFIX): run them once until the first audio cross-attention

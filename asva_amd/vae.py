@@ -25,7 +25,7 @@ from torch import nn
 
 from . import ops
 from .unet import FrozenConfig, _Affine, _Conv, _Linear, _Pk, _Ref
-from .weights import pack_conv1x1, pack_conv3x3, pack_linear
+from .weights import is_twin, pack_conv1x1, pack_conv3x3, pack_linear, rest_of, to_act
 
 
 class DecoderOutput:
@@ -275,7 +275,8 @@ class AutoencoderKL(nn.Module):
             device = torch.device(device)
             if device.type == "cuda" and device.index is None:
                 device = torch.device("cuda", torch.cuda.current_device())
-        if self._packed is not None and (device is None or self._packed.blob.device == device):
+        if (self._packed is not None and (device is None or self._packed.blob.device == device)
+                and getattr(self._packed, "split", False) == P.SPLIT and getattr(self._packed, "act_dtype", P.ACT) == P.ACT):
             return self._packed
         device = device if device is not None else self.device
         if device.type != "cuda" and not getattr(ops, "EMULATED", False):
@@ -299,11 +300,11 @@ class AutoencoderKL(nn.Module):
         def conv1(m):
             cout, cin = m.weight.shape[:2]
             cop, cip = (cout + 7) // 8 * 8, (cin + 7) // 8 * 8
-            w = torch.zeros(cop, cip, dtype=P.ACT, device=m.weight.device)
-            w[:cout, :cin] = pack_conv1x1(m.weight.detach().float())
+            w = torch.zeros(cop, cip, device=m.weight.device)
+            w[:cout, :cin] = m.weight.detach().float().reshape(cout, cin)
             b = torch.zeros(cop, device=m.weight.device)
             b[:cout] = m.bias.detach().float()
-            return _Pk(w=reg(w), b=reg(b))
+            return _Pk(w=reg(to_act(w)), b=reg(b))
 
         def res(m):
             return _Pk(norm1=aff(m.norm1), conv1=conv3(m.conv1), norm2=aff(m.norm2), conv2=conv3(m.conv2),
@@ -336,12 +337,17 @@ class AutoencoderKL(nn.Module):
         for t in items:
             offs.append(total)
             total += (t.numel() * t.element_size() + 255) // 256 * 256
-        blob = torch.zeros(total, dtype=torch.uint8, device=device)
+        # split precision: a twin blob, the rest plane of every 16-bit item at the same offset in the second half (precision.py)
+        blob = torch.zeros(total * (2 if P.SPLIT else 1), dtype=torch.uint8, device=device)
         views = []
         for t, o in zip(items, offs):
             nb = t.numel() * t.element_size()
             if not t.is_meta:
                 blob[o:o + nb].copy_(t.reshape(-1).view(torch.uint8))
+                if P.SPLIT and t.dtype == P.ACT:
+                    if not is_twin(t):
+                        raise RuntimeError("split-precision packing: a 16-bit item was not produced by weights.to_act")
+                    blob[total + o:total + o + nb].copy_(rest_of(t).reshape(-1).view(torch.uint8))
             views.append(blob[o:o + nb].view(t.dtype).view(t.shape))
 
         def resolve(obj):
@@ -357,6 +363,8 @@ class AutoencoderKL(nn.Module):
 
         resolve(pk)
         pk.blob = blob
+        pk.split = P.SPLIT
+        pk.act_dtype = P.ACT
         self._packed = pk
         return pk
 

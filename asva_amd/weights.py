@@ -18,12 +18,50 @@ import torch
 from . import precision as P
 
 
+def to_act(w: torch.Tensor) -> torch.Tensor:
+    """f32 values -> the 16-bit storage type.  In split-precision mode (precision.SPLIT) the result is the main plane of a
+    twin allocation [2, ...]: plane 0 = round16(w), plane 1 = round16(w - plane 0); the rest plane travels with every view
+    of the result (same offset in the second half of the storage)."""
+    w = w.detach().float().contiguous()
+    if not P.SPLIT or w.device.type == "meta":
+        return w.to(P.ACT)
+    n = w.numel()
+    npad = (n + 7) // 8 * 8
+    base = torch.zeros((2, npad), dtype=P.ACT, device=w.device)
+    main = w.reshape(-1).to(P.ACT)
+    base[0, :n] = main
+    base[1, :n] = (w.reshape(-1) - main.float()).to(P.ACT)
+    return base[0, :n].view(w.shape)
+
+
+def is_twin(t: torch.Tensor) -> bool:
+    """True for a view into the first half of a twin allocation (see to_act)"""
+    nb = t.untyped_storage().nbytes()
+    if t.numel() == 0 or nb % 32:
+        return False
+    last = sum((s - 1) * st for s, st in zip(t.shape, t.stride()))
+    return (t.storage_offset() + last + 1) * t.element_size() <= nb // 2
+
+
+def rest_of(t: torch.Tensor) -> torch.Tensor:
+    """the rest plane of a twin tensor, as a view with the same shape and strides"""
+    half = t.untyped_storage().nbytes() // 2 // t.element_size()
+    return torch.as_strided(t, t.shape, t.stride(), t.storage_offset() + half)
+
+
+def from_act(t: torch.Tensor) -> torch.Tensor:
+    """the f32 values a kernel reconstructs from a packed 16-bit tensor (main + rest in split mode)"""
+    if P.SPLIT and is_twin(t):
+        return t.float() + rest_of(t).float()
+    return t.float()
+
+
 def pack_linear(w: torch.Tensor) -> torch.Tensor:
-    return w.detach().to(P.ACT).contiguous()
+    return to_act(w)
 
 
 def pack_conv1x1(w: torch.Tensor) -> torch.Tensor:
-    return w.detach().reshape(w.shape[0], w.shape[1]).to(P.ACT).contiguous()
+    return to_act(w.detach().reshape(w.shape[0], w.shape[1]))
 
 
 def pack_conv3x3(w: torch.Tensor, cin_pad: int | None = None, cout_pad: int | None = None) -> torch.Tensor:
@@ -33,7 +71,7 @@ def pack_conv3x3(w: torch.Tensor, cin_pad: int | None = None, cout_pad: int | No
     cout_pad = cout_pad or (cout + 3) // 4 * 4
     p = torch.zeros((cout_pad, 3, 3, cin_pad), dtype=torch.float32, device=w.device)
     p[:cout, :, :, :cin] = w.detach().float().permute(0, 2, 3, 1)
-    return p.reshape(cout_pad, 9 * cin_pad).to(P.ACT).contiguous()
+    return to_act(p.reshape(cout_pad, 9 * cin_pad))
 
 
 def geglu_row_order(nh: int) -> torch.Tensor:
@@ -47,7 +85,7 @@ def geglu_row_order(nh: int) -> torch.Tensor:
 def pack_geglu(w: torch.Tensor, b: torch.Tensor | None):
     nh = w.shape[0] // 2
     order = geglu_row_order(nh).to(w.device)
-    wp = w.detach()[order].to(P.ACT).contiguous()
+    wp = to_act(w.detach()[order])
     bp = None if b is None else b.detach()[order].float().contiguous()
     return wp, bp
 

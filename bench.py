@@ -185,6 +185,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE-decode leg")
+    ap.add_argument("--no-precise", action="store_true", help="skip the split-precision leg")
     ap.add_argument("--also-clips", type=int, default=4,
                     help="after the headline measurement, also time this many clips batched into one forward per GPU "
                          "(BASELINE cfg 3 runs 4 per GPU); 0 = skip")
@@ -343,6 +344,38 @@ def main():
                           "ms_per_forward": round(tb / ks * 1e3, 4), "steps": ks,
                           "step_mfma_frac": round(ALGORITHMIC_TFLOP_PER_STEP * n / (tb / ks) / PEAK_BF16_TFLOPS, 4),
                           "workload": f"BASELINE configs[2] per-GPU shape: {n} clips per forward"}
+    if world == 1 and not a.no_precise:
+        # the mode that meets BASELINE.json's stated tolerance (<= 1e-3 rel-L2 vs the reference's fp32 pipeline; measured
+        # 3e-5 on this forward, tests/test_precise_gpu.py): split-precision storage (bf16 main + rest planes), every matrix
+        # product three MFMA passes.  Same clip, same step definition; reported beside the bf16 headline, never instead of it.
+        from asva_amd import precision as P
+
+        P.set_split(True)
+        try:
+            unet._invalidate()
+            eng_p = DenoiseEngine(unet, DDIMScheduler(), audio_guidance_scale=4.0, use_graph=not a.no_graph)
+            eng_p.set_conditioning(text[:1], audio[:1], null_audio, audio_segment_mask(12), 12)
+            lp = lat[:1].clone()
+            eng_p.prepare(lp, n_sched)
+            kp = max(10, a.steps // 4)
+            for i in range(3):
+                eng_p.step(lp, i)
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            for i in range(kp):
+                eng_p.step(lp, (3 + i) % n_sched)
+            torch.cuda.synchronize()
+            tp = time.perf_counter() - tp
+            out["precise"] = {"mode": "bf16x2 split precision (main + rest planes, 3-pass MFMA)", "value": round(kp / tp, 3),
+                              "unit": "steps/s", "ms_per_step": round(tp / kp * 1e3, 4), "steps": kp,
+                              "all_finite": bool(torch.isfinite(lp).all()),
+                              "rel_l2_vs_reference_fp32": "asserted < 1e-3 by tests/test_precise_gpu.py (measured: profiles/r3_error_budget.json)",
+                              "mfma_frac_of_3x_work": round(3 * ALGORITHMIC_TFLOP_PER_STEP / (tp / kp) / PEAK_BF16_TFLOPS, 4)}
+            del eng_p
+        finally:
+            P.set_split(False)
+            unet._invalidate()
+            torch.cuda.empty_cache()
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(unet, clip)
         out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)

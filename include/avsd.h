@@ -33,7 +33,7 @@ extern "C" {
 #define AVSD_ELAUNCH (-2)  /* hipLaunch / runtime error                          */
 #define AVSD_ENODEV (-3)   /* no gfx950 device / wrong architecture              */
 
-#define AVSD_ABI_VERSION 4
+#define AVSD_ABI_VERSION 5
 
 /* ---- library ------------------------------------------------------------------------ */
 int avsd_abi_version(void);
@@ -81,7 +81,7 @@ int avsd_device_info(char* name_host, int len, int* num_cu_host);
  */
 enum { AVSD_GEMM_PLAIN = 0, AVSD_GEMM_TMIX = 1, AVSD_GEMM_CONV3 = 2 };
 enum { AVSD_GEMM_GEGLU = 1, AVSD_GEMM_OUT_F32 = 2, AVSD_GEMM_GELU = 4, AVSD_GEMM_XCD_N = 8, AVSD_GEMM_ROWSTATS = 16,
-       AVSD_GEMM_LNFUSE = 32, AVSD_GEMM_RES1_F32 = 64, AVSD_GEMM_RES2_F32 = 128 };
+       AVSD_GEMM_LNFUSE = 32, AVSD_GEMM_RES1_F32 = 64, AVSD_GEMM_RES2_F32 = 128, AVSD_GEMM_X2 = 256 };
 #define AVSD_GEMM_MAX_TILE 33
 
 typedef struct avsd_gemm_desc {
@@ -134,6 +134,11 @@ typedef struct avsd_gemm_desc {
   float* out_master;                    /* f32 [M][ldm] or NULL: un-rounded copy of the result (not with GEGLU) */
   int32_t ldm;
   int32_t reserved0;
+  /* AVSD_GEMM_X2 (split precision, see "split-precision storage" below): every 16-bit operand is a pair of planes; these are
+   * the ELEMENT offsets from each main plane to its rest plane (same strides).  The product is accumulated as
+   * W.A + Wr.A + W.Ar (three MFMA passes into one f32 accumulator); 16-bit residuals are read as main + rest and the output
+   * is written as main = round16(v), rest = round16(v - main).  LDS-direct tiles 4, 7, 11, 12, 13, 24, 25 only. */
+  int64_t a_lo, a2_lo, w_lo, out_lo, res1_lo, res2_lo;
 } avsd_gemm_desc;
 
 int avsd_gemm_bf16(const avsd_gemm_desc* desc_host, void* stream);
@@ -312,6 +317,34 @@ int avsd_copy(const void* src, void* dst, int64_t bytes, int rep, void* stream);
  * clip n.  The padding slots lk..lk_pad-1 (lk = nk or rows) are written as zeros by the same launch.  Once per clip. */
 int avsd_xattn_pack_kv(const void* kv, int n_kv, int rows, int C, const int32_t* idx, int n_frames, int nk,
                        void* k_out, void* vt_out, int lk_pad, void* stream);
+
+/* ---- split-precision ("x2") storage: the mode that meets north_star's 1e-3 against the reference's fp32 pipeline ----------
+ * (scripts/animation_gen.py:43-44 runs fp32).  A 16-bit tensor becomes a PAIR of planes with identical strides:
+ *     main = round16(v),  rest = round16(v - main)          (16 significant bits in bf16, no range loss)
+ * `*_lo` arguments are the ELEMENT offsets from a main plane to its rest plane.  Matrix products run as three MFMA passes
+ * (main.main + rest.main + main.rest; the rest.rest term is 2^-18 of the product) into the same f32 accumulator — the
+ * GEMM family through AVSD_GEMM_X2, the attentions below — and every other kernel reconstructs v = main + rest (exact in
+ * f32), computes in f32 as before and writes both planes.  Same arithmetic otherwise as the entry points they mirror. */
+int avsd_linear_small_m_x2(const float* x, const void* W, int64_t w_lo, const float* bias, float* out,
+                           int M, int N, int K, int ldw, int act_in, int act_out, void* stream);
+int avsd_groupnorm_stats_x2(const void* x1, int ld1, int c1, int64_t x1_lo, const void* x2, int ld2, int c2, int64_t x2_lo,
+                            int nb, int rows_per_batch, int groups, float* scratch, int nchunks, void* stream);
+int avsd_groupnorm_apply_x2(const void* x1, int ld1, int c1, int64_t x1_lo, const void* x2, int ld2, int c2, int64_t x2_lo,
+                            int nb, int rows_per_batch, int groups, const float* gamma, const float* beta, float eps,
+                            const float* scratch, int nchunks, int act, void* y, int ldy, int64_t y_lo, void* stream);
+int avsd_layernorm_x2(const void* x, int ldx, int64_t x_lo, void* y, int ldy, int64_t y_lo, int M, int C,
+                      const float* gamma, const float* beta, float eps, const float* pos, int hw, int frames, void* stream);
+int avsd_attention_x2(const void* Q, int ldq, int64_t q_lo, const void* K, int ldk, int64_t k_lo, const void* V, int ldv,
+                      int64_t v_lo, void* O, int ldo, int64_t o_lo, int Bq, int Lq, int Lk, int kv_rows, int heads, int d,
+                      int q_per_kv, const int32_t* key_index, int frames, float scale, void* stream);
+int avsd_temporal_attention_x2(const void* QKV, int ldqkv, int64_t qkv_lo, void* O, int ldo, int64_t o_lo, int B, int frames,
+                               int hw, int heads, int d, float scale, void* stream);
+int avsd_ncfhw_to_rows_x2(const float* src, void* dst, int64_t dst_lo, int B, int C, int F, int HW, int cpad, int rep,
+                          float scale, void* stream);
+/* f32 [n] -> planes (conditioning inputs: text / audio encodings handed over in f32). */
+int avsd_split_f32(const float* src, void* dst, int64_t dst_lo, int64_t n, void* stream);
+int avsd_vae_postprocess_x2(const void* src, int ld, int64_t src_lo, float* dst, int N, int HW, void* stream);
+int avsd_vae_postprocess_u8_x2(const void* src, int ld, int64_t src_lo, void* dst_u8, int N, int HW, void* stream);
 
 /* ---- launch plans (a host without Python runs the path) ----------------------------------------------------
  * A plan is the sequence of calls to the entry points above that one operation of the reference issues — the UNet forward

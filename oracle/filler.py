@@ -29,17 +29,34 @@ def fill_tensor(name: str, shape, dtype=torch.float32) -> torch.Tensor:
     return t.to(dtype)
 
 
+def heavy_tail_scale(name: str, n_out: int) -> torch.Tensor:
+    """per-output-channel gains (deterministic in the parameter name): most channels 10^u with u uniform in [-1, 0.3], and
+    one channel in 16 an outlier with a gain of 10..100 — the outlier-channel regime of trained diffusion UNets, which
+    closed-form N(0, 1/fan_in) weights never visit.  Gains span three decades across the channels of a layer and
+    are normalised to unit RMS per matrix (un-normalised gains of 1e-2 .. 1e2 on every layer make the reference's own fp32
+    forward overflow: 1.5e25 inside the tiny network)."""
+    g = torch.Generator(device="cpu").manual_seed((zlib.crc32(name.encode()) ^ 0x5A5A5A5A) & 0x7FFFFFFF)
+    u = 1.3 * torch.rand(n_out, generator=g) - 1.0
+    out = torch.rand(n_out, generator=g) < 1.0 / 16
+    u = torch.where(out, 1.0 + torch.rand(n_out, generator=g), u)
+    gain = 10.0 ** u
+    return gain / gain.pow(2).mean().sqrt()          # unit RMS: the spread stays, the residual stream does not explode
+
+
 def fill_state_dict(shapes: dict, dtype=torch.float32) -> dict:
     """shapes: name -> shape (e.g. tests/golden/unet_sd15_state_dict_shapes.json)."""
     return {k: fill_tensor(k, v, dtype) for k, v in shapes.items()}
 
 
-def fill_module_(module: torch.nn.Module, prefix: str = "", round_bf16: bool = False) -> None:
+def fill_module_(module: torch.nn.Module, prefix: str = "", round_bf16: bool = False, heavy_tail: bool = False) -> None:
     """round_bf16: matrices (dim >= 2) are rounded to bf16-representable values, so a bf16-weight implementation holds
-    exactly the parameters the fp32 reference ran with (block-level goldens)."""
+    exactly the parameters the fp32 reference ran with (block-level goldens).  heavy_tail: every matrix gets per-output-channel
+    gains spanning 1e-2 .. 1e2 (heavy_tail_scale)."""
     with torch.no_grad():
         for k, p in module.state_dict().items():
             t = fill_tensor(prefix + k, p.shape, p.dtype)
+            if heavy_tail and t.dim() >= 2:
+                t = t * heavy_tail_scale(prefix + k, t.shape[0]).reshape(-1, *([1] * (t.dim() - 1))).to(t.dtype)
             if round_bf16 and t.dim() >= 2:
                 t = t.to(torch.bfloat16).to(p.dtype)
             p.copy_(t)

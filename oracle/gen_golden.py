@@ -230,15 +230,77 @@ def full_shape():
     idx = torch.arange(0, flat.numel(), flat.numel() // 4096)[:4096]
     torch.save({"timestep": 981, "idx": idx, "sample": flat[idx].clone(), "mean": flat.mean().item(),
                 "std": flat.std().item(), "absmax": flat.abs().max().item(), "norm": flat.norm().item(),
-                "shape": list(y.shape), "full": y.to(torch.float16)},
+                "shape": list(y.shape), "full": y.to(torch.float16), "full32": y.clone()},      # full32: for the modes below 1e-3
                os.path.join(OUT, "unet_sd15_forward.pt"))
     print("full-shape forward: std", flat.std().item(), "params", sum(p.numel() for p in m.parameters()), len(shapes))
+
+
+@torch.no_grad()
+def cfg1_ddim25(m=None, steps=25):
+    """BASELINE configs[0] / [1]: a whole 25-step DDIM clip at full shape — the REFERENCE's UNet inside the loop of
+    pipeline_audio_cond_animation.py:330-365 (latents duplicated for audio-only guidance 4.0, scheduler on frames 1.., frame 0
+    pinned).  The scheduler arithmetic is diffusers' (absent here): oracle/sched_ref.RefDDIM restates it.  Stores the latents
+    after steps 1, 5, 10, 25 in f32 (tests/test_denoise_gpu.py)."""
+    from oracle.sched_ref import RefDDIM
+
+    torch.set_num_threads(os.cpu_count())
+    m = m or _full_model()
+    Fr = 12
+    lat = seeded_randn(61, 1, 4, Fr, 32, 32)
+    lat[:, :, 0] *= 0.18215
+    text, audio, null_audio = seeded_randn(62, 1, 77, 768), seeded_randn(63, 1, 229, 768), seeded_randn(64, 1, 229, 768)
+    txt = torch.cat([text, text])[:, None].expand(2, Fr, 77, 768)
+    aud = torch.cat([null_audio, audio])[:, None].expand(2, Fr, 229, 768)
+    mask = audio_segment_mask(Fr)[None].expand(2, -1, -1).contiguous()
+    sch = RefDDIM()
+    sch.set_timesteps(steps)
+    x = lat.clone()
+    keep = {}
+    for i, t in enumerate(sch.timesteps):
+        n = m(torch.cat([x, x]), torch.tensor(int(t)), txt, aud, audio_attention_mask=mask).sample
+        n0, n1 = n.chunk(2)
+        eps = n0 + 4.0 * (n1 - n0)
+        x[:, :, 1:] = sch.step(eps[:, :, 1:], t, x[:, :, 1:])
+        if i + 1 in (1, 5, 10, steps):
+            keep[i + 1] = x.clone()
+        print(f"ddim step {i + 1}/{steps}: t {int(t)} |x| {x.norm().item():.4f}", flush=True)
+    torch.save({"steps": steps, "guidance": 4.0, "seeds": {"lat": 61, "text": 62, "audio": 63, "null_audio": 64},
+                "timesteps": [int(t) for t in sch.timesteps], "latents_after": keep},
+               os.path.join(OUT, "cfg1_ddim25_latents.pt"))
+
+
+@torch.no_grad()
+def tiny_heavy_tail():
+    """the tiny end-to-end network with outlier-channel weights (oracle/filler.heavy_tail_scale): per-channel gains over four
+    decades, activations in the hundreds to thousands — the regime where IEEE-half storage can overflow"""
+    m = AudioUNet3DConditionModel(**TINY_CFG).eval()
+    fill_module_(m, heavy_tail=True)
+    B, Fr, H, W = 2, 4, 8, 8
+    x = seeded_randn(71, B, 4, Fr, H, W)
+    text = seeded_randn(72, B, 1, 7, 64).expand(B, Fr, 7, 64).contiguous()
+    audio = seeded_randn(73, B, 1, 229, 64).expand(B, Fr, 229, 64).contiguous()
+    mask = audio_segment_mask(Fr)[None].expand(B, -1, -1).contiguous()
+    amax = {}
+    def note(name):
+        def hook(_m, _i, o):
+            o = o[0] if isinstance(o, tuple) else getattr(o, "sample", o)
+            if torch.is_tensor(o):
+                amax[name] = float(o.abs().max())
+        return hook
+
+    hooks = [mod.register_forward_hook(note(name)) for name, mod in m.named_modules() if name]
+    y = m(x, torch.tensor(501), text, audio, audio_attention_mask=mask).sample
+    for h in hooks:
+        h.remove()
+    print("heavy-tail tiny forward: out std", y.std().item(), "largest activation", max(amax.values()))
+    torch.save({"config": jsonable(m.config), "seeds": {"x": 71, "text": 72, "audio": 73}, "timestep": 501, "out": y,
+                "max_activation": max(amax.values())}, os.path.join(OUT, "unet_tiny_heavy_tail.pt"))
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
-    ap.add_argument("--only", default="", help="comma list of: tiny, ops, blocks, full, cfg3, cfg4")
+    ap.add_argument("--only", default="", help="comma list of: tiny, ops, blocks, heavy, full, ddim25, cfg3, cfg4")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     only = set(a.only.split(",")) if a.only else None
@@ -251,6 +313,10 @@ if __name__ == "__main__":
         blocks_hip_legal()
     if want("full", a.full):
         full_shape()
+    if want("heavy", True):
+        tiny_heavy_tail()
+    if want("ddim25", a.full):
+        cfg1_ddim25()
     if want("cfg3", a.full) or want("cfg4", a.full):
         mm = _full_model()
         if want("cfg3", a.full):

@@ -22,14 +22,14 @@ def load_shapes(name):
         return json.load(f)
 
 
-def filled_unet(cfg, dtype=torch.float32):
+def filled_unet(cfg, dtype=torch.float32, heavy_tail=False):
     """Product model with the closed-form filler weights (oracle/filler.py) — the same weights the
     reference model had when the golden vectors were generated."""
     from asva_amd.unet import AudioUNet3DConditionModel
     from oracle.filler import fill_module_
 
     m = AudioUNet3DConditionModel.from_config(cfg).eval()
-    fill_module_(m)
+    fill_module_(m, heavy_tail=heavy_tail)
     return m.to(dtype)
 
 

@@ -113,10 +113,12 @@ SIGNATURES = {
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float, c_void_p]),
     "avsd_temporal_attention_x2": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_float,
                                            c_void_p]),
+    "avsd_softmax_rows_x2": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
     "avsd_ncfhw_to_rows_x2": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "avsd_split_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "avsd_vae_postprocess_x2": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_void_p]),
     "avsd_vae_postprocess_u8_x2": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_void_p]),
+    "avsd_gemm_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     # launch plans (asva_amd/plan.py records them; any host replays them)
     "avsd_plan_bundle_load": (c_int, [C.c_char_p, C.POINTER(c_void_p)]),
     "avsd_plan_bundle_free": (None, [c_void_p]),

@@ -964,7 +964,7 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
     AVSD_REQUIRE(!d.res1 || (d.flags & AVSD_GEMM_RES1_F32) || d.res1_lo != 0, "gemm/x2: a 16-bit res1 needs res1_lo");
     AVSD_REQUIRE(!d.res2 || (d.flags & AVSD_GEMM_RES2_F32) || d.res2_lo != 0, "gemm/x2: a 16-bit res2 needs res2_lo");
     AVSD_REQUIRE(((d.a_lo | d.a2_lo | d.w_lo | d.out_lo | d.res1_lo | d.res2_lo) & 7) == 0, "gemm/x2: plane offsets must be multiples of 8 elements");
-    AVSD_REQUIRE(!d.out_master && !d.splitk_cnt && d.batch_stride_w == 0, "gemm/x2: no f32 master, in-launch split-K reduction or batched weights");
+    AVSD_REQUIRE(!d.out_master && !d.splitk_cnt, "gemm/x2: no f32 master, no in-launch split-K reduction");
     AVSD_REQUIRE(d.mode != AVSD_GEMM_PLAIN || !d.A2 || d.k_split % 64 == 0, "gemm/x2: a two-source A needs k_split %% 64 == 0 (got %d)", d.k_split);
     const double a_rows = d.mode == AVSD_GEMM_CONV3 ? (double)(d.M / (d.ho * d.wo)) * d.hs * d.ws : (double)d.M;
     AVSD_REQUIRE(a_rows * d.lda * 2.0 < 2147483648.0 && (double)d.N * d.ldw * 2.0 < 2147483648.0, "gemm/x2: operands must be < 2 GiB per plane");

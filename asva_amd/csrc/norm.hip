@@ -276,7 +276,7 @@ void launch_layernorm(const h16_t* x, int ldx, int64_t lox, h16_t* y, int ldy, i
 }
 
 // ---- row softmax: S f32 -> P bf16, one wave per row ---------------------------------------------
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* S, int lds, h16_t* P, int ldp, int rows,
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* S, int lds, h16_t* P, int ldp, int64_t p_lo, int rows,
                                                            int L) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -297,10 +297,11 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* S, int l
   h16_t* o = P + (int64_t)row * ldp;
   for (int j = lane * 4; j < L; j += 256) {
     const float4 v = *reinterpret_cast<const float4*>(s + j);
-    uint2 st;
-    st.x = pack2h(__expf(v.x - mx) * inv, __expf(v.y - mx) * inv);
-    st.y = pack2h(__expf(v.z - mx) * inv, __expf(v.w - mx) * inv);
+    uint2 st, sr;
+    split2(__expf(v.x - mx) * inv, __expf(v.y - mx) * inv, st.x, sr.x);
+    split2(__expf(v.z - mx) * inv, __expf(v.w - mx) * inv, st.y, sr.y);
     *reinterpret_cast<uint2*>(o + j) = st;
+    if (p_lo) *reinterpret_cast<uint2*>(o + p_lo + j) = sr;      // split-precision planes
   }
 }
 
@@ -436,10 +437,14 @@ extern "C" int avsd_layernorm_x2(const void* x, int ldx, int64_t lox, void* y, i
 }
 
 extern "C" int avsd_softmax_rows(const float* S, int lds, void* P, int ldp, int rows, int L, void* stream) {
+  return avsd_softmax_rows_x2(S, lds, P, ldp, 0, rows, L, stream);
+}
+
+extern "C" int avsd_softmax_rows_x2(const float* S, int lds, void* P, int ldp, int64_t p_lo, int rows, int L, void* stream) {
   AVSD_REQUIRE(S && P && rows > 0 && L > 0, "softmax_rows: bad arguments");
-  AVSD_REQUIRE(L % 4 == 0 && lds % 4 == 0 && ldp % 4 == 0, "softmax_rows: L, lds, ldp must be multiples of 4");
+  AVSD_REQUIRE(L % 4 == 0 && lds % 4 == 0 && ldp % 4 == 0 && p_lo % 4 == 0, "softmax_rows: L, lds, ldp must be multiples of 4");
   hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), S, lds, (h16_t*)P, ldp, rows, L);
+                     reinterpret_cast<hipStream_t>(stream), S, lds, (h16_t*)P, ldp, p_lo, rows, L);
   AVSD_CHECK_LAUNCH("softmax_rows launch");
   return AVSD_OK;
 }

@@ -517,6 +517,17 @@ def gemm(
     return out
 
 
+def gemm_f32(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """exact-f32 yardstick: out = a . w^T + bias on v_mfma_f32_32x32x2_f32 (avsd_gemm_f32); a [M, K], w [N, K] f32"""
+    _req(a, F32, "a")
+    _req(w, F32, "w")
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty((M, N), dtype=F32, device=a.device)
+    check(_lib.lib().avsd_gemm_f32(_p(a), _ld(a), _p(w), _ld(w), _p(bias), _p(out), _ld(out), M, N, K, _stream()), "avsd_gemm_f32")
+    return out
+
+
 def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, alpha: float = 1.0, out_f32: bool = False,
                  bias: Optional[torch.Tensor] = None, tile: int = 0, ln: Optional[tuple] = None) -> torch.Tensor:
     """out[b] = alpha * a[b] . w[b]^T for 3-D a [B, M, K], w [B, N, K] (VAE mid-block attention)."""
@@ -541,10 +552,7 @@ def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, alpha: float = 1.0, out_f3
         d.ln_stats, d.ln_colsum, d.ln_nblk, d.ln_eps = _p(st), _p(colsum), K // 32, float(eps)
         d.flags |= LNFUSE
     if P.SPLIT:
-        if B > 1 and w.stride(0) != 0:
-            raise ValueError("gemm_batched: split precision needs one weight shared by the batches (w.stride(0) == 0)")
         d.flags |= X2
-        d.batch_stride_w = 0
         d.a_lo, d.w_lo, d.out_lo = _lo(a), _lo(w), (0 if out_f32 else _lo(out))
     if tile == 0:
         def _launch(t):
@@ -645,8 +653,8 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
 def softmax_rows(s: torch.Tensor) -> torch.Tensor:
     _req(s, F32, "s")
     rows, L = s.shape
-    out = torch.empty((rows, L), dtype=P.ACT, device=s.device)
-    check(_lib.lib().avsd_softmax_rows(_p(s), _ld(s), _p(out), _ld(out), rows, L, _stream()), "avsd_softmax_rows")
+    out = alloc16((rows, L), s.device)
+    check(_lib.lib().avsd_softmax_rows_x2(_p(s), _ld(s), _p(out), _ld(out), _lo(out), rows, L, _stream()), "avsd_softmax_rows_x2")
     return out
 
 

@@ -339,12 +339,22 @@ int avsd_attention_x2(const void* Q, int ldq, int64_t q_lo, const void* K, int l
                       int q_per_kv, const int32_t* key_index, int frames, float scale, void* stream);
 int avsd_temporal_attention_x2(const void* QKV, int ldqkv, int64_t qkv_lo, void* O, int ldo, int64_t o_lo, int B, int frames,
                                int hw, int heads, int d, float scale, void* stream);
+int avsd_softmax_rows_x2(const float* S, int lds, void* P, int ldp, int64_t p_lo, int rows, int L, void* stream);
 int avsd_ncfhw_to_rows_x2(const float* src, void* dst, int64_t dst_lo, int B, int C, int F, int HW, int cpad, int rep,
                           float scale, void* stream);
 /* f32 [n] -> planes (conditioning inputs: text / audio encodings handed over in f32). */
 int avsd_split_f32(const float* src, void* dst, int64_t dst_lo, int64_t n, void* stream);
 int avsd_vae_postprocess_x2(const void* src, int ld, int64_t src_lo, float* dst, int N, int HW, void* stream);
 int avsd_vae_postprocess_u8_x2(const void* src, int ld, int64_t src_lo, void* dst_u8, int N, int HW, void* stream);
+
+/* ---- exact-f32 yardstick ---------------------------------------------------------------------------------------------------
+ * out[M, N] = A[M, K] . W[N, K]^T + bias[n], all f32, on the f32-input matrix cores (v_mfma_f32_32x32x2_f32: bitwise a
+ * k-ordered fmaf chain, 157 TFLOP/s peak = 1/16 of the bf16 rate).  Not on the product path: it is the on-box reference that
+ * separates kernel arithmetic from storage rounding when the 16-bit and split-precision GEMMs are validated, and the rate
+ * bench.py quotes next to theirs.  The reference computes the same products with fp32 torch.nn.Linear / nn.Conv2d
+ * (scripts/animation_gen.py:43-44).  K, lda, ldw multiples of 4; A, W 16-byte aligned. */
+int avsd_gemm_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N, int K,
+                  void* stream);
 
 /* ---- launch plans (a host without Python runs the path) ----------------------------------------------------
  * A plan is the sequence of calls to the entry points above that one operation of the reference issues — the UNet forward

@@ -87,6 +87,10 @@ def _ln_fold(acc, ln, rows):
     return rstd[:, None] * (acc - mean[:, None] * colsum[None, :])
 
 
+def to_act(x):
+    return x.to(P.ACT).contiguous()
+
+
 def gemm_batched(a, w, *, alpha=1.0, out_f32=False, bias=None, tile=0, ln=None):
     v = alpha * torch.einsum("bmk,bnk->bmn", a.float(), w.float())
     if ln is not None:

@@ -21,10 +21,10 @@ def test_sd15_vae_decoder_matches_oracle():
     assert out.shape == (3, 3, 128, 128) and out.dtype == torch.float32
     err = rel_l2(out, ref)
     print(f"SD1.5 VAE decode (3 x 16x16 latents): rel-L2 vs oracle {err:.3e}")
-    assert err < 3e-2
+    assert err < 2e-2          # 1.5 x the measured 1.3e-2; the fp16 and split-precision decoders: tests/test_precise_gpu.py
     lat = (z * 0.18215).reshape(1, 3, 4, 16, 16).permute(0, 2, 1, 3, 4).contiguous().cuda()
     vid = vae.decode_to_video(lat)
-    assert rel_l2(vid[0], (ref / 2 + 0.5).clamp(0, 1)) < 3e-2 and float(vid.min()) >= 0 and float(vid.max()) <= 1
+    assert rel_l2(vid[0], (ref / 2 + 0.5).clamp(0, 1)) < 2e-2 and float(vid.min()) >= 0 and float(vid.max()) <= 1
 
 
 def test_sd15_vae_encoder_matches_oracle():
@@ -61,8 +61,20 @@ def test_vae_decode_full_clip_shape_is_finite_and_chunking_is_consistent():
     print(f"VAE decode 12x256x256: {(time.time() - t0) * 1e3:.1f} ms")
 
 
-@pytest.mark.parametrize("kind", ["pndm", "ddim"])
-def test_pipeline_matches_oracle_pipeline(kind):
+@pytest.mark.parametrize("kind,split", [("pndm", False), ("ddim", False), ("pndm", True), ("ddim", True)])
+def test_pipeline_matches_oracle_pipeline(kind, split):
+    """split = True: the same generation in split precision, held to 1e-3 — a defect of that size in the scheduler glue, the
+    guidance mix, the latent preparation or the decoder cannot hide behind 16-bit rounding there."""
+    from asva_amd import precision as P
+
+    P.set_split(split)
+    try:
+        _pipeline_vs_oracle(kind, 1e-3 if split else 5e-2, 1e-4 if split else 2e-2)
+    finally:
+        P.set_split(False)
+
+
+def _pipeline_vs_oracle(kind, tol, tol_eager):
     from asva_amd.pipeline import AudioCondAnimationPipeline
     from asva_amd.schedulers import DDIMScheduler, PNDMScheduler
     from oracle import pipeline_ref
@@ -90,7 +102,7 @@ def test_pipeline_matches_oracle_pipeline(kind):
     vid = pipe(**kw)["videos"]
     e2 = rel_l2(vid, ref_vid)
     print(f"{kind}: latents after {steps} steps rel-L2 {e1:.3e}; decoded video rel-L2 {e2:.3e}")
-    assert e1 < 5e-2 and e2 < 5e-2
+    assert e1 < tol and e2 < tol
     assert vid.device.type == "cpu" and vid.shape == (1, f, 3, h * 8, w * 8)
     # tile selection is deterministic (committed table / static rule): the same call again is bit-identical
     assert torch.equal(pipe(**kw, output_latents=True), lat)
@@ -98,14 +110,14 @@ def test_pipeline_matches_oracle_pipeline(kind):
     # (one fused f32 kernel vs torch ops), the 1e-7 differences are amplified by the 16-bit roundings of the following steps
     pipe.use_engine = False
     lat2 = pipe(**kw, output_latents=True)
-    assert rel_l2(lat2, lat) < 2e-2
+    assert rel_l2(lat2, lat) < tol_eager
     # a second clip of the same geometry reuses the captured graph (conditioning refreshed in place)
     pipe.use_engine = True
     kw2 = dict(kw, audio_encodings=g["audio"][:1], null_audio_encodings=g["audio"][1:2])
     lat3 = pipe(**kw2, output_latents=True)
     ref3 = pipeline_ref.denoise(unet_sd, dict(unet.config), x0, g["text"][:1], g["audio"][:1], g["audio"][1:2], g["mask"],
                                 steps, 4.0, kind)
-    assert rel_l2(lat3, ref3) < 5e-2
+    assert rel_l2(lat3, ref3) < tol
 
 
 def test_generate_videos_batches_the_clips_of_a_video():

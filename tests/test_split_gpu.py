@@ -323,3 +323,31 @@ def test_small_kernels(ops):
     assert rel_l2(out, ref) < 1e-6
     u8 = ops.vae_postprocess_u8(img, 2, 4, 4)
     assert (u8.float() - (ref.permute(0, 2, 3, 1) * 255).floor().float()).abs().max() <= 1
+
+
+# ---- the exact-f32 yardstick (avsd_gemm_f32, v_mfma_f32_32x32x2_f32) and what it says about the other two GEMMs ------------
+@pytest.mark.parametrize("M,N,K", [(384, 320, 320), (1000, 644, 1284), (2048, 1280, 768), (130, 36, 40)])
+def test_f32_yardstick_gemm_is_exact_f32(ops, M, N, K):
+    a, w, b = rndf(M, K, seed=1), rndf(N, K, seed=2, scale=K ** -0.5), rndf(N, seed=3)
+    out = ops.gemm_f32(a, w, b)
+    ref = a.double() @ w.double().T + b.double()
+    assert rel_l2(out, ref) < 1e-6          # f32 round-off of a K-long fmaf chain (measured 1-5e-7 for K = 40 .. 1284)
+
+
+def test_three_gemms_on_the_same_f32_operands(ops):
+    """storage rounding vs kernel arithmetic, separated: f32 operands through (1) the exact-f32 MFMA GEMM, (2) the split-precision
+    GEMM (operands rounded to 16 bits, three passes), (3) the plain bf16 GEMM (operands rounded to 8 bits)"""
+    from asva_amd import precision as P
+
+    M, N, K = 1536, 1280, 1280
+    a, w = rndf(M, K, seed=1), rndf(N, K, seed=2, scale=K ** -0.5)
+    ref = a.double() @ w.double().T
+    e_f32 = rel_l2(ops.gemm_f32(a, w), ref)
+    e_x2 = rel_l2(ops.gemm(ops.to_act(a), ops.to_act(w), out_f32=True), ref)
+    P.set_split(False)
+    try:
+        e_bf16 = rel_l2(ops.gemm(a.bfloat16(), w.bfloat16(), out_f32=True), ref)
+    finally:
+        P.set_split(True)
+    print(f"GEMM {M}x{N}x{K} on f32 operands vs fp64: exact-f32 MFMA {e_f32:.2e}, split precision {e_x2:.2e}, bf16 {e_bf16:.2e}")
+    assert e_f32 < 1e-6 and e_x2 < 1.5e-5 and 1e-3 < e_bf16 < 5e-3

@@ -29,4 +29,17 @@ for M, N, K in [(24576, 320, 320), (24576, 320, 1280), (24576, 2560, 320), (6144
     ops.gemm(a, w, out=out)                 # tunes this shape
     t_own = gtime(lambda: ops.gemm(a, w, out=out))
     fl = 2.0 * M * N * K
-    print(f"{M:6d} {N:6d} {K:6d}: torch.matmul {t_lib:7.1f} us ({fl / t_lib / 1e6:6.0f} TF)   avsd_gemm rule {t_rule:7.1f} us ({fl / t_rule / 1e6:6.0f} TF)  tuned {t_own:7.1f} us ({fl / t_own / 1e6:6.0f} TF)")
+    extra = ""
+    if os.environ.get("YARDSTICK_PRECISE", "1") != "0" and M * N <= 8192 * 8192:
+        # the exact-f32 MFMA yardstick and the split-precision (3-pass) GEMM on the same shape
+        af, wf = a.float(), w.float()
+        t_f32 = gtime(lambda: ops.gemm_f32(af, wf), reps=5)
+        from asva_amd import precision as P
+        P.set_split(True)
+        ops.set_autotune(False)
+        a2, w2 = ops.to_act(af), ops.to_act(wf)
+        o2 = ops.alloc16((M, N), a2.device)
+        t_x2 = gtime(lambda: ops.gemm(a2, w2, out=o2), reps=5)
+        P.set_split(False)
+        extra = f"  | exact-f32 MFMA {t_f32:8.1f} us ({fl / t_f32 / 1e6:5.0f} TF)  split x2 {t_x2:7.1f} us ({3 * fl / t_x2 / 1e6:5.0f} TF of 3-pass work)"
+    print(f"{M:6d} {N:6d} {K:6d}: torch.matmul {t_lib:7.1f} us ({fl / t_lib / 1e6:6.0f} TF)   avsd_gemm rule {t_rule:7.1f} us ({fl / t_rule / 1e6:6.0f} TF)  tuned {t_own:7.1f} us ({fl / t_own / 1e6:6.0f} TF){extra}")

@@ -29,9 +29,15 @@ def main():
     ap.add_argument("--out", default="gpurun_out/tiles_gfx950.json")
     ap.add_argument("--skip-cfg4", action="store_true")
     ap.add_argument("--extend", action="store_true", help="keep the shipped table's entries; tune only the shapes it lacks")
+    ap.add_argument("--split", action="store_true", help="tune the split-precision (AVSD_GEMM_X2) shapes of cfg 2 and the VAE "
+                                                        "(their table keys carry the X2 flag, so they live beside the 16-bit ones)")
     a = ap.parse_args()
     ops.set_autotune(True)
     dev = torch.device("cuda", 0)
+    if a.split:
+        from asva_amd import precision as P
+
+        P.set_split(True)
     unet = bench.build_unet(dev, 0, 1)
     t0 = time.time()
 
@@ -44,7 +50,7 @@ def main():
         # per-branch text (dual guidance) and shared text (audio-only guidance: the prefix runs once, asva_amd/unet.py _SHARE_PREFIX)
         for txt in ([text] if branches == 1 else [text, torch.cat([text[:n_clips]] * branches)]):
             unet.set_conditioning(txt, audio, audio_segment_mask(frames), frames)
-            for f32 in (False, True):
+            for f32 in ((False,) if a.split else (False, True)):
                 unet.f32_residual = f32
                 unet.denoise_forward(lat, t, rep=branches)
         unet.f32_residual = False
@@ -52,9 +58,10 @@ def main():
         print(f"tuned ({branches * n_clips}, 4, {frames}, {hw}, {hw}): {len(ops.tile_cache())} shapes, {time.time() - t0:.0f} s", flush=True)
 
     fwd(1, 12, 32)              # cfg 2
-    fwd(4, 12, 32)              # cfg 3 per-GPU forward
-    fwd(1, 12, 32, branches=3)  # dual guidance
-    fwd(1, 12, 32, branches=1)  # no guidance
+    if not a.split:
+        fwd(4, 12, 32)              # cfg 3 per-GPU forward
+        fwd(1, 12, 32, branches=3)  # dual guidance
+        fwd(1, 12, 32, branches=1)  # no guidance
     SD15_VAE_CONFIG = bench.SD15_VAE
     from asva_amd.vae import AutoencoderKL
 
@@ -63,10 +70,11 @@ def main():
     z = torch.randn(12, 4, 32, 32, device=dev)
     vae.decode(z)
     vae.decode(z, postprocess="uint8")
-    vae.encode(torch.rand(1, 3, 256, 256, device=dev) * 2 - 1)
+    if not a.split:
+        vae.encode(torch.rand(1, 3, 256, 256, device=dev) * 2 - 1)
     torch.cuda.synchronize()
     print(f"tuned VAE 12x256x256: {len(ops.tile_cache())} shapes, {time.time() - t0:.0f} s", flush=True)
-    if not a.skip_cfg4:
+    if not a.skip_cfg4 and not a.split:
         fwd(1, 24, 64)
         vae.decode(torch.randn(24, 4, 64, 64, device=dev))
         torch.cuda.synchronize()

@@ -64,6 +64,24 @@ class XAttnDesc(C.Structure):
     ]
 
 
+class FfnDesc(C.Structure):
+    """Mirror of `avsd_ffn_desc` (include/avsd.h)."""
+
+    _fields_ = [
+        ("h", c_void_p), ("ldh", C.c_int32), ("res_f32", C.c_int32),
+        ("res", c_void_p), ("ldres", C.c_int32), ("M", C.c_int32),
+        ("C", C.c_int32), ("nh", C.c_int32),
+        ("ln_stats", c_void_p), ("ln_eps", C.c_float), ("ldw1", C.c_int32),
+        ("w1", c_void_p),
+        ("cb1", c_void_p),
+        ("w2c", c_void_p),
+        ("bias2", c_void_p),
+        ("out", c_void_p), ("ldo", C.c_int32), ("ldm", C.c_int32),
+        ("out_master", c_void_p),
+        ("rowstats", c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); exactly the symbols include/avsd.h declares
 SIGNATURES = {
     "avsd_abi_version": (c_int, []),
@@ -75,6 +93,9 @@ SIGNATURES = {
     "avsd_cross_attention_block": (c_int, [C.POINTER(XAttnDesc), c_void_p]),
     "avsd_cross_attention_block_supported": (c_int, [c_int, c_int, c_int]),
     "avsd_sizeof_xattn_desc": (c_int, []),
+    "avsd_ffn_block": (c_int, [C.POINTER(FfnDesc), c_void_p]),
+    "avsd_ffn_block_supported": (c_int, [c_int, c_int]),
+    "avsd_sizeof_ffn_desc": (c_int, []),
     "avsd_linear_small_m": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "avsd_groupnorm_stats": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "avsd_groupnorm_apply": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
@@ -170,6 +191,10 @@ def lib() -> C.CDLL:
         if handle.avsd_sizeof_xattn_desc() != C.sizeof(XAttnDesc):
             raise AvsdError(
                 f"avsd_xattn_desc layout mismatch: C {handle.avsd_sizeof_xattn_desc()} B vs ctypes {C.sizeof(XAttnDesc)} B"
+            )
+        if handle.avsd_sizeof_ffn_desc() != C.sizeof(FfnDesc):
+            raise AvsdError(
+                f"avsd_ffn_desc layout mismatch: C {handle.avsd_sizeof_ffn_desc()} B vs ctypes {C.sizeof(FfnDesc)} B"
             )
         if handle.avsd_precision().decode() != P.NAME:
             raise AvsdError(f"{path} computes in {handle.avsd_precision().decode()}, expected {P.NAME}")

@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 from . import precision as P
-from ._lib import GemmDesc, XAttnDesc, check
+from ._lib import FfnDesc, GemmDesc, XAttnDesc, check
 
 PLAIN, TMIX, CONV3 = 0, 1, 2
 GEGLU, OUT_F32, GELU, XCD_N, ROWSTATS, LNFUSE, RES1_F32, RES2_F32, X2 = 1, 2, 4, 8, 16, 32, 64, 128, 256
@@ -750,6 +750,59 @@ def cross_attention_block(h: torch.Tensor, stats: torch.Tensor, wq: torch.Tensor
                                                                          "avsd_cross_attention_block"),
                           (h, stats, wq, q_colsum, q_bias, k, vt, wo, o_bias, res, out, master, rowstats))
         _TIMER.stop(ev, "cross_attention_block", 4.0 * M * Cc * Cc + 4.0 * M * lk * Cc, _nbytes(h, out, res, master) + 4.0 * Cc * Cc)
+    return out
+
+
+def ffn_block_supported(C: int, nh: int, M: int) -> bool:
+    return not P.SPLIT and bool(_lib.lib().avsd_ffn_block_supported(C, nh)) and M % 96 == 0
+
+
+def ffn_fold_terms(colsum1: torch.Tensor, bias1: torch.Tensor) -> torch.Tensor:
+    """[2 nh] colsum and bias of the packed GEGLU projection -> cb1 [nh / 16, 2, 32] (one 256-byte record per 16-feature chunk)"""
+    return torch.stack([colsum1.float().reshape(-1, 32), bias1.float().reshape(-1, 32)], 1).contiguous()
+
+
+def ffn_block(h: torch.Tensor, stats: torch.Tensor, w1: torch.Tensor, cb1: torch.Tensor, w2c: torch.Tensor,
+              bias2: torch.Tensor, *, res: torch.Tensor, eps: float = 1e-5, master: Optional[torch.Tensor] = None,
+              rowstats: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = res + W2 . (value * gelu(gate)) + bias2 with [value | gate] = LN(h) . W1^T + bias1 in one launch; see
+    avsd_ffn_block (include/avsd.h).  w1 [2 nh, C] LayerNorm-folded + GEGLU-packed, cb1 = ffn_fold_terms(colsum, bias),
+    w2c [nh / 16, C, 16] chunk-major W2."""
+    _req(h, P.ACT, "h")
+    _req(w1, P.ACT, "w1")
+    _req(w2c, P.ACT, "w2c")
+    _req(stats, F32, "stats")
+    _req(cb1, F32, "cb1")
+    M, Cc = h.shape
+    nh = w1.shape[0] // 2
+    if not cb1.is_contiguous() or cb1.numel() != 4 * nh:
+        raise ValueError("ffn_block: cb1 must be contiguous f32 [nh / 16, 2, 32]")
+    if not w2c.is_contiguous() or tuple(w2c.shape) != (nh // 16, Cc, 16) or not stats.is_contiguous() or stats.shape != (M, Cc // 32, 2):
+        raise ValueError("ffn_block: w2c must be contiguous [nh/16, C, 16] and stats contiguous f32 [M, C/32, 2]")
+    if out is None:
+        out = torch.empty((M, Cc), dtype=P.ACT, device=h.device)
+    d = FfnDesc()
+    d.h, d.ldh = _p(h), _ld(h)
+    _req(res, F32 if res.dtype == F32 else P.ACT, "res")
+    d.res, d.ldres, d.res_f32 = _p(res), _ld(res), int(res.dtype == F32)
+    d.M, d.C, d.nh = M, Cc, nh
+    d.ln_stats, d.ln_eps = _p(stats), float(eps)
+    d.w1, d.ldw1, d.cb1 = _p(w1), _ld(w1), _p(cb1)
+    d.w2c, d.bias2 = _p(w2c), _p(bias2)
+    d.out, d.ldo = _p(out), _ld(out)
+    if master is not None:
+        _req(master, F32, "master")
+        d.out_master, d.ldm = _p(master), _ld(master)
+    if rowstats is not None:
+        _req(rowstats, F32, "rowstats")
+        d.rowstats = _p(rowstats)
+    ev = _TIMER.start() if _TIMER is not None else None
+    check(_lib.lib().avsd_ffn_block(C.byref(d), _stream()), "avsd_ffn_block")
+    if ev is not None:
+        dc = FfnDesc.from_buffer_copy(d)
+        _TIMER.add_replay("ffn_block", lambda dc=dc: check(_lib.lib().avsd_ffn_block(C.byref(dc), _stream()), "avsd_ffn_block"),
+                          (h, stats, w1, cb1, w2c, bias2, res, out, master, rowstats))
+        _TIMER.stop(ev, "ffn_block", 2.0 * M * Cc * 3 * nh, _nbytes(h, out, res, master) + 2.0 * 3 * nh * Cc)
     return out
 
 

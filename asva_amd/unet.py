@@ -45,6 +45,11 @@ _F32_RES = os.environ.get("AVSD_F32_RESIDUAL", "0") != "0"
 # Per model: `unet.fp8_attention = True` (optionally `unet.fp8_scales = (q, k, v)` per-tensor scales, default 1.0).
 _ATTN_FP8 = os.environ.get("AVSD_ATTN_FP8", "0") != "0"
 _FUSE_XATTN = os.environ.get("AVSD_FUSE_XATTN", "1") != "0"
+# GEGLU feed-forward as ONE launch where the kernel is built (C = 320, avsd_ffn_block).  Measured on MI355X (tools/ffn_bench.py,
+# profiles/r3_ffn_probe.txt): 141 us against 127-130 us for the two GEMMs on the 24576-row layer of one clip (485 vs 481 us at four
+# clips) — the A waves' serial chain (LDS fragment reads, MFMAs, GELU) does not overlap enough to pay for the lost co-residency.
+# Off by default; AVSD_FUSE_FFN=1 switches it on (the packed blob then carries the chunk-major W2).
+_FUSE_FFN = os.environ.get("AVSD_FUSE_FFN", "0") != "0"
 # Optional (AVSD_SIDE_STREAM=1): independent side work (ResBlock shortcut convolutions, the frame-0 K/V projection of the
 # spatial attention, the time-embedding MLP) on a second HIP stream, forked from and joined back into the main one — parallel
 # branches of the captured hipGraph.  Measured on MI355X: two whole B=1 forwards on two streams take 0.71x their sum
@@ -428,6 +433,10 @@ class Packer:
         if p.audio:
             p.norm_audio = self.aff(b.norm_audio)
             p.attn_audio = self.attn(b.attn_audio, False, b.norm_audio)
+        if _FUSE_FFN and not P.SPLIT and p.dim == 320:      # the fused feed-forward kernel reads W2 chunk-major: [nh / 16][C][16] (avsd_ffn_block)
+            w2 = b.ff.net[2].weight.detach().float()
+            p.ff2c = reg(to_act(w2.reshape(w2.shape[0], w2.shape[1] // 16, 16).permute(1, 0, 2).contiguous()))
+            p.cb1_ln = reg(ops.ffn_fold_terms(from_act(w1_ln).sum(1), b1_ln))
         return p
 
     def block(self, m: _Block):
@@ -1163,11 +1172,15 @@ def _transformer(st, x: _Act, p, hw, heads, split: int = 1) -> _Act:
     o = ops.temporal_attention(qkv, b=B, frames=Fr, hw=L, heads=heads)
     h = stream(o, p.attn_temp.wo, p.attn_temp.bo, h)
     # 5. GEGLU feed-forward, activation fused in the first GEMM's epilogue (:361-371)
-    if fused:
-        g = ops.gemm(h.lo, p.w1_ln, bias=p.b1_ln, geglu=True, ln=(stats[si], p.s1_ln, eps))
+    if fused and _FUSE_FFN and getattr(p, "ff2c", None) is not None and ops.ffn_block_supported(C, p.w1_ln.shape[0] // 2, M):
+        m = _master(st, h.lo, C)            # one launch: the M x 4C hidden tensor never exists
+        h = _Act(ops.ffn_block(h.lo, stats[si], p.w1_ln, p.cb1_ln, p.ff2c, p.ff2.b, res=h.res, eps=eps, master=m), m)
     else:
-        g = ops.gemm(ops.layernorm(h.lo, p.norm3.g, p.norm3.b), p.w1, bias=p.b1, geglu=True)
-    h = stream(g, p.ff2.w, p.ff2.b, h, want_stats=False)
+        if fused:
+            g = ops.gemm(h.lo, p.w1_ln, bias=p.b1_ln, geglu=True, ln=(stats[si], p.s1_ln, eps))
+        else:
+            g = ops.gemm(ops.layernorm(h.lo, p.norm3.g, p.norm3.b), p.w1, bias=p.b1, geglu=True)
+        h = stream(g, p.ff2.w, p.ff2.b, h, want_stats=False)
     return stream(h.lo, p.proj_out.w, p.proj_out.b, x, want_stats=False)
 
 

@@ -180,6 +180,35 @@ int avsd_cross_attention_block_supported(int C, int heads, int lk_pad);
 int avsd_cross_attention_block(const avsd_xattn_desc* desc_host, void* stream);
 int avsd_sizeof_xattn_desc(void);
 
+/* ---- fused GEGLU feed-forward block -----------------------------------------------------------------------------------
+ * One launch for the last residual update of BasicTransformerBlock (ff_spatio_audio_temp_transformer_3d.py:361-371; diffusers
+ * FeedForward with GEGLU):    out = res + W2 . (value * gelu_erf(gate)) + bias2 ,   [value | gate] = LayerNorm(h) . W1^T + bias1
+ * h [M][C] is the 16-bit residual stream with the row statistics `ln_stats` [M][C/32][2] of AVSD_GEMM_ROWSTATS; w1 is the
+ * LayerNorm-folded GEGLU projection exactly as AVSD_GEMM_LNFUSE + AVSD_GEMM_GEGLU take it ([2 nh][ldw1], rows packed per 32 as
+ * [16 value | 16 gate]) and cb1 its ln_colsum and bias, interleaved per 32-row block: cb1[j][0][c] = colsum[32 j + c],
+ * cb1[j][1][c] = bias[32 j + c] ([nh/16][2][32] f32: one 256-byte record per chunk); w2c is the output projection W2 [C][nh] re-laid chunk-major, w2c[j][n][k] = W2[n][16 j + k]
+ * ([nh/16][C][16]: every 16-feature chunk one contiguous block); `res` is h again (16-bit) or its f32 master (res_f32).
+ * The M x nh hidden tensor is never written: the 96-row activation tile stays in LDS while the hidden dimension is walked in
+ * 16-feature chunks (ffn.hip).  Outputs like avsd_gemm_bf16: `out` 16-bit [M][ldo], optional `out_master` f32, `rowstats`.
+ * Built for C = 320 (SD1.5 level 0: M = 24576 rows per clip = 256 workgroups of 96 rows); avsd_ffn_block_supported() tells, other
+ * widths run the two GEMMs.  M % 96 == 0. */
+typedef struct avsd_ffn_desc {
+  const void* h;        int32_t ldh;   int32_t res_f32;
+  const void* res;      int32_t ldres; int32_t M;
+  int32_t C, nh;
+  const float* ln_stats; float ln_eps; int32_t ldw1;
+  const void* w1;
+  const float* cb1;
+  const void* w2c;
+  const float* bias2;
+  void* out;            int32_t ldo;   int32_t ldm;
+  float* out_master;
+  float* rowstats;
+} avsd_ffn_desc;
+int avsd_ffn_block_supported(int C, int nh);
+int avsd_ffn_block(const avsd_ffn_desc* desc_host, void* stream);
+int avsd_sizeof_ffn_desc(void);
+
 /* out[M, N] (f32) = act_out( act_in(x[M, K] f32) . W[N, K]^T + bias ), M <= 16.
  * act: 0 none, 1 SiLU.  Time-embedding MLP and the per-ResBlock time_emb_proj
  * (audio_cond_unet_3d_condition.py:673-680, ff_spatio_temp_resnet_3d.py:170), and the

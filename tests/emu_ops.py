@@ -157,6 +157,22 @@ def cross_attention_block_supported(C, heads, lk_pad, M, L):
     return C == 320 and heads == 8 and lk_pad in (32, 64, 96) and M % 128 == 0 and L % 128 == 0
 
 
+def ffn_block_supported(C, nh, M):
+    return C == 320 and nh % 16 == 0 and M % 96 == 0
+
+
+def ffn_fold_terms(colsum1, bias1):
+    return torch.stack([colsum1.float().reshape(-1, 32), bias1.float().reshape(-1, 32)], 1).contiguous()
+
+
+def ffn_block(h, stats, w1, cb1, w2c, bias2, *, res, eps=1e-5, master=None, rowstats=None, out=None):
+    """same rounding point as the fused kernel: the hidden activations are rounded to the storage type once"""
+    colsum1, bias1 = cb1[:, 0].reshape(-1), cb1[:, 1].reshape(-1)
+    g = gemm(h, w1, bias=bias1, geglu=True, ln=(stats, colsum1, eps))
+    w2 = w2c.permute(1, 0, 2).reshape(w2c.shape[1], -1)
+    return gemm(g, w2, bias=bias2, res1=res, master=master, rowstats=rowstats, out=out)
+
+
 def cross_attention_block(h, stats, wq, q_colsum, q_bias, k, vt, lk, wo, o_bias, *, res, heads, L, q_per_kv, eps=1e-5, scale=None,
                           rowstats=None, master=None, out=None):
     """same rounding points as the fused kernel: q, P and o are rounded to the storage type"""

@@ -651,3 +651,50 @@ def test_xattn_pack_kv_matches_indexing(ops, gather):
         kv3 = kv3[:, idx.long()].reshape(nb, lk, 2 * C)
     assert torch.equal(k[:, :lk], kv3[..., :C]) and torch.equal(vt[:, :, :lk], kv3[..., C:].transpose(1, 2))
     assert not k[:, lk:].any() and not vt[:, :, lk:].any()          # padding zero-filled by the launch
+
+
+# ---- fused GEGLU feed-forward block (avsd_ffn_block) ---------------------------------------------------------------------------
+@pytest.mark.parametrize("M,f32res", [(96, False), (1152, False), (1152, True), (24576, False)])
+def test_ffn_block_matches_the_two_gemms_and_fp32(ops, M, f32res):
+    """out = res + W2 (value * gelu(gate)) + b2 with [value | gate] = LN3(h) W1^T + b1 (ff_spatio_audio_temp_transformer_3d.py:
+    361-371) in one launch, against (a) the LayerNorm-folded GEGLU GEMM followed by the output GEMM — the same roundings, so
+    only the f32 summation order differs — and (b) a plain fp32 statement of the block"""
+    from asva_amd.unet import Packer, _Affine
+    from asva_amd.weights import pack_geglu, pack_linear
+
+    C, NH = 320, 1280
+    x = rnd(M, C, seed=1)
+    w0 = rnd(C, C, seed=2, scale=C ** -0.5)
+    stats = torch.empty(M, C // 32, 2, device=dev())
+    h = ops.gemm(x, w0, rowstats=stats)                       # a residual stream with its row statistics
+    norm = _Affine(C)
+    with torch.no_grad():
+        norm.weight.copy_(1.0 + 0.1 * rndf(C, seed=3).cpu())
+        norm.bias.copy_(0.1 * rndf(C, seed=4).cpu())
+    norm = norm.to(dev())
+    w1 = rndf(2 * NH, C, seed=5, scale=C ** -0.5)
+    b1 = rndf(2 * NH, seed=6, scale=0.1)
+    w2 = rndf(C, NH, seed=7, scale=NH ** -0.5)
+    b2 = rndf(C, seed=8, scale=0.1)
+    g3, be3 = norm.weight.detach().float(), norm.bias.detach().float()
+    w1_ln, b1_ln = pack_geglu(w1 * g3[None, :], w1 @ be3 + b1)
+    s1_ln = w1_ln.float().sum(1)
+    w2p = pack_linear(w2)
+    w2c = w2p.reshape(C, NH // 16, 16).permute(1, 0, 2).contiguous()
+    res = h.float() if f32res else h
+    master = torch.empty(M, C, device=dev()) if f32res else None
+    out = ops.ffn_block(h, stats, w1_ln, ops.ffn_fold_terms(s1_ln, b1_ln), w2c, b2, res=res, master=master)
+    # (a) the two launches it replaces
+    g = ops.gemm(h, w1_ln, bias=b1_ln, geglu=True, ln=(stats, s1_ln, 1e-5))
+    two = ops.gemm(g, w2p, bias=b2, res1=res)
+    assert rel_l2(out, two) < 3e-3                            # hidden activations: same rounding point; order of the f32 sums differs
+    # (b) fp32 statement on the same 16-bit weights
+    hf = h.float()
+    n3 = F.layer_norm(hf, (C,), g3, be3, 1e-5)
+    hid = n3 @ w1.to(torch.bfloat16).float().T + b1
+    ref = hf + (hid[:, :NH] * F.gelu(hid[:, NH:])) @ w2p.float().T + b2
+    err = rel_l2(out, ref)
+    assert err < 6e-3, err                                     # folded-gain weights are rounded after the fold: as the unfused path
+    assert rel_l2(two, ref) < 6e-3
+    if master is not None:
+        assert rel_l2(master, ref) < 4e-3 and rel_l2(out, master) < 3e-3

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 python bench.py > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/${TAG}_bench_n1.err
 cut -c1-300 gpurun_out/${TAG}_bench_n1.json
-BENCH="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-roofline --no-vae --also-clips 0"
+BENCH="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-roofline --no-vae --no-precise --also-clips 0"
 # kernel trace of the graph-replayed run
 (cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- $BENCH --steps 60 --warmup 5 > /tmp/kt.log 2>&1)
 KT=$(find /tmp/prof_kt -name "*.db" | head -1)

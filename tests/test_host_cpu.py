@@ -439,3 +439,48 @@ def test_mjpeg_avi_writer_roundtrip(tmp_path):
     v, fps, a, afps = read_mjpeg_avi(path)
     assert v.shape == video.shape and abs(fps - 6.0) < 1e-6 and afps == 16000 and a.shape == audio.shape
     assert (v.float() - video.float()).abs().mean() < 8.0 and (a - audio).abs().max() < 1e-4
+
+
+def test_split_precision_twin_storage_and_packing():
+    """Host convention of the split-precision mode (asva_amd/precision.py): a split tensor is a view into the first half of its
+    storage, its rest plane sits at the same offset in the second half; weights.to_act builds such pairs, views keep their rest
+    plane, and Packer.finish lays the whole blob out the same way.  (No kernel runs here: -m gpu covers the arithmetic.)"""
+    from asva_amd import precision as P
+    from asva_amd import unet as U
+    from asva_amd import weights as W
+    from tests import emu_ops
+
+    w = torch.randn(24, 40, generator=torch.Generator().manual_seed(0))
+    assert not W.is_twin(W.to_act(w))                     # mode off: plain 16-bit tensor
+    P.set_split(True)
+    old_ops = U.ops
+    try:
+        t = W.to_act(w)
+        assert t.dtype == P.ACT and t.shape == w.shape and W.is_twin(t)
+        main, rest = t.float(), W.rest_of(t).float()
+        assert torch.equal(main, w.to(P.ACT).float()) and torch.equal(rest, (w - main).to(P.ACT).float())
+        v = W.from_act(t)
+        assert ((v - w).norm() / w.norm()).item() < 2.0 ** -16 and ((main - w).norm() / w.norm()).item() > 1e-3
+        sl = t[4:9, 8:24]                                  # a view carries its rest plane
+        assert W.is_twin(sl) and torch.equal(W.from_act(sl), v[4:9, 8:24])
+        assert not W.is_twin(torch.zeros(8, 8, dtype=P.ACT))
+        # the packed blob of a model is one twin allocation: rest planes at the same offsets in the second half
+        U.ops = emu_ops
+        g = load_golden("unet_tiny_e2e.pt")
+        m = filled_unet(g["config"])
+        pk = m.pack("cpu")
+        assert pk.split and pk.blob.numel() % 2 == 0
+        half = pk.blob.numel() // 2
+        wq = pk.down[0].attentions[0].attn1.wq_ln
+        assert W.is_twin(wq) and wq.untyped_storage().data_ptr() == pk.blob.untyped_storage().data_ptr()
+        off = wq.storage_offset() * 2
+        assert torch.equal(pk.blob[half + off:half + off + wq.numel() * 2].view(P.ACT).view(wq.shape), W.rest_of(wq))
+        b = m.down_blocks[0].attentions[0].transformer_blocks[0]
+        want = b.attn1.to_q.weight.detach().float() * b.norm1.weight.detach().float()[None, :]
+        assert ((W.from_act(wq) - want).norm() / want.norm()).item() < 2.0 ** -16
+        # leaving the mode repacks
+        P.set_split(False)
+        assert not m.pack("cpu").split
+    finally:
+        P.set_split(False)
+        U.ops = old_ops

@@ -844,8 +844,12 @@ int dispatch_tile_x2(const avsd_gemm_desc& d, int tile, hipStream_t s) {
     case 13: return launch2<64, 64, 2, 2, 2, MODE, 0, true>(d, s);     // 64 KB: two blocks per CU
     case 24: return launch2<128, 64, 2, 2, 3, MODE, 2, true>(d, s);    // 144 KB, loader waves
     case 25: return launch2<64, 64, 2, 2, 4, MODE, 2, true>(d, s);     // 128 KB, loader waves
+    // split-precision-only shapes (ids above the 16-bit range): what a doubled 2-stage ring still holds
+    case 34: return launch2<128, 160, 4, 1, 2, MODE, 0, true>(d, s);   // 144 KB: N = 320 layers in two column tiles, 32x160 wave tiles
+    case 35: return launch2<256, 64, 4, 2, 2, MODE, 0, true>(d, s);    // 160 KB, 8 waves
+    case 36: return launch2<128, 192, 2, 2, 2, MODE, 0, true>(d, s);   // 160 KB, 64x96 wave tiles
     default:
-      avsd_set_error("gemm: AVSD_GEMM_X2 runs on tiles 4, 7, 11, 12, 13, 24, 25 (got %d)", tile);
+      avsd_set_error("gemm: AVSD_GEMM_X2 runs on tiles 4, 7, 11, 12, 13, 24, 25, 34, 35, 36 (got %d)", tile);
       return AVSD_EINVAL;
   }
 }
@@ -954,7 +958,8 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
   if (d.split_k > 1) {
     AVSD_REQUIRE(d.splitk_ws != nullptr, "gemm: split_k needs a workspace");
     AVSD_REQUIRE(!(d.flags & AVSD_GEMM_GEGLU) && d.batch == 1, "gemm: split_k cannot be combined with GEGLU or batching");
-    AVSD_REQUIRE(d.tile >= 4 && d.tile <= AVSD_GEMM_MAX_TILE, "gemm: split_k needs an LDS-direct tile (4..33), got %d", d.tile);
+    AVSD_REQUIRE(d.tile >= 4 && d.tile <= ((d.flags & AVSD_GEMM_X2) ? AVSD_GEMM_MAX_TILE_X2 : AVSD_GEMM_MAX_TILE),
+                 "gemm: split_k needs an LDS-direct tile (4..33; split precision: ..36), got %d", d.tile);
     AVSD_REQUIRE(d.split_k <= (d.K + 63) / 64, "gemm: split_k (%d) exceeds the number of K tiles", d.split_k);
     AVSD_REQUIRE(!d.splitk_cnt || d.N % 32 == 0, "gemm: the in-launch split-K reduction needs N %% 32 == 0 (got %d)", d.N);
   }

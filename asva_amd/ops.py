@@ -107,8 +107,8 @@ SPLITK_CANDIDATES = ((6, 2), (6, 4), (6, 8), (9, 2), (9, 4), (4, 2), (4, 4), (4,
                      (20, 2), (20, 4), (24, 2), (24, 4), (24, 8), (25, 2), (25, 4), (26, 2), (26, 4), (26, 8),
                      (29, 2), (29, 4), (29, 8), (30, 2), (30, 4), (30, 8), (31, 2), (31, 4), (31, 8))
 # split precision (AVSD_GEMM_X2): the tiles whose doubled LDS stage fits (gemm.hip dispatch_tile_x2)
-X2_TILE_CANDIDATES = ((4, 1), (7, 1), (11, 1), (12, 1), (13, 1), (24, 1), (25, 1))
-X2_SPLITK_CANDIDATES = ((4, 2), (4, 4), (4, 8), (7, 2), (7, 4), (7, 8), (11, 2), (11, 4), (24, 2), (24, 4), (24, 8), (25, 2), (25, 4), (25, 8))
+X2_TILE_CANDIDATES = ((4, 1), (7, 1), (11, 1), (12, 1), (13, 1), (24, 1), (25, 1), (34, 1), (35, 1), (36, 1))
+X2_SPLITK_CANDIDATES = ((34, 2), (34, 4), (35, 2), (35, 4), (36, 2), (36, 4), (4, 2), (4, 4), (4, 8), (7, 2), (7, 4), (7, 8), (11, 2), (11, 4), (24, 2), (24, 4), (24, 8), (25, 2), (25, 4), (25, 8))
 _TILE_CACHE: dict = {}
 _AUTOTUNE = os.environ.get("AVSD_AUTOTUNE", "0") == "1"
 
@@ -181,6 +181,8 @@ def _heuristic_tile_x2(M: int, N: int, K: int, geglu: bool, splitk_ok: bool):
         return ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
 
     nk = (K + 63) // 64
+    if N % 160 == 0 and N <= 640 and tiles(128, 160) >= 224:
+        return 34, 1
     if N >= 128 and tiles(128, 128) >= 224:
         return 11, 1
     if tiles(128, 64) >= 224:

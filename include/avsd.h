@@ -83,6 +83,7 @@ enum { AVSD_GEMM_PLAIN = 0, AVSD_GEMM_TMIX = 1, AVSD_GEMM_CONV3 = 2 };
 enum { AVSD_GEMM_GEGLU = 1, AVSD_GEMM_OUT_F32 = 2, AVSD_GEMM_GELU = 4, AVSD_GEMM_XCD_N = 8, AVSD_GEMM_ROWSTATS = 16,
        AVSD_GEMM_LNFUSE = 32, AVSD_GEMM_RES1_F32 = 64, AVSD_GEMM_RES2_F32 = 128, AVSD_GEMM_X2 = 256 };
 #define AVSD_GEMM_MAX_TILE 33
+#define AVSD_GEMM_MAX_TILE_X2 36   /* AVSD_GEMM_X2 also has tiles 34..36 (gemm.hip dispatch_tile_x2) */
 
 typedef struct avsd_gemm_desc {
   const void* A;        /* bf16 */
@@ -137,7 +138,7 @@ typedef struct avsd_gemm_desc {
   /* AVSD_GEMM_X2 (split precision, see "split-precision storage" below): every 16-bit operand is a pair of planes; these are
    * the ELEMENT offsets from each main plane to its rest plane (same strides).  The product is accumulated as
    * W.A + Wr.A + W.Ar (three MFMA passes into one f32 accumulator); 16-bit residuals are read as main + rest and the output
-   * is written as main = round16(v), rest = round16(v - main).  LDS-direct tiles 4, 7, 11, 12, 13, 24, 25 only. */
+   * is written as main = round16(v), rest = round16(v - main).  LDS-direct tiles 4, 7, 11, 12, 13, 24, 25, 34, 35, 36 only. */
   int64_t a_lo, a2_lo, w_lo, out_lo, res1_lo, res2_lo;
 } avsd_gemm_desc;
 

@@ -31,6 +31,15 @@ def fp16_library():
     P.set_precision("bf16")
 
 
+@pytest.fixture
+def split_precision():
+    from asva_amd import precision as P
+
+    P.set_split(True)
+    yield
+    P.set_split(False)
+
+
 def _setup(kind):
     from asva_amd import precision as P
     from asva_amd.engine import DenoiseEngine
@@ -43,8 +52,10 @@ def _setup(kind):
     gen = torch.Generator().manual_seed(3)
     lat0 = torch.randn(1, 4, f, h, w, generator=gen).to(dev)
     # the CFG batch of audio-only guidance, already in the storage type: text [t, t], audio [null, a] (pipeline :150-194)
-    text = torch.cat([g["text"][:1], g["text"][:1]]).to(dev, P.ACT).contiguous()
-    audio = torch.cat([g["audio"][:1], g["audio"][1:2]]).to(dev, P.ACT).contiguous()
+    # (split precision: the host hands f32 and the conditioning plan's first launches split it into the two planes)
+    cond = torch.float32 if P.SPLIT else P.ACT
+    text = torch.cat([g["text"][:1], g["text"][:1]]).to(dev, cond).contiguous()
+    audio = torch.cat([g["audio"][:1], g["audio"][1:2]]).to(dev, cond).contiguous()
     eng = DenoiseEngine(unet, PNDMScheduler() if kind == "pndm" else DDIMScheduler(), audio_guidance_scale=4.0, use_graph=False)
     return g, unet, vae, eng, lat0, text, audio, f
 
@@ -144,6 +155,23 @@ def test_plans_replay_bit_identically_from_fresh_buffers(tmp_path):
     torch.cuda.synchronize()
     assert not torch.equal(b3.view("noise_pred"), _bytes(r["noise"]))
     b3.close()
+
+
+def test_split_precision_plans_replay_bit_identically(tmp_path, split_precision):
+    """The split-precision step is the same kind of launch list: twin weight blobs travel as CONST regions (both planes), the
+    f32 conditioning inputs are split by recorded launches, and a replay from zero-filled buffers reproduces the recording
+    run bit for bit."""
+    r = _record(tmp_path, "ddim", steps=2)
+    b = r["bundle"]
+    b.bind_fresh(r["lat0"].device)
+    for name, src in (("text", r["text"]), ("audio", r["audio"]), ("x", r["lat0"]), ("t", r["t"]), ("latents", r["lat0"])):
+        b.view(name).copy_(_bytes(src))
+    for p in ("set_conditioning", "forward", "decode"):
+        b.run(p)
+    torch.cuda.synchronize()
+    assert torch.equal(b.view("noise_pred"), _bytes(r["noise"]))
+    assert torch.equal(b.view("frames"), _bytes(r["frames"]))
+    b.close()
 
 
 @pytest.mark.parametrize("kind", ["pndm", "ddim"])

@@ -100,6 +100,9 @@ SIGNATURES = {
     "avsd_groupnorm_stats": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "avsd_groupnorm_apply": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                      c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "avsd_groupnorm_fused_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "avsd_groupnorm_fused": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
+                                     c_int, c_void_p, c_int, c_void_p]),
     "avsd_groupnorm_nchunks": (c_int, [c_int, c_int, c_int]),
     "avsd_groupnorm_scratch_floats": (c_int, [c_int, c_int, c_int, c_int]),
     "avsd_layernorm": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p]),
@@ -128,6 +131,8 @@ SIGNATURES = {
                                         c_int, c_void_p]),
     "avsd_groupnorm_apply_x2": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_int, c_void_p,
                                         c_void_p, c_float, c_void_p, c_int, c_int, c_void_p, c_int, c_int64, c_void_p]),
+    "avsd_groupnorm_fused_x2": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_int, c_void_p,
+                                        c_void_p, c_float, c_int, c_void_p, c_int, c_int64, c_void_p]),
     "avsd_layernorm_x2": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p,
                                   c_int, c_int, c_void_p]),
     "avsd_attention_x2": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_void_p, c_int, c_int64,

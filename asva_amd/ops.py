@@ -589,11 +589,16 @@ def linear_small_m(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
     return out
 
 
+# one-launch GroupNorm for small batches (csrc/groupnorm_fused.hip); AVSD_GN_FUSED=0: always the pair
+_GN_FUSED = os.environ.get("AVSD_GN_FUSED", "1") != "0"
+
+
 def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], nb: int, rows_per_batch: int, groups: int,
               gamma: torch.Tensor, beta: torch.Tensor, eps: float, act: bool,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """GroupNorm(+SiLU) of the channel concat [x1 | x2]; statistics pooled over each run of
-    `rows_per_batch` rows.  Two launches: partial sums, then reduce + apply."""
+    `rows_per_batch` rows.  One launch for small batches (avsd_groupnorm_fused: the ResBlock norms at 4 x 4, the per-frame
+    norms up to 16 x 16), else two: partial sums, then reduce + apply."""
     _req(x1, P.ACT, "x1")
     c1 = x1.shape[1]
     c2 = 0
@@ -604,22 +609,33 @@ def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], nb: int, rows_per_ba
     _req(beta, F32, "beta")
     L = _lib.lib()
     rows = nb * rows_per_batch
-    nchunks = L.avsd_groupnorm_nchunks(nb, rows_per_batch, c1 + c2)
-    partial = torch.empty((L.avsd_groupnorm_scratch_floats(nb, nchunks, groups, c1 + c2),), dtype=F32, device=x1.device)
     if out is None:
         out = alloc16((rows, c1 + c2), x1.device)
     s = _stream()
+    ld2 = _ld(x2) if x2 is not None else 0
     ev = _TIMER.start() if _TIMER is not None else None
+    if _GN_FUSED and L.avsd_groupnorm_fused_supported(nb, rows_per_batch, groups, c1, c2, int(P.SPLIT)):
+        if P.SPLIT:
+            check(L.avsd_groupnorm_fused_x2(_p(x1), _ld(x1), c1, _lo(x1), _p(x2), ld2, c2, _lo(x2), nb, rows_per_batch, groups, _p(gamma),
+                                            _p(beta), float(eps), int(act), _p(out), _ld(out), _lo(out), s), "avsd_groupnorm_fused_x2")
+        else:
+            check(L.avsd_groupnorm_fused(_p(x1), _ld(x1), c1, _p(x2), ld2, c2, nb, rows_per_batch, groups, _p(gamma), _p(beta), float(eps),
+                                         int(act), _p(out), _ld(out), s), "avsd_groupnorm_fused")
+        if ev is not None:
+            _TIMER.stop(ev, "groupnorm", 0.0, _nbytes(x1, x2) + _nbytes(out))
+        return out
+    nchunks = L.avsd_groupnorm_nchunks(nb, rows_per_batch, c1 + c2)
+    partial = torch.empty((L.avsd_groupnorm_scratch_floats(nb, nchunks, groups, c1 + c2),), dtype=F32, device=x1.device)
     if P.SPLIT:
-        check(L.avsd_groupnorm_stats_x2(_p(x1), _ld(x1), c1, _lo(x1), _p(x2), _ld(x2) if x2 is not None else 0, c2, _lo(x2), nb,
+        check(L.avsd_groupnorm_stats_x2(_p(x1), _ld(x1), c1, _lo(x1), _p(x2), ld2, c2, _lo(x2), nb,
                                         rows_per_batch, groups, _p(partial), nchunks, s), "avsd_groupnorm_stats_x2")
-        check(L.avsd_groupnorm_apply_x2(_p(x1), _ld(x1), c1, _lo(x1), _p(x2), _ld(x2) if x2 is not None else 0, c2, _lo(x2), nb,
+        check(L.avsd_groupnorm_apply_x2(_p(x1), _ld(x1), c1, _lo(x1), _p(x2), ld2, c2, _lo(x2), nb,
                                         rows_per_batch, groups, _p(gamma), _p(beta), float(eps), _p(partial), nchunks, int(act),
                                         _p(out), _ld(out), _lo(out), s), "avsd_groupnorm_apply_x2")
     else:
-        check(L.avsd_groupnorm_stats(_p(x1), _ld(x1), c1, _p(x2), _ld(x2) if x2 is not None else 0, c2, nb, rows_per_batch,
+        check(L.avsd_groupnorm_stats(_p(x1), _ld(x1), c1, _p(x2), ld2, c2, nb, rows_per_batch,
                                      groups, _p(partial), nchunks, s), "avsd_groupnorm_stats")
-        check(L.avsd_groupnorm_apply(_p(x1), _ld(x1), c1, _p(x2), _ld(x2) if x2 is not None else 0, c2, nb, rows_per_batch,
+        check(L.avsd_groupnorm_apply(_p(x1), _ld(x1), c1, _p(x2), ld2, c2, nb, rows_per_batch,
                                      groups, _p(gamma), _p(beta), float(eps), _p(partial), nchunks, int(act), _p(out), _ld(out), s),
               "avsd_groupnorm_apply")
     if ev is not None:

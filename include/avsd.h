@@ -235,6 +235,16 @@ int avsd_groupnorm_stats(const void* x1, int ld1, int c1, const void* x2, int ld
 int avsd_groupnorm_apply(const void* x1, int ld1, int c1, const void* x2, int ld2, int c2,
                          int nb, int rows_per_batch, int groups, const float* gamma, const float* beta, float eps,
                          const float* scratch, int nchunks, int act, void* y, int ldy, void* stream);
+/* One-launch form for SMALL batches: a workgroup keeps whole groups (rows_per_batch rows x the channels of a few groups,
+ * <= ~1900 16-byte vectors) in registers between the statistics and the apply: no scratch, no second read of the input.
+ * Same arithmetic as the pair above (f32 sums per thread, folded in double in a fixed order; results differ from the pair
+ * in the last bits only).  avsd_groupnorm_fused_supported(...) != 0 tells whether a geometry qualifies: the UNet's ResBlock
+ * norms at 4 x 4 and its per-frame Transformer3D norms up to 16 x 16 do (5-7 us against 10-12 us for the pair); larger
+ * batches are refused — too few workgroups own whole groups for the element-wise work (profiles/r3_gn_probe.txt).
+ * Replaces the same reference sites as the pair. */
+int avsd_groupnorm_fused_supported(int nb, int rows_per_batch, int groups, int c1, int c2, int split);
+int avsd_groupnorm_fused(const void* x1, int ld1, int c1, const void* x2, int ld2, int c2, int nb, int rows_per_batch,
+                         int groups, const float* gamma, const float* beta, float eps, int act, void* y, int ldy, void* stream);
 /* Suggested nchunks, and the scratch size in floats for it (pure host arithmetic). */
 int avsd_groupnorm_nchunks(int nb, int rows_per_batch, int channels);
 int avsd_groupnorm_scratch_floats(int nb, int nchunks, int groups, int channels);
@@ -359,6 +369,9 @@ int avsd_linear_small_m_x2(const float* x, const void* W, int64_t w_lo, const fl
                            int M, int N, int K, int ldw, int act_in, int act_out, void* stream);
 int avsd_groupnorm_stats_x2(const void* x1, int ld1, int c1, int64_t x1_lo, const void* x2, int ld2, int c2, int64_t x2_lo,
                             int nb, int rows_per_batch, int groups, float* scratch, int nchunks, void* stream);
+int avsd_groupnorm_fused_x2(const void* x1, int ld1, int c1, int64_t x1_lo, const void* x2, int ld2, int c2, int64_t x2_lo,
+                            int nb, int rows_per_batch, int groups, const float* gamma, const float* beta, float eps, int act,
+                            void* y, int ldy, int64_t y_lo, void* stream);
 int avsd_groupnorm_apply_x2(const void* x1, int ld1, int c1, int64_t x1_lo, const void* x2, int ld2, int c2, int64_t x2_lo,
                             int nb, int rows_per_batch, int groups, const float* gamma, const float* beta, float eps,
                             const float* scratch, int nchunks, int act, void* y, int ldy, int64_t y_lo, void* stream);

@@ -268,25 +268,54 @@ def test_linear_small_m(ops):
 
 
 # ---- normalisation -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("fused", [True, False])     # one launch (csrc/groupnorm_fused.hip) where the batch fits, else / or stats + apply
 @pytest.mark.parametrize("nb,rows,c1,c2,groups,act", [
     (2, 12 * 64, 320, 0, 32, True),      # 5-D resnet norm
     (24, 64, 640, 0, 32, False),         # per-frame transformer norm
     (2, 12 * 16, 1280, 640, 32, True),   # concat with a group straddling the two sources (60 ch/group)
     (2, 4 * 64, 80, 80, 16, True),       # tiny config, 10 ch/group
     (1, 7 * 9, 2560, 0, 32, True),
+    (2, 12 * 16, 640, 320, 32, True),    # 30 channels per group: four groups = 15 vectors per row
+    (2, 12 * 16, 1280, 1280, 32, True),
+    (2, 12 * 64, 1280, 1280, 32, True),
+    (24, 256, 320, 0, 32, False),        # per-frame norm: four 10-channel groups per workgroup
+    (24, 16, 1280, 0, 32, False),
+    (12, 256, 512, 0, 32, True),         # 16 channels per group
+    (2, 12 * 1024, 320, 0, 32, True),    # 32 x 32 level: stats + apply either way
+    (3, 50, 32, 0, 8, True),             # 4 channels per group: a vector holds two whole groups
 ])
-def test_groupnorm(ops, nb, rows, c1, c2, groups, act):
-    x1 = rnd(nb * rows, c1, seed=1) + 0.5
-    x2 = rnd(nb * rows, c2, seed=2) * 2 if c2 else None
+def test_groupnorm(ops, nb, rows, c1, c2, groups, act, fused, monkeypatch):
+    monkeypatch.setattr(ops, "_GN_FUSED", fused)
+    # sources and output are column slices of wider buffers (ld > channels), as the UNet's skip / fused-output views are
+    x1 = (rnd(nb * rows, c1 + 16, seed=1) + 0.5)[:, 8:8 + c1]
+    x2 = (rnd(nb * rows, c2 + 8, seed=2) * 2)[:, :c2] if c2 else None
     C = c1 + c2
     gamma, beta = rndf(C, seed=3) + 1.0, rndf(C, seed=4)
     eps = 1e-5
-    out = ops.groupnorm(x1, x2, nb, rows, groups, gamma, beta, eps, act)
+    buf = torch.zeros(nb * rows, C + 8, dtype=x1.dtype, device=x1.device)
+    out = ops.groupnorm(x1, x2, nb, rows, groups, gamma, beta, eps, act, out=buf[:, :C])
+    assert not buf[:, C:].any()
     x = torch.cat([x1, x2], 1) if c2 else x1
     xr = x.float().reshape(nb, rows, C).permute(0, 2, 1)
     ref = F.group_norm(xr, groups, gamma, beta, eps)
     ref = (F.silu(ref) if act else ref).permute(0, 2, 1).reshape(nb * rows, C)
     assert rel_l2(out, ref) < TOL_BF16
+    # each group separately (a wrong group boundary inside a straddling vector would hide in the whole-tensor norm)
+    cg = C // groups
+    e = ((out.float() - ref) ** 2).reshape(nb, rows, groups, cg).sum((1, 3)).sqrt() / (ref ** 2).reshape(nb, rows, groups, cg).sum((1, 3)).sqrt()
+    assert float(e.max()) < 2 * TOL_BF16
+
+
+def test_groupnorm_one_launch_geometry():
+    from asva_amd import _lib
+
+    L = _lib.lib()
+    # the small batches are one launch: ResBlock norms at 4 x 4, per-frame norms up to 16 x 16
+    for nb, rows, c1, c2 in [(2, 192, 1280, 0), (2, 192, 1280, 1280), (24, 256, 640, 0), (24, 64, 1280, 0), (24, 16, 1280, 0)]:
+        assert L.avsd_groupnorm_fused_supported(nb, rows, 32, c1, c2, 0) == 1 and L.avsd_groupnorm_fused_supported(nb, rows, 32, c1, c2, 1) == 1
+    for nb, rows, c1, c2 in [(2, 12288, 320, 0), (2, 3072, 640, 0), (2, 768, 1280, 0), (24, 1024, 320, 0), (12, 16384, 256, 0)]:
+        assert L.avsd_groupnorm_fused_supported(nb, rows, 32, c1, c2, 0) == 0
+    assert L.avsd_groupnorm_fused(None, 320, 320, None, 0, 0, 2, 12288, 32, None, None, 1e-5, 1, None, 320, None) != 0     # refused, not launched
 
 
 @pytest.mark.parametrize("M,C", [(1000, 320), (257, 640), (64, 1280), (33, 80), (16, 2048)])

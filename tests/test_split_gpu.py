@@ -204,10 +204,13 @@ def test_gemm_batched_shared_weight(ops):
     assert rel_l2(ops.from_act(out), ref) < TOL16
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("two", [False, True])
 @pytest.mark.parametrize("actv", [False, True])
-def test_groupnorm(ops, two, actv):
-    nb, rows, c1, c2, G = 2, 768, 320, (320 if two else 0), 32
+@pytest.mark.parametrize("rows,c1", [(768, 320), (192, 1280), (192, 640), (64, 960)])
+def test_groupnorm(ops, two, actv, rows, c1, fused, monkeypatch):
+    monkeypatch.setattr(ops, "_GN_FUSED", fused)
+    nb, c2, G = 2, (320 if two else 0), 32
     x1, v1 = act(ops, nb * rows, c1, seed=1)
     x2, v2 = act(ops, nb * rows, c2, seed=2) if two else (None, None)
     C = c1 + c2

@@ -656,7 +656,11 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm2_kernel(const avsd_g
   else epilogue<FN, FM, (64 * (WM * WN + LW) > 512)>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
 }
 
-// out = epilogue(sum_s ws[s]) for split-K launches: one thread per 4 consecutive columns
+// out = epilogue(sum_s ws[s]) for split-K launches: one thread per 4 consecutive columns.  S = the slice count (2 / 4 / 8:
+// all slab loads of a thread are issued before the first add — the kernel is one memory round trip deep instead of S;
+// 7.4 -> ~4 us per launch, 73 launches per step) or 0 (any count, one load at a time).  The sum runs in slice order either
+// way: bit-identical to the in-launch form above.
+template <int S>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const avsd_gemm_desc p) {
   const int nq = p.N / 4;
   const int64_t total = (int64_t)p.M * nq;
@@ -667,9 +671,38 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const avsd_gemm_desc
     const int m = (int)(i / nq);
     const int n = (int)(i - (int64_t)m * nq) * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < p.split_k; ++s) {
-      const float4 v = *reinterpret_cast<const float4*>(p.splitk_ws + ((int64_t)s * p.M + m) * p.N + n);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    // epilogue operands first: their loads share the round trip of the slab loads
+    float4 pre_bias = make_float4(0.f, 0.f, 0.f, 0.f), pre_vec = pre_bias, pre_r1f = pre_bias, pre_r2f = pre_bias;
+    uint2 pre_r1 = make_uint2(0, 0), pre_r1lo = pre_r1, pre_r2 = pre_r1, pre_r2lo = pre_r1;
+    if (p.bias) pre_bias = *reinterpret_cast<const float4*>(p.bias + n);
+    if (p.rowvec) pre_vec = *reinterpret_cast<const float4*>(p.rowvec + (int64_t)(m / p.rows_per_vec) * p.ldv + n);
+    if (R1) {
+      if (p.flags & AVSD_GEMM_RES1_F32) {
+        pre_r1f = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res1) + (int64_t)m * p.ldr1 + n);
+      } else {
+        pre_r1 = *reinterpret_cast<const uint2*>(R1 + (int64_t)m * p.ldr1 + n);
+        if (x2) pre_r1lo = *reinterpret_cast<const uint2*>(R1 + p.res1_lo + (int64_t)m * p.ldr1 + n);
+      }
+    }
+    if (R2) {
+      if (p.flags & AVSD_GEMM_RES2_F32) {
+        pre_r2f = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res2) + (int64_t)m * p.ldr2 + n);
+      } else {
+        pre_r2 = *reinterpret_cast<const uint2*>(R2 + (int64_t)m * p.ldr2 + n);
+        if (x2) pre_r2lo = *reinterpret_cast<const uint2*>(R2 + p.res2_lo + (int64_t)m * p.ldr2 + n);
+      }
+    }
+    if constexpr (S > 0) {
+      float4 sv[S];
+#pragma unroll
+      for (int s = 0; s < S; ++s) sv[s] = *reinterpret_cast<const float4*>(p.splitk_ws + ((int64_t)s * p.M + m) * p.N + n);
+#pragma unroll
+      for (int s = 0; s < S; ++s) { acc.x += sv[s].x; acc.y += sv[s].y; acc.z += sv[s].z; acc.w += sv[s].w; }
+    } else {
+      for (int s = 0; s < p.split_k; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(p.splitk_ws + ((int64_t)s * p.M + m) * p.N + n);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
     }
     float v[4] = {p.alpha * acc.x, p.alpha * acc.y, p.alpha * acc.z, p.alpha * acc.w};
     if (p.flags & AVSD_GEMM_LNFUSE) {
@@ -683,41 +716,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const avsd_gemm_desc
       v[0] = fmaf(v[0], rstd, -mean * rstd * cs.x); v[1] = fmaf(v[1], rstd, -mean * rstd * cs.y);
       v[2] = fmaf(v[2], rstd, -mean * rstd * cs.z); v[3] = fmaf(v[3], rstd, -mean * rstd * cs.w);
     }
-    if (p.bias) {
-      const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-      v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-    }
-    if (p.rowvec) {
-      const float4 bb = *reinterpret_cast<const float4*>(p.rowvec + (int64_t)(m / p.rows_per_vec) * p.ldv + n);
-      v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-    }
+    if (p.bias) { v[0] += pre_bias.x; v[1] += pre_bias.y; v[2] += pre_bias.z; v[3] += pre_bias.w; }
+    if (p.rowvec) { v[0] += pre_vec.x; v[1] += pre_vec.y; v[2] += pre_vec.z; v[3] += pre_vec.w; }
     if (p.flags & AVSD_GEMM_GELU) {
       for (int i = 0; i < 4; ++i) v[i] = gelu_erf_f(v[i]);
     }
     if (R1) {
       if (p.flags & AVSD_GEMM_RES1_F32) {
-        const float4 rr = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res1) + (int64_t)m * p.ldr1 + n);
-        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+        v[0] += pre_r1f.x; v[1] += pre_r1f.y; v[2] += pre_r1f.z; v[3] += pre_r1f.w;
       } else {
-        const uint2 rr = *reinterpret_cast<const uint2*>(R1 + (int64_t)m * p.ldr1 + n);
-        v[0] += lo2f(rr.x); v[1] += hi2f(rr.x); v[2] += lo2f(rr.y); v[3] += hi2f(rr.y);
-        if (x2) {
-          const uint2 r2 = *reinterpret_cast<const uint2*>(R1 + p.res1_lo + (int64_t)m * p.ldr1 + n);
-          v[0] += lo2f(r2.x); v[1] += hi2f(r2.x); v[2] += lo2f(r2.y); v[3] += hi2f(r2.y);
-        }
+        v[0] += lo2f(pre_r1.x); v[1] += hi2f(pre_r1.x); v[2] += lo2f(pre_r1.y); v[3] += hi2f(pre_r1.y);
+        if (x2) { v[0] += lo2f(pre_r1lo.x); v[1] += hi2f(pre_r1lo.x); v[2] += lo2f(pre_r1lo.y); v[3] += hi2f(pre_r1lo.y); }
       }
     }
     if (R2) {
       if (p.flags & AVSD_GEMM_RES2_F32) {
-        const float4 rr = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res2) + (int64_t)m * p.ldr2 + n);
-        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+        v[0] += pre_r2f.x; v[1] += pre_r2f.y; v[2] += pre_r2f.z; v[3] += pre_r2f.w;
       } else {
-        const uint2 rr = *reinterpret_cast<const uint2*>(R2 + (int64_t)m * p.ldr2 + n);
-        v[0] += lo2f(rr.x); v[1] += hi2f(rr.x); v[2] += lo2f(rr.y); v[3] += hi2f(rr.y);
-        if (x2) {
-          const uint2 r2 = *reinterpret_cast<const uint2*>(R2 + p.res2_lo + (int64_t)m * p.ldr2 + n);
-          v[0] += lo2f(r2.x); v[1] += hi2f(r2.x); v[2] += lo2f(r2.y); v[3] += hi2f(r2.y);
-        }
+        v[0] += lo2f(pre_r2.x); v[1] += hi2f(pre_r2.x); v[2] += lo2f(pre_r2.y); v[3] += hi2f(pre_r2.y);
+        if (x2) { v[0] += lo2f(pre_r2lo.x); v[1] += hi2f(pre_r2lo.x); v[2] += lo2f(pre_r2lo.y); v[3] += hi2f(pre_r2lo.y); }
       }
     }
     if (p.out_master) *reinterpret_cast<float4*>(p.out_master + (int64_t)m * p.ldm + n) = make_float4(v[0], v[1], v[2], v[3]);
@@ -778,7 +795,12 @@ int launch2(const avsd_gemm_desc& d, hipStream_t s) {
     const int64_t total = (int64_t)d.M * (d.N / 4);
     int64_t g = (total + 255) / 256;
     if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, d);
+    switch (nsplit) {
+      case 2: hipLaunchKernelGGL(splitk_reduce_kernel<2>, dim3((unsigned)g), dim3(256), 0, s, d); break;
+      case 4: hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((unsigned)g), dim3(256), 0, s, d); break;
+      case 8: hipLaunchKernelGGL(splitk_reduce_kernel<8>, dim3((unsigned)g), dim3(256), 0, s, d); break;
+      default: hipLaunchKernelGGL(splitk_reduce_kernel<0>, dim3((unsigned)g), dim3(256), 0, s, d); break;
+    }
     AVSD_CHECK_LAUNCH("gemm split-K reduce launch");
   }
   return AVSD_OK;
@@ -897,6 +919,7 @@ int avsd_gemm_dispatch_tmix(const avsd_gemm_desc& d, int tile, hipStream_t s) { 
 int avsd_gemm_dispatch_conv3(const avsd_gemm_desc& d, int tile, hipStream_t s) { return dispatch_tile<AVSD_GEMM_CONV3>(d, tile, s); }
 #endif
 
+int avsd_gemm_dispatch_8phase(const avsd_gemm_desc& d, hipStream_t s);      // gemm8p.hip
 int avsd_gemm_dispatch_x2_plain(const avsd_gemm_desc& d, int tile, hipStream_t s);
 int avsd_gemm_dispatch_x2_tmix(const avsd_gemm_desc& d, int tile, hipStream_t s);
 int avsd_gemm_dispatch_x2_conv3(const avsd_gemm_desc& d, int tile, hipStream_t s);
@@ -954,6 +977,14 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
     AVSD_REQUIRE(d.ho == (hin + 2 - 3) / d.stride + 1 && d.wo == (win + 2 - 3) / d.stride + 1, "gemm/conv3: (ho,wo)=(%d,%d) inconsistent with input (%d,%d) stride %d", d.ho, d.wo, hin, win, d.stride);
   } else {
     AVSD_REQUIRE(false, "gemm: unknown mode %d", d.mode);
+  }
+  if (d.tile == AVSD_GEMM_TILE_8PHASE) {
+    AVSD_REQUIRE(!(d.flags & AVSD_GEMM_X2) && d.split_k <= 1 && !d.A2 &&
+                     (d.mode == AVSD_GEMM_PLAIN || (d.mode == AVSD_GEMM_CONV3 && d.cin % 64 == 0)),
+                 "gemm: the 8-phase tile takes PLAIN single-source or CONV3 (cin %% 64 == 0) operands, no split_k, no split precision");
+    const double a_rows8 = d.mode == AVSD_GEMM_CONV3 ? (double)(d.M / (d.ho * d.wo)) * d.hs * d.ws : (double)d.M;
+    AVSD_REQUIRE(a_rows8 * d.lda * 2.0 < 2147483648.0 && (double)d.N * d.ldw * 2.0 < 2147483648.0, "gemm: the 8-phase tile addresses operands < 2 GiB");
+    return avsd_gemm_dispatch_8phase(d, reinterpret_cast<hipStream_t>(stream));
   }
   if (d.split_k > 1) {
     AVSD_REQUIRE(d.splitk_ws != nullptr, "gemm: split_k needs a workspace");

@@ -109,6 +109,7 @@ SPLITK_CANDIDATES = ((6, 2), (6, 4), (6, 8), (9, 2), (9, 4), (4, 2), (4, 4), (4,
 # split precision (AVSD_GEMM_X2): the tiles whose doubled LDS stage fits (gemm.hip dispatch_tile_x2)
 X2_TILE_CANDIDATES = ((4, 1), (7, 1), (11, 1), (12, 1), (13, 1), (24, 1), (25, 1), (34, 1), (35, 1), (36, 1))
 X2_SPLITK_CANDIDATES = ((34, 2), (34, 4), (35, 2), (35, 4), (36, 2), (36, 4), (4, 2), (4, 4), (4, 8), (7, 2), (7, 4), (7, 8), (11, 2), (11, 4), (24, 2), (24, 4), (24, 8), (25, 2), (25, 4), (25, 8))
+TILE_8PHASE = 37            # 256 x 256 phase-interleaved tile (csrc/gemm8p.hip): selectable, not a tuner candidate (never the fastest here)
 _TILE_CACHE: dict = {}
 _AUTOTUNE = os.environ.get("AVSD_AUTOTUNE", "0") == "1"
 

@@ -84,6 +84,9 @@ enum { AVSD_GEMM_GEGLU = 1, AVSD_GEMM_OUT_F32 = 2, AVSD_GEMM_GELU = 4, AVSD_GEMM
        AVSD_GEMM_LNFUSE = 32, AVSD_GEMM_RES1_F32 = 64, AVSD_GEMM_RES2_F32 = 128, AVSD_GEMM_X2 = 256 };
 #define AVSD_GEMM_MAX_TILE 33
 #define AVSD_GEMM_MAX_TILE_X2 36   /* AVSD_GEMM_X2 also has tiles 34..36 (gemm.hip dispatch_tile_x2) */
+/* 256 x 256 tile with the phase-interleaved main loop (gemm8p.hip): PLAIN single-source or CONV3 with cin % 64 == 0,
+ * no split_k, no AVSD_GEMM_X2; other descriptors are refused with this tile id. */
+#define AVSD_GEMM_TILE_8PHASE 37
 
 typedef struct avsd_gemm_desc {
   const void* A;        /* bf16 */

@@ -80,6 +80,44 @@ def test_gemm_asymmetric_transpose_detect(ops):
         assert torch.equal(out, w.float().T.contiguous())
 
 
+def test_gemm_8phase_tile(ops):
+    """csrc/gemm8p.hip (tile id 37: 256 x 256, phase-interleaved main loop): same sums in the same order as the other LDS-direct
+    tiles -> bit-identical to tile 9 on aligned and ragged shapes, through the plain and the implicit-conv loaders; descriptors it
+    does not take are refused."""
+    from asva_amd.weights import pack_conv3x3
+
+    T8 = ops.TILE_8PHASE
+    for M, N, K in [(384, 320, 320), (1000, 640, 1280), (128, 64, 64), (77, 132, 200), (2048, 1280, 768), (512, 512, 64)]:
+        a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+        bias, res = rndf(N, seed=3), rnd(M, N, seed=4)
+        out = ops.gemm(a, w, bias=bias, res1=res, tile=T8)
+        assert rel_l2(out, a.float() @ w.float().T + bias + res.float()) < TOL_BF16
+        assert torch.equal(out, ops.gemm(a, w, bias=bias, res1=res, tile=9))
+        assert all(torch.equal(ops.gemm(a, w, bias=bias, res1=res, tile=T8), out) for _ in range(5))     # run-to-run
+    eye = torch.eye(128, dtype=torch.bfloat16, device=dev())
+    wasym = (torch.arange(128 * 128, device=dev()).reshape(128, 128) % 251).to(torch.bfloat16)
+    assert torch.equal(ops.gemm(eye, wasym, out_f32=True, tile=T8), wasym.float().T.contiguous())
+    for stride, ups in [(1, 0), (2, 0), (1, 1)]:
+        for n_img, hs, ws, cin, cout in [(3, 16, 16, 64, 128), (2, 8, 12, 320, 320)]:
+            x = rnd(n_img * hs * ws, cin, seed=1)
+            w = rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5)
+            b = rndf(cout, seed=3)
+            out = ops.gemm(x, pack_conv3x3(w, cin), bias=b, mode=ops.CONV3, conv=(n_img, hs, ws, stride, ups), tile=T8)
+            xi = x.float().reshape(n_img, hs, ws, cin).permute(0, 3, 1, 2)
+            if ups:
+                xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
+            ref = F.conv2d(xi, w.float(), b, stride=stride, padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
+            assert rel_l2(out, ref) < TOL_BF16
+            assert torch.equal(out, ops.gemm(x, pack_conv3x3(w, cin), bias=b, mode=ops.CONV3, conv=(n_img, hs, ws, stride, ups), tile=9))
+    a, w = rnd(512, 1280, seed=1), rnd(256, 1280, seed=2)
+    with pytest.raises(RuntimeError, match="8-phase"):
+        ops.gemm(a, w, tile=T8, split_k=2)
+    with pytest.raises(RuntimeError, match="8-phase"):
+        ops.gemm(a[:, :640], w, a2=a[:, 640:], tile=T8)
+    with pytest.raises(RuntimeError, match="8-phase"):
+        ops.gemm(rnd(2 * 64, 8, seed=1), rnd(64, 72, seed=2), mode=ops.CONV3, conv=(2, 8, 8, 1, 0), tile=T8)
+
+
 def test_gemm_strided_views_two_residuals_rowvec_alpha(ops):
     M, N, K = 768, 320, 640
     big = rnd(M, 3 * K, seed=5)

@@ -22,8 +22,11 @@ for M, C in shapes:
     variants = {"plain": lambda t: ops.gemm(h, wp, bias=bp, out=out_p, tile=t),
                 "geglu": lambda t: ops.gemm(h, wp, bias=bp, geglu=True, out=out_g, tile=t),
                 "geglu+ln": lambda t: ops.gemm(h, wp, bias=bp, geglu=True, ln=(stats, cs, 1e-5), out=out_g, tile=t)}
-    print(f"== M={M} N={8 * C} K={C}  ({2.0 * M * 8 * C * C / 1e9:.1f} GFLOP)")
-    for t in (6, 9, 11, 12, 13, 14, 17, 18, 19, 20, 21, 23, 26):
+    a_l = torch.randn(M, C, device=dev).bfloat16(); w_l = torch.randn(8 * C, C, device=dev).bfloat16()
+    torch.matmul(a_l, w_l.t(), out=out_p); torch.cuda.synchronize()
+    t_lib = ops._time_hot(lambda tt, sk: torch.matmul(a_l, w_l.t(), out=out_p), (0, 1), reps=8) * 1e3
+    print(f"== M={M} N={8 * C} K={C}  ({2.0 * M * 8 * C * C / 1e9:.1f} GFLOP)   torch.matmul (all {8 * C} columns, no epilogue): {t_lib:.1f} us")
+    for t in (6, 9, 11, 12, 13, 14, 17, 18, 19, 20, 21, 23, 26, 31, 32):
         row = []
         for name, fn in variants.items():
             try:

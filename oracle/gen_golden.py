@@ -157,7 +157,8 @@ def blocks_hip_legal():
                                             audio_cross_attention_dim=768, norm_num_groups=32)
     fill_module_(m, "blk.tr_320.", round_bf16=True)
     g["tr_320_wide"] = m(x320w, encoder_hidden_states=tx, audio_encoder_hidden_states=au, audio_attention_mask=mk).sample
-    g = {k: (v.to(torch.float16) if torch.is_tensor(v) else v) for k, v in g.items()}     # outputs are O(1): 3e-4 rel rounding
+    # stored in f32 (8.8 MB): the split-precision path is compared at 1e-4, below the 2e-4 rounding of an fp16 fixture
+    g = {k: (v.to(torch.float32).contiguous() if torch.is_tensor(v) else v) for k, v in g.items()}
     torch.save(g, os.path.join(OUT, "unet_blocks_hip.pt"))
     print("HIP-legal block goldens:", [k for k, v in g.items() if torch.is_tensor(v)])
 

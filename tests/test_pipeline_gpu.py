@@ -63,13 +63,14 @@ def test_vae_decode_full_clip_shape_is_finite_and_chunking_is_consistent():
 
 @pytest.mark.parametrize("kind,split", [("pndm", False), ("ddim", False), ("pndm", True), ("ddim", True)])
 def test_pipeline_matches_oracle_pipeline(kind, split):
-    """split = True: the same generation in split precision, held to 1e-3 — a defect of that size in the scheduler glue, the
-    guidance mix, the latent preparation or the decoder cannot hide behind 16-bit rounding there."""
+    """split = True: the same generation in split precision, held to 1.5e-4 (measured 5.4e-5 latents / 3.2e-5 frames after 4 steps;
+    north_star's bar is 1e-3) — a defect of that size in the scheduler glue, the guidance mix, the latent preparation or the decoder
+    cannot hide behind 16-bit rounding there."""
     from asva_amd import precision as P
 
     P.set_split(split)
     try:
-        _pipeline_vs_oracle(kind, 1e-3 if split else 5e-2, 1e-4 if split else 2e-2)
+        _pipeline_vs_oracle(kind, 1.5e-4 if split else 5e-2, 1e-4 if split else 2e-2)
     finally:
         P.set_split(False)
 

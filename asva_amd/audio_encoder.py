@@ -223,9 +223,12 @@ class ImageBindSegmaskAudioEncoder(nn.Module):
     # -- kernel-side weights ------------------------------------------------------------------------------------
     def pack(self):
         """bf16 GEMM operands, f32 biases / norm parameters / tables, on the module's device."""
-        if self._packed is not None:
+        key = (P.ACT, P.SPLIT, str(self.device))
+        if self._packed is not None and self._packed.get("key") == key:
             return self._packed
-        bf = lambda t: t.detach().to(P.ACT).contiguous()      # noqa: E731
+        from .weights import to_act
+
+        bf = lambda t: to_act(t.detach().to(self.device))      # noqa: E731  (split precision: main + rest planes)
         f32 = lambda t: t.detach().to(torch.float32).contiguous()      # noqa: E731
         pre = self.preprocessor
         pk = {
@@ -235,7 +238,7 @@ class ImageBindSegmaskAudioEncoder(nn.Module):
             "pos": f32(pre.pos_embedding_helper.pos_embed.reshape(-1, EMBED)),
             "head_g": f32(self.head[0].weight), "head_b": f32(self.head[0].bias), "head_w": bf(self.head[2].weight),
             "final_g": f32(self.final_layer_norm.weight), "final_b": f32(self.final_layer_norm.bias),
-            "blocks": [],
+            "blocks": [], "key": key,
         }
         for blk in self.trunk.blocks:
             pk["blocks"].append({
@@ -267,7 +270,12 @@ class ImageBindSegmaskAudioEncoder(nn.Module):
         for w in pk["blocks"]:
             n1 = ops.layernorm(h, w["n1_g"], w["n1_b"], 1e-6)
             qkv = ops.gemm(n1, w["in_w"], bias=w["in_b"])                                   # [b*230, 2304] = q | k | v
-            qkv.view(b, L, 3 * EMBED)[:, L - 1, EMBED:] = w["bias_kv"]                      # the appended key/value pair
+            slot = qkv.view(b, L, 3 * EMBED)[:, L - 1, EMBED:]                              # the appended key/value pair
+            slot.copy_(w["bias_kv"].expand_as(slot))
+            if P.SPLIT:
+                from .weights import rest_of
+
+                rest_of(slot).copy_(rest_of(w["bias_kv"]).expand_as(slot))
             att = ops.attention(qkv[:, :EMBED], qkv[:, EMBED:2 * EMBED], qkv[:, 2 * EMBED:], bq=b, lq=L, lk=L, kv_rows=L,
                                 heads=HEADS, q_per_kv=1, frames=1, scale=scale)
             h = ops.gemm(att, w["out_w"], bias=w["out_b"], res1=h)
@@ -284,9 +292,9 @@ class ImageBindSegmaskAudioEncoder(nn.Module):
         b = input_features.shape[0]
         L = 2 + N_FREQ * N_TIME
         h = self.trunk_tokens(input_features)
-        enc = ops.layernorm(h, pk["final_g"], pk["final_b"], 1e-6).view(b, L, EMBED)[:, :L - 1].float()   # (b, 229, 768)
-        cls_rows = ops.layernorm(h.view(b, L, EMBED)[:, 0].contiguous(), pk["head_g"], pk["head_b"], 1e-6)
-        cls_embeds = ops.linear_small_m(cls_rows.float(), pk["head_w"], None)                             # (b, 1024)
+        enc = ops.from_act(ops.layernorm(h, pk["final_g"], pk["final_b"], 1e-6).view(b, L, EMBED)[:, :L - 1]).contiguous()   # (b, 229, 768)
+        cls_rows = ops.layernorm(h.view(b, L, EMBED)[:, 0], pk["head_g"], pk["head_b"], 1e-6)            # row stride L * EMBED
+        cls_embeds = ops.linear_small_m(ops.from_act(cls_rows).contiguous(), pk["head_w"], None)         # (b, 1024)
         masks = audio_segment_mask(self.n_segment).to(enc.device)[None].expand(b, -1, -1).contiguous()
         if not return_dict:
             return cls_embeds, enc, masks

@@ -972,6 +972,11 @@ def patchify(x: torch.Tensor, kh: int, kw: int, stride: int) -> torch.Tensor:
         raise ValueError("patchify: x must be contiguous")
     B, Cc, H, W = x.shape
     ph, pw = (H - kh) // stride + 1, (W - kw) // stride + 1
+    if P.SPLIT:
+        # split precision (once per clip, conditioning side): the gather is a strided device copy, the two planes come from
+        # avsd_split_f32 — same values as the kernel's, with the rest plane kept
+        cols = torch.nn.functional.unfold(x, (kh, kw), stride=stride)                 # (B, C*kh*kw, ph*pw), c-major then kh, kw
+        return to_act(cols.transpose(1, 2).reshape(B * ph * pw, Cc * kh * kw))
     out = torch.empty((B * ph * pw, Cc * kh * kw), dtype=P.ACT, device=x.device)
     check(_lib.lib().avsd_patchify(_p(x), _p(out), B, Cc, H, W, kh, kw, stride, _stream()), "avsd_patchify")
     return out
@@ -985,6 +990,11 @@ def vit_tokens(patches: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, b: i
     n_p, Cc = patches.shape[0] // b, patches.shape[1]
     if not patches.is_contiguous() or pos.shape != (1 + n_p, Cc) or cls.numel() != Cc:
         raise ValueError("vit_tokens: shape mismatch")
+    if P.SPLIT:          # split precision: the same f32 sums, both planes (device ops + avsd_split_f32; once per clip)
+        tok = torch.zeros((b, 1 + n_p + tail_rows, Cc), dtype=F32, device=patches.device)
+        tok[:, 0] = cls.reshape(1, Cc) + pos[0]
+        tok[:, 1:1 + n_p] = from_act(patches).view(b, n_p, Cc) + pos[1:]
+        return to_act(tok.view(-1, Cc))
     out = torch.empty((b * (1 + n_p + tail_rows), Cc), dtype=P.ACT, device=patches.device)
     check(_lib.lib().avsd_vit_tokens(_p(patches), _p(cls), _p(pos), _p(out), b, n_p, Cc, tail_rows, _stream()), "avsd_vit_tokens")
     return out

@@ -91,6 +91,10 @@ def to_act(x):
     return x.to(P.ACT).contiguous()
 
 
+def from_act(t):
+    return t.float()
+
+
 def gemm_batched(a, w, *, alpha=1.0, out_f32=False, bias=None, tile=0, ln=None):
     v = alpha * torch.einsum("bmk,bnk->bmn", a.float(), w.float())
     if ln is not None:

@@ -93,7 +93,21 @@ def _write_tree(root):
     return names
 
 
-def test_generate_videos_for_dataset_from_checkpoint_directories(tmp_path, monkeypatch):
+@pytest.mark.parametrize("split", [False, True])
+def test_generate_videos_for_dataset_from_checkpoint_directories(tmp_path, monkeypatch, split):
+    # split = True: the same run in split precision (asva_amd/precision.py) — checkpoint packing, ImageBind audio trunk, VAE
+    # encode, engine and decoder all in the mode held to north_star's tolerance; the denoised latents then match the oracle
+    # pipeline to 1.5e-4 (measured 3.8e-5) instead of the bf16 path's 5e-2
+    from asva_amd import precision as _P
+
+    _P.set_split(split)
+    try:
+        _driver_run(tmp_path, monkeypatch, 1.5e-4 if split else 5e-2, 0.6 if split else 4.0)
+    finally:
+        _P.set_split(False)
+
+
+def _driver_run(tmp_path, monkeypatch, tol_latents, tol_u8):
     import avgen.pipelines.pipeline_audio_cond_animation as ref_api
     import asva_amd.pipeline as P
     from asva_amd.audio_encoder import ImageBindSegmaskAudioEncoder
@@ -154,13 +168,13 @@ def test_generate_videos_for_dataset_from_checkpoint_directories(tmp_path, monke
                                 STEPS, 4.0, "pndm")
     err = rel_l2(got, want)
     print(f"dataset driver clip 0: denoised latents vs oracle pipeline rel-L2 {err:.3e}")
-    assert err < 5e-2
+    assert err < tol_latents
     frames_or = pipeline_ref.decode({k: v.float().cpu() for k, v in vae.state_dict().items()}, VAE_CFG, want)
     frames_hip = pipe.vae.decode_to_uint8_frames(got)[0].cpu()
     want_u8 = (frames_or[0].permute(0, 2, 3, 1) * 255).to(torch.uint8)
     diff = (frames_hip.int() - want_u8.int()).abs().float().mean().item()
     print(f"dataset driver clip 0: uint8 frames vs oracle, mean abs difference {diff:.2f} / 255")
-    assert diff < 4.0
+    assert diff < tol_u8
     # the driver itself sampled the image latent, so its frames differ from the mean-latent run only through that sample:
     # same shape, same first-frame statistics within the VAE's posterior spread
     drv = written[0][1]

@@ -932,6 +932,23 @@ int avsd_gemm_dispatch_x2_conv3(const avsd_gemm_desc& d, int tile, hipStream_t s
 #endif
 
 #if !defined(AVSD_GEMM_TU) || AVSD_GEMM_TU == 3
+int avsd_gemm_dispatch_conv3r(const avsd_gemm_desc& d, hipStream_t s);      // conv3r.hip
+
+// the reduce / epilogue launch of a split-K GEMM, for kernels outside this file that write the same slabs (conv3r.hip)
+int avsd_gemm_splitk_reduce(const avsd_gemm_desc& d, hipStream_t s) {
+  const int64_t total = (int64_t)d.M * (d.N / 4);
+  int64_t g = (total + 255) / 256;
+  if (g > 2048) g = 2048;
+  switch (d.split_k) {
+    case 2: hipLaunchKernelGGL(splitk_reduce_kernel<2>, dim3((unsigned)g), dim3(256), 0, s, d); break;
+    case 4: hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((unsigned)g), dim3(256), 0, s, d); break;
+    case 8: hipLaunchKernelGGL(splitk_reduce_kernel<8>, dim3((unsigned)g), dim3(256), 0, s, d); break;
+    default: hipLaunchKernelGGL(splitk_reduce_kernel<0>, dim3((unsigned)g), dim3(256), 0, s, d); break;
+  }
+  AVSD_CHECK_LAUNCH("gemm split-K reduce launch");
+  return AVSD_OK;
+}
+
 extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
   AVSD_REQUIRE(dp != nullptr, "gemm: null descriptor");
   avsd_gemm_desc d = *dp;
@@ -977,6 +994,10 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
     AVSD_REQUIRE(d.ho == (hin + 2 - 3) / d.stride + 1 && d.wo == (win + 2 - 3) / d.stride + 1, "gemm/conv3: (ho,wo)=(%d,%d) inconsistent with input (%d,%d) stride %d", d.ho, d.wo, hin, win, d.stride);
   } else {
     AVSD_REQUIRE(false, "gemm: unknown mode %d", d.mode);
+  }
+  if (d.tile >= AVSD_GEMM_TILE_CONV3R_FIRST && d.tile <= AVSD_GEMM_TILE_CONV3R_LAST) {
+    if (d.split_k > 1) AVSD_REQUIRE(d.splitk_ws != nullptr, "gemm: split_k needs a workspace");
+    return avsd_gemm_dispatch_conv3r(d, reinterpret_cast<hipStream_t>(stream));
   }
   if (d.tile == AVSD_GEMM_TILE_8PHASE) {
     AVSD_REQUIRE(!(d.flags & AVSD_GEMM_X2) && d.split_k <= 1 && !d.A2 &&

@@ -109,6 +109,29 @@ SPLITK_CANDIDATES = ((6, 2), (6, 4), (6, 8), (9, 2), (9, 4), (4, 2), (4, 4), (4,
 # split precision (AVSD_GEMM_X2): the tiles whose doubled LDS stage fits (gemm.hip dispatch_tile_x2)
 X2_TILE_CANDIDATES = ((4, 1), (7, 1), (11, 1), (12, 1), (13, 1), (24, 1), (25, 1), (34, 1), (35, 1), (36, 1))
 X2_SPLITK_CANDIDATES = ((34, 2), (34, 4), (35, 2), (35, 4), (36, 2), (36, 4), (4, 2), (4, 4), (4, 8), (7, 2), (7, 4), (7, 8), (11, 2), (11, 4), (24, 2), (24, 4), (24, 8), (25, 2), (25, 4), (25, 8))
+# 3x3 stride-1 convolutions with the input tile resident in LDS (csrc/conv3r.hip): tile ids 40-49, geometry-dependent
+# (avsd_gemm_conv3r_supported); split_k cuts the cin / 64 channel chunks
+CONV3R_TILES = tuple(range(40, 50))
+CONV3R_SPLITS = (1, 2, 4, 5, 8, 10)
+_CONV3R = os.environ.get("AVSD_CONV3R", "1") != "0"
+
+
+def conv3r_candidates(hs: int, ws: int, cin: int, M: int, N: int):
+    """(tile, split_k) pairs of the LDS-resident convolution tiles that fit this image geometry and leave >= 2 chunks per slice"""
+    out = []
+    for t in CONV3R_TILES:
+        bm = _lib.lib().avsd_gemm_conv3r_supported(t, hs, ws, cin)
+        if bm <= 0:
+            continue
+        bn = (128, 128, 160, 160, 128, 128, 256, 320, 256, 64)[t - 40]
+        wgs = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
+        for sk in CONV3R_SPLITS:
+            if sk > 1 and (wgs >= 256 or (cin // 64) // sk < 2 or (cin // 64) % sk != 0):
+                continue
+            out.append((t, sk))
+    return tuple(out)
+
+
 TILE_8PHASE = 37            # 256 x 256 phase-interleaved tile (csrc/gemm8p.hip): selectable, not a tuner candidate (never the fastest here)
 _TILE_CACHE: dict = {}
 _AUTOTUNE = os.environ.get("AVSD_AUTOTUNE", "0") == "1"
@@ -503,8 +526,15 @@ def gemm(
         if not geglu and not two_src_unaligned and ((M + 127) // 128) * ((N + 127) // 128) < 256 and nk >= 16:
             cands = cands + tuple(c for c in (X2_SPLITK_CANDIDATES if P.SPLIT else SPLITK_CANDIDATES) if nk // c[1] >= 4)
         splitk_ok = not geglu and not two_src_unaligned
-        picked = _pick_tile((mode, M, N, K, d.flags, d.stride, d.ups, d.pad, int(master is not None)), _launch, cands,
-                            warm=(a, a2, res1, res2))
+        if (_CONV3R and mode == CONV3 and not P.SPLIT and d.stride == 1 and d.ups == 0 and d.pad == 1 and ln is None):
+            cands = cands + conv3r_candidates(d.hs, d.ws, d.cin, M, N)
+        # 16-bit convolutions are keyed by the image geometry too: which LDS-resident tiles apply depends on (hs, ws)
+        key = (mode, M, N, K, d.flags, d.stride, d.ups, d.pad, int(master is not None))
+        if mode == CONV3 and not P.SPLIT:
+            key = key + (d.hs, d.ws)
+        picked = _pick_tile(key, _launch, cands, warm=(a, a2, res1, res2))
+        if picked is not None and picked[0] in CONV3R_TILES and not (_CONV3R and _lib.lib().avsd_gemm_conv3r_supported(picked[0], d.hs, d.ws, d.cin)):
+            picked = None
         heur = _heuristic_tile_x2 if P.SPLIT else _heuristic_tile
         tile, split_k = picked if picked is not None else heur(M, N, K, geglu, splitk_ok)
     _set(tile, split_k)

@@ -87,6 +87,13 @@ enum { AVSD_GEMM_GEGLU = 1, AVSD_GEMM_OUT_F32 = 2, AVSD_GEMM_GELU = 4, AVSD_GEMM
 /* 256 x 256 tile with the phase-interleaved main loop (gemm8p.hip): PLAIN single-source or CONV3 with cin % 64 == 0,
  * no split_k, no AVSD_GEMM_X2; other descriptors are refused with this tile id. */
 #define AVSD_GEMM_TILE_8PHASE 37
+/* 3x3 stride-1 pad-1 convolution tiles with the input tile resident in LDS (conv3r.hip): K is walked chunk-major (64 input
+ * channels at a time), the BM output rows plus one image row of halo on either side are staged once per chunk and read by all
+ * nine taps; only the weight tile streams per K tile.  CONV3 descriptors with stride 1, ups 0, pad 1, one source,
+ * cin % 64 == 0, image width <= 32 and a tile of whole image rows / whole images (avsd_gemm_conv3r_supported); split_k cuts
+ * the channel chunks (split_k <= cin / 64).  No AVSD_GEMM_X2 / GEGLU / LNFUSE.  Other descriptors are refused with these ids. */
+#define AVSD_GEMM_TILE_CONV3R_FIRST 40
+#define AVSD_GEMM_TILE_CONV3R_LAST 49
 
 typedef struct avsd_gemm_desc {
   const void* A;        /* bf16 */
@@ -146,6 +153,8 @@ typedef struct avsd_gemm_desc {
 } avsd_gemm_desc;
 
 int avsd_gemm_bf16(const avsd_gemm_desc* desc_host, void* stream);
+/* rows per tile of conv3r tile id `tile` if an (hs x ws)-pixel image with cin channels can use it, else 0 */
+int avsd_gemm_conv3r_supported(int tile, int hs, int ws, int cin);
 /* sizeof(avsd_gemm_desc) as compiled: lets an FFI binding verify its mirror of the struct. */
 int avsd_sizeof_gemm_desc(void);
 

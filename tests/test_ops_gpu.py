@@ -198,6 +198,59 @@ def test_gemm_conv3x3(ops, stride, ups, n_img, hs, ws, cin, cout, tile):
     assert rel_l2(out, ref) < TOL_BF16
 
 
+@pytest.mark.parametrize("tile", list(range(40, 50)))
+@pytest.mark.parametrize("n_img,hs,ws,cin,cout,split", [
+    (3, 32, 32, 64, 320, 1),      # bands of image rows, one chunk
+    (2, 32, 32, 320, 192, 1),     # five chunks: the A double buffer turns over; N tail for 128- / 160- / 256-wide tiles
+    (5, 16, 16, 128, 132, 2),     # N not a multiple of 32, one chunk per slice
+    (7, 8, 8, 192, 128, 3),       # whole images per tile, M tail (448 rows), uneven... 3 chunks / 3 slices
+    (6, 4, 4, 320, 192, 2),       # M = 96 < one tile; 5 chunks over 2 slices (3 + 2)
+    (3, 8, 16, 64, 64, 1),        # non-square image
+    (2, 16, 32, 640, 320, 5),     # ten chunks, five slices
+])
+def test_gemm_conv3_resident(ops, n_img, hs, ws, cin, cout, split, tile):
+    """conv3r.hip: the 3x3 stride-1 convolution with the input tile resident in LDS, every tile id the geometry admits, against
+    F.conv2d in f32 and against the tap-major tile 9 (same products, other f32 order); full epilogue; split over channel chunks"""
+    from asva_amd import _lib
+    from asva_amd.weights import pack_conv3x3
+
+    bm = _lib.lib().avsd_gemm_conv3r_supported(tile, hs, ws, cin)
+    M = n_img * hs * ws
+    x = rnd(M, cin, seed=1)
+    w = rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5)
+    b = rndf(cout, seed=3)
+    res = rnd(M, cout, seed=4)
+    wp = pack_conv3x3(w)
+    if bm == 0:
+        with pytest.raises(RuntimeError):
+            ops.gemm(x, wp, bias=b, mode=ops.CONV3, conv=(n_img, hs, ws, 1, 0), tile=tile)
+        return
+    assert bm % ws == 0 and ((hs * ws) % bm == 0 or bm % (hs * ws) == 0)
+    xi = x.float().reshape(n_img, hs, ws, cin).permute(0, 3, 1, 2)
+    ref = F.conv2d(xi, w.float(), b, padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
+    out = ops.gemm(x, wp, bias=b, res1=res, mode=ops.CONV3, conv=(n_img, hs, ws, 1, 0), tile=tile, split_k=split)
+    assert rel_l2(out, ref + res.float()) < TOL_BF16
+    o32 = ops.gemm(x, wp, bias=b, out_f32=True, mode=ops.CONV3, conv=(n_img, hs, ws, 1, 0), tile=tile, split_k=split)
+    assert rel_l2(o32, ref) < TOL_F32
+    assert rel_l2(o32, ops.gemm(x, wp, bias=b, out_f32=True, mode=ops.CONV3, conv=(n_img, hs, ws, 1, 0), tile=9)) < TOL_F32
+    # run to run identical (no atomics, fixed slice order)
+    assert torch.equal(o32, ops.gemm(x, wp, bias=b, out_f32=True, mode=ops.CONV3, conv=(n_img, hs, ws, 1, 0), tile=tile, split_k=split))
+
+
+def test_gemm_conv3_resident_refuses_other_convolutions(ops):
+    from asva_amd.weights import pack_conv3x3
+
+    x = rnd(2 * 16 * 16, 64, seed=1)
+    wp = pack_conv3x3(rnd(64, 64, 3, 3, seed=2))
+    for conv in [(2, 16, 16, 2, 0), (2, 16, 16, 1, 1), (2, 16, 16, 2, 0, 0)]:      # stride 2, upsample fold, asymmetric pad
+        with pytest.raises(RuntimeError):
+            ops.gemm(x, wp, mode=ops.CONV3, conv=conv, tile=40)
+    with pytest.raises(RuntimeError):                                                # cin % 64 != 0
+        ops.gemm(rnd(2 * 16 * 16, 32, seed=1), pack_conv3x3(rnd(64, 32, 3, 3, seed=2)), mode=ops.CONV3, conv=(2, 16, 16, 1, 0), tile=44)
+    with pytest.raises(RuntimeError):                                                # more slices than chunks
+        ops.gemm(x, wp, mode=ops.CONV3, conv=(2, 16, 16, 1, 0), tile=44, split_k=2)
+
+
 @pytest.mark.parametrize("tile,split", [(0, 1), (3, 1), (6, 1), (13, 1), (17, 1), (20, 1), (25, 1), (7, 2), (26, 4)])
 def test_gemm_layernorm_fusion(ops, tile, split):
     """LayerNorm folded into the GEMMs around it (AVSD_GEMM_ROWSTATS / AVSD_GEMM_LNFUSE): the producer's per-32-column

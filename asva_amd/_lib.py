@@ -42,6 +42,7 @@ class GemmDesc(C.Structure):
         ("out_master", c_void_p), ("ldm", C.c_int32), ("reserved0", C.c_int32),
         ("a_lo", C.c_int64), ("a2_lo", C.c_int64), ("w_lo", C.c_int64), ("out_lo", C.c_int64), ("res1_lo", C.c_int64),
         ("res2_lo", C.c_int64),
+        ("gn_table", c_void_p), ("gn_rows_per_batch", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -92,6 +93,7 @@ SIGNATURES = {
     "avsd_sizeof_gemm_desc": (c_int, []),
     "avsd_cross_attention_block": (c_int, [C.POINTER(XAttnDesc), c_void_p]),
     "avsd_gemm_conv3r_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "avsd_gemm_conv3r_gn_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "avsd_cross_attention_block_supported": (c_int, [c_int, c_int, c_int]),
     "avsd_sizeof_xattn_desc": (c_int, []),
     "avsd_ffn_block": (c_int, [C.POINTER(FfnDesc), c_void_p]),
@@ -101,6 +103,7 @@ SIGNATURES = {
     "avsd_groupnorm_stats": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "avsd_groupnorm_apply": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                      c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "avsd_groupnorm_table": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     "avsd_groupnorm_fused_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "avsd_groupnorm_fused": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                      c_int, c_void_p, c_int, c_void_p]),

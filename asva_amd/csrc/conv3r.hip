@@ -52,22 +52,25 @@ __device__ __forceinline__ void wait_ring(int nw, bool a) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int LW>
+template <int BM, int BN, int WM, int WN, int STAGES, int LW, bool GN = false>
 __global__ __launch_bounds__(64 * (WM * WN + LW)) void conv3r_kernel(const avsd_gemm_desc p) {
+  static_assert(!GN || LW > 0, "the GroupNorm prologue runs on the loader waves");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smemr[];
   constexpr int NC = WM * WN;
   constexpr int NWAVES = LW > 0 ? LW : NC;
   constexpr int AR_MAX = BM + HALO_MAX;
   constexpr int PAC = (AR_MAX / 8 + NWAVES - 1) / NWAVES;     // A pieces per loading wave per chunk
+  constexpr int PACT = PAC + (GN ? 1 : 0);                    // + this wave's copy of the chunk's (scale, shift) table
   constexpr int A_BYTES = PAC * NWAVES * 1024;
   constexpr int W_BYTES = BN * 128;
   constexpr int PW = (BN / 8) / NWAVES;
   static_assert(PW * NWAVES * 8 == BN, "weight tile rows must split evenly into 1-KiB pieces per loading wave");
-  static_assert((STAGES - 2) * PW + PAC < 64, "vmcnt is a 6-bit counter");
+  static_assert((STAGES - 2) * PW + PACT < 64, "vmcnt is a 6-bit counter");
   static_assert(STAGES >= 2 && STAGES <= 9, "ring depth");
   constexpr int FM = BM / WM / 32;
   constexpr int FN = BN / WN / 32;
   constexpr int ZERO_OFF = 2 * A_BYTES + STAGES * W_BYTES;    // one zeroed 256-byte line
+  constexpr int TBL_OFF = ZERO_OFF + 256;                     // GN: [2 buffers][NWAVES] x 1 KiB: 64 channels x (scale, shift) f32
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -109,22 +112,23 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void conv3r_kernel(const avsd_
   const h16_t* Wb = reinterpret_cast<const h16_t*>(p.W);
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, 0x7fffffff, 0x00020000);
+  // second source: the input is the channel concat [A (k_split channels) | A2]
+  const bool two = p.A2 != nullptr;
+  const int csplit = two ? (p.k_split >> 6) : nchunks;
+  const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(two ? p.A2 : p.A), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc((void*)(GN ? (const void*)p.gn_table : p.A), 0, 0x7fffffff, 0x00020000);
+  const int gn_b = GN ? m0 / p.gn_rows_per_batch : 0;        // the tile lies inside one normalisation batch (host-checked)
 
   if (tid < 64) *reinterpret_cast<unsigned*>(smemr + ZERO_OFF + tid * 4) = 0u;
   __syncthreads();                            // (before any load is in flight: this waits for vmcnt(0) too)
 
   // ---- loader state -------------------------------------------------------------------------------------------------
   // A piece j of this wave: line L = piece * 4 + lane / 16, slot s = lane % 16 -> staged row 2 L + (s >> 3), chunk (s & 7) ^ (L & 7)
-  int aoff[PAC];           // element offset of the lane's vector at channel 0 of the chunk, or -1
-#pragma unroll
-  for (int j = 0; j < PAC; ++j) {
-    const int L = (wave + j * NWAVES) * 4 + (lane >> 4);
-    const int s = lane & 15;
-    const int row = 2 * L + (s >> 3);
-    const int ch = (s & 7) ^ (L & 7);
-    const int g = m0 - ws + row;
-    aoff[j] = (row < ar && g >= 0 && g < p.M) ? g * p.lda + ch * 8 : -1;
-  }
+  // (row and global row advance by 8 * NWAVES per piece; the chunk slot ch does not depend on j: 4 * NWAVES % 8 == 0)
+  static_assert((4 * NWAVES) % 8 == 0, "piece stride must keep the swizzle phase");
+  const int a_row0 = 2 * (wave * 4 + (lane >> 4)) + ((lane & 15) >> 3);
+  const int a_ch8 = (((lane & 15) & 7) ^ ((wave * 4 + (lane >> 4)) & 7)) * 8;
+  const int a_g0 = m0 - ws + a_row0;
   int wo[PW];
   bool wv[PW];
 #pragma unroll
@@ -137,12 +141,46 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void conv3r_kernel(const avsd_
   }
   auto issue_a = [&](int chunk) {
     unsigned char* ab = smemr + (chunk & 1) * A_BYTES;
+    const bool first = chunk < csplit;
+    const int ld = first ? p.lda : p.lda2;
+    const int coff = a_ch8 + (first ? chunk : chunk - csplit) * 64;
 #pragma unroll
     for (int j = 0; j < PAC; ++j) {
-      const unsigned vo = aoff[j] >= 0 ? (unsigned)(aoff[j] + chunk * 64) * 2u : OOBR;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(ab + (wave + j * NWAVES) * 1024), 16, (int)vo, 0, 0, 0);
+      const int g = a_g0 + j * 8 * NWAVES;
+      const bool ok = a_row0 + j * 8 * NWAVES < ar && g >= 0 && g < p.M;
+      const unsigned vo = ok ? (unsigned)(g * ld + coff) * 2u : OOBR;
+      lds_ptr_t dst = (lds_ptr_t)(ab + (wave + j * NWAVES) * 1024);
+      if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, dst, 16, (int)vo, 0, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, dst, 16, (int)vo, 0, 0, 0);
+    }
+    if constexpr (GN) {      // 64 channels x (scale, shift) = 512 B: lanes 0-31 fetch 16 B each, the rest zero-fill
+      const unsigned vo = lane < 32 ? (unsigned)((gn_b * p.cin + chunk * 64) * 8 + lane * 16) : OOBR;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsT, (lds_ptr_t)(smemr + TBL_OFF + ((chunk & 1) * NWAVES + wave) * 1024), 16, (int)vo, 0, 0, 0);
     }
   };
+  // GN: SiLU(x * scale[c] + shift[c]) in place on one staged 1-KiB piece `pc` of A buffer `buf`.  Same f32 formula and rounding
+  // as gn_apply_kernel.  (Zero-filled and neighbour rows are transformed too: no valid tap reads them.)  A lane's 8 channels
+  // are the same in every piece a wave handles (the piece stride is even, so the swizzle phase L & 7 does not change): the 16
+  // table values are fetched once per chunk (load_tbl) and stay in registers.
+  float gsc[8], gsh[8];
+  auto load_tbl = [&](int buf, int pc0, int tw) {
+    const int L = pc0 * 4 + (lane >> 4);
+    const int ch = (lane & 7) ^ (L & 7);
+    const float4* tb = reinterpret_cast<const float4*>(smemr + TBL_OFF + (buf * NWAVES + tw) * 1024 + ch * 64);
+    const float4 t0 = tb[0], t1 = tb[1], t2 = tb[2], t3 = tb[3];
+    gsc[0] = t0.x; gsc[1] = t0.z; gsc[2] = t1.x; gsc[3] = t1.z; gsc[4] = t2.x; gsc[5] = t2.z; gsc[6] = t3.x; gsc[7] = t3.z;
+    gsh[0] = t0.y; gsh[1] = t0.w; gsh[2] = t1.y; gsh[3] = t1.w; gsh[4] = t2.y; gsh[5] = t2.w; gsh[6] = t3.y; gsh[7] = t3.w;
+  };
+  auto xform_piece = [&](int buf, int pc) {
+    unsigned char* pp = smemr + buf * A_BYTES + pc * 1024 + lane * 16;
+    const uint4 v = *reinterpret_cast<const uint4*>(pp);
+    float f[8];
+    unpack8(v, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = silu_f(fmaf(f[e], gsc[e], gsh[e]));
+    *reinterpret_cast<uint4*>(pp) = pack8(f);
+  };
+  auto lds_drain = [&]() { __builtin_amdgcn_s_waitcnt(0xc07f); asm volatile("" ::: "memory"); };   // lgkmcnt(0)
   int i_t = 0, i_chunk = c0, i_tap = 0;       // next W tile to issue
   auto issue_w = [&]() {
     unsigned char* sb = smemr + 2 * A_BYTES + (i_t % STAGES) * W_BYTES;
@@ -165,7 +203,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void conv3r_kernel(const avsd_
       const int j = kt - d;
       if (j >= 0 && j % 9 == 0 && c0 + j / 9 + 1 < c1) a = true;
     }
-    wait_ring<STAGES - 2, PW, PAC>(nw, a);
+    wait_ring<STAGES - 2, PW, PACT>(nw, a);
   };
 
   if (is_loader && nk > 0) {
@@ -174,13 +212,43 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void conv3r_kernel(const avsd_
     for (int s = 0; s < STAGES - 1; ++s)
       if (s < nk) issue_w();
   }
+  if constexpr (GN) {
+    // first chunk: nothing to hide it behind — every wave of the block transforms a share once the loaders' pieces have landed
+    if (nk > 0) {
+      if (is_loader) wait_vmcnt<(STAGES - 1) * PW>();          // nk >= 9 > STAGES - 1: all prologue W tiles were issued
+      __builtin_amdgcn_s_barrier();
+      static_assert((NC + LW) % 2 == 0, "piece stride must keep the swizzle phase");
+      load_tbl(c0 & 1, wave_all, 0);
+      for (int pc = wave_all; pc < PAC * NWAVES; pc += NC + LW) xform_piece(c0 & 1, pc);
+      lds_drain();
+    }
+  }
   if (LW > 0 && is_loader) {
+    // GN: the pieces of chunk c + 1 (issued at tap 0, landed by the time the W tile of tap STAGES - 1 has) are transformed by the
+    // wave that fetched them, PPI per iteration from tap STAGES - 1 on: hidden beside the MFMA waves' matrix work
+    constexpr int TS = STAGES - 1;
+    constexpr int PPI = (PAC + (9 - TS) - 1) / (9 - TS);
     int tap = 0, chunk = c0;
     for (int kt = 0; kt < nk; ++kt) {
       wait_tile(kt);
       __builtin_amdgcn_s_barrier();
       if (tap == 0 && chunk + 1 < c1) issue_a(chunk + 1);
       if (kt + STAGES - 1 < nk) issue_w();
+      if constexpr (GN) {
+        if (tap >= TS && chunk + 1 < c1) {
+          // above the MFMA waves' s_setprio(1): at equal or lower priority this wave's VALU work waits for issue slots behind
+          // two waves that issue back to back, and its late arrival at the barrier stalls them all
+          __builtin_amdgcn_s_setprio(3);
+          if (tap == TS) load_tbl((chunk + 1) & 1, wave, wave);
+#pragma unroll
+          for (int u = 0; u < PPI; ++u) {
+            const int j = (tap - TS) * PPI + u;
+            if (j < PAC) xform_piece((chunk + 1) & 1, wave + j * NWAVES);
+          }
+          lds_drain();
+          __builtin_amdgcn_s_setprio(0);
+        }
+      }
       if (++tap == 9) { tap = 0; ++chunk; }
     }
     return;
@@ -294,17 +362,18 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void conv3r_kernel(const avsd_
   epilogue<FN, FM, (64 * (WM * WN + LW) > 512)>(p, acc, m0 + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, 0, pre_ln, false);
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int LW>
+template <int BM, int BN, int WM, int WN, int STAGES, int LW, bool GN = false>
 int launch_r(const avsd_gemm_desc& d, hipStream_t s) {
   constexpr int NWAVES = LW > 0 ? LW : WM * WN;
   constexpr int PAC = ((BM + HALO_MAX) / 8 + NWAVES - 1) / NWAVES;
-  constexpr size_t lds = (size_t)2 * PAC * NWAVES * 1024 + (size_t)STAGES * BN * 128 + 256;
+  constexpr size_t lds = (size_t)2 * PAC * NWAVES * 1024 + (size_t)STAGES * BN * 128 + 256 + (GN ? 2 * NWAVES * 1024 : 0);
+  if (GN) AVSD_REQUIRE(d.gn_rows_per_batch % BM == 0, "gemm/conv3r: a normalisation batch (%d rows) must be whole %d-row tiles", d.gn_rows_per_batch, BM);
   static_assert(lds <= 160 * 1024, "tile does not fit the 160 KB of LDS");
   AVSD_REQUIRE(BM % d.ws == 0 && ((d.hs * d.ws) % BM == 0 || BM % (d.hs * d.ws) == 0),
                "gemm/conv3r: a %d-row tile must be whole image rows of one image or whole images (image %d x %d)", BM, d.hs, d.ws);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3r_kernel<BM, BN, WM, WN, STAGES, LW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3r_kernel<BM, BN, WM, WN, STAGES, LW, GN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       avsd_set_error("conv3r: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
@@ -315,7 +384,7 @@ int launch_r(const avsd_gemm_desc& d, hipStream_t s) {
   const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
   const int nsplit = d.split_k > 1 ? d.split_k : 1;
   dim3 grid((unsigned)(ntm * ntn), (unsigned)nsplit, 1);
-  hipLaunchKernelGGL((conv3r_kernel<BM, BN, WM, WN, STAGES, LW>), grid, dim3(64 * (WM * WN + LW)), lds, s, d);
+  hipLaunchKernelGGL((conv3r_kernel<BM, BN, WM, WN, STAGES, LW, GN>), grid, dim3(64 * (WM * WN + LW)), lds, s, d);
   AVSD_CHECK_LAUNCH("conv3r launch");
   if (nsplit > 1) return avsd_gemm_splitk_reduce(d, s);
   return AVSD_OK;
@@ -325,9 +394,23 @@ int launch_r(const avsd_gemm_desc& d, hipStream_t s) {
 
 // tile ids AVSD_GEMM_TILE_CONV3R_FIRST + k (include/avsd.h)
 int avsd_gemm_dispatch_conv3r(const avsd_gemm_desc& d, hipStream_t s) {
-  AVSD_REQUIRE(d.mode == AVSD_GEMM_CONV3 && d.stride == 1 && d.ups == 0 && d.pad == 1 && !d.A2 && d.batch == 1 &&
+  AVSD_REQUIRE(d.mode == AVSD_GEMM_CONV3 && d.stride == 1 && d.ups == 0 && d.pad == 1 && d.batch == 1 &&
                    !(d.flags & (AVSD_GEMM_X2 | AVSD_GEMM_GEGLU | AVSD_GEMM_LNFUSE)) && !d.splitk_cnt,
-               "gemm/conv3r: stride-1 pad-1 single-source 3x3 convolutions only (no upsample fold, split precision, GEGLU, LayerNorm fold, batching)");
+               "gemm/conv3r: stride-1 pad-1 3x3 convolutions only (no upsample fold, split precision, GEGLU, LayerNorm fold, batching)");
+  if (d.A2) AVSD_REQUIRE(d.k_split > 0 && d.k_split % 64 == 0 && d.k_split < d.cin && d.lda2 % 8 == 0 && (double)d.M * d.lda2 * 2.0 < 2147483648.0,
+                         "gemm/conv3r: a two-source input needs k_split %% 64 == 0 inside cin (got %d of %d)", d.k_split, d.cin);
+  if (d.flags & AVSD_GEMM_GNFUSE) {
+    AVSD_REQUIRE(d.gn_table && d.gn_rows_per_batch > 0 && d.M % d.gn_rows_per_batch == 0,
+                 "gemm/conv3r: GNFUSE needs gn_table and gn_rows_per_batch dividing M (%d)", d.M);
+    AVSD_REQUIRE((double)(d.M / d.gn_rows_per_batch) * d.cin * 8.0 < 2147483648.0, "gemm/conv3r: (scale, shift) table too large");
+    switch (d.tile - AVSD_GEMM_TILE_CONV3R_FIRST) {
+      case 0: return launch_r<256, 128, 4, 2, 3, 4, true>(d, s);
+      case 2: return launch_r<256, 160, 4, 1, 3, 4, true>(d, s);
+      case 3: return launch_r<256, 160, 8, 1, 3, 4, true>(d, s);
+      case 4: return launch_r<128, 128, 2, 2, 4, 2, true>(d, s);
+      default: AVSD_REQUIRE(false, "gemm/conv3r: tile %d has no loader waves for the GroupNorm prologue (40, 42, 43, 44 do)", d.tile);
+    }
+  }
   AVSD_REQUIRE(d.cin % 64 == 0 && 2 * d.ws <= HALO_MAX, "gemm/conv3r: cin %% 64 == 0 and image width <= %d (got cin %d, width %d)", HALO_MAX / 2, d.cin, d.ws);
   AVSD_REQUIRE(d.split_k <= 1 || d.split_k <= d.cin / 64, "gemm/conv3r: split_k (%d) exceeds the %d channel chunks", d.split_k, d.cin / 64);
   AVSD_REQUIRE((double)d.M * d.lda * 2.0 < 2147483648.0 && (double)d.N * d.ldw * 2.0 < 2147483648.0, "gemm/conv3r: operands must be < 2 GiB");
@@ -346,6 +429,8 @@ int avsd_gemm_dispatch_conv3r(const avsd_gemm_desc& d, hipStream_t s) {
   }
 }
 
+// rows per tile of a GNFUSE-capable tile (loader waves), else 0
+extern "C" int avsd_gemm_conv3r_gn_supported(int tile, int hs, int ws, int cin, int c1, int rows_per_batch);
 // largest BM the image geometry admits for tile id `tile` (0 = unsupported): lets a host enumerate candidates
 extern "C" int avsd_gemm_conv3r_supported(int tile, int hs, int ws, int cin) {
   static const int bm[10] = {256, 256, 256, 256, 128, 128, 128, 128, 256, 128};
@@ -353,4 +438,13 @@ extern "C" int avsd_gemm_conv3r_supported(int tile, int hs, int ws, int cin) {
   if (k < 0 || k >= 10 || cin % 64 != 0 || ws <= 0 || hs <= 0 || 2 * ws > HALO_MAX) return 0;
   const int b = bm[k];
   return (b % ws == 0 && ((hs * ws) % b == 0 || b % (hs * ws) == 0)) ? b : 0;
+}
+
+extern "C" int avsd_gemm_conv3r_gn_supported(int tile, int hs, int ws, int cin, int c1, int rows_per_batch) {
+  const int k = tile - AVSD_GEMM_TILE_CONV3R_FIRST;
+  if (!(k == 0 || k == 2 || k == 3 || k == 4)) return 0;
+  const int b = avsd_gemm_conv3r_supported(tile, hs, ws, cin);
+  if (b == 0 || rows_per_batch <= 0 || rows_per_batch % b != 0) return 0;
+  if (c1 != cin && (c1 <= 0 || c1 >= cin || c1 % 64 != 0)) return 0;
+  return b;
 }

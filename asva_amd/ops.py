@@ -17,7 +17,7 @@ from . import precision as P
 from ._lib import FfnDesc, GemmDesc, XAttnDesc, check
 
 PLAIN, TMIX, CONV3 = 0, 1, 2
-GEGLU, OUT_F32, GELU, XCD_N, ROWSTATS, LNFUSE, RES1_F32, RES2_F32, X2 = 1, 2, 4, 8, 16, 32, 64, 128, 256
+GEGLU, OUT_F32, GELU, XCD_N, ROWSTATS, LNFUSE, RES1_F32, RES2_F32, X2, GNFUSE = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 _XCD_MODE = os.environ.get("AVSD_XCD_MODE", "auto")     # auto | m | n  (which operand each XCD's L2 fetches once)
 F32 = torch.float32      # (16-bit storage dtype: P.ACT, asva_amd/precision.py)
 
@@ -116,14 +116,21 @@ CONV3R_SPLITS = (1, 2, 4, 5, 8, 10)
 _CONV3R = os.environ.get("AVSD_CONV3R", "1") != "0"
 
 
-def conv3r_candidates(hs: int, ws: int, cin: int, M: int, N: int):
-    """(tile, split_k) pairs of the LDS-resident convolution tiles that fit this image geometry and leave >= 2 chunks per slice"""
+_CONV3R_BN = (128, 128, 160, 160, 128, 128, 256, 320, 256, 64)
+
+
+def conv3r_candidates(hs: int, ws: int, cin: int, M: int, N: int, gn: Optional[tuple] = None):
+    """(tile, split_k) pairs of the LDS-resident convolution tiles that fit this image geometry and leave >= 2 chunks per slice;
+    gn = (channels of the first source, rows per normalisation batch): only the tiles that carry the GroupNorm prologue"""
     out = []
     for t in CONV3R_TILES:
-        bm = _lib.lib().avsd_gemm_conv3r_supported(t, hs, ws, cin)
+        if gn is not None:
+            bm = _lib.lib().avsd_gemm_conv3r_gn_supported(t, hs, ws, cin, gn[0], gn[1])
+        else:
+            bm = _lib.lib().avsd_gemm_conv3r_supported(t, hs, ws, cin)
         if bm <= 0:
             continue
-        bn = (128, 128, 160, 160, 128, 128, 256, 320, 256, 64)[t - 40]
+        bn = _CONV3R_BN[t - 40]
         wgs = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
         for sk in CONV3R_SPLITS:
             if sk > 1 and (wgs >= 256 or (cin // 64) // sk < 2 or (cin // 64) % sk != 0):
@@ -132,6 +139,31 @@ def conv3r_candidates(hs: int, ws: int, cin: int, M: int, N: int):
     return tuple(out)
 
 
+def conv3r_gn_supported(hs: int, ws: int, cin: int, c1: int, rows_per_batch: int) -> bool:
+    """can a 3x3 stride-1 convolution over (hs x ws)-pixel images take GroupNorm + SiLU as its prologue (gemm(..., gn=))?"""
+    # measured (tools/gn_prologue_bench.py, profiles/r3_gn_prologue_probe.txt): the prologue costs the convolution 6-16 us (the first
+    # chunk is transformed before any matrix work; later chunks take VALU issue slots beside the MFMA waves) and saves the apply
+    # pass — 10-17 us at 32 x 32, 3-13 us at 16 x 16, < 3 us at 8 x 8: it pays on images of >= _CONV3R_GN_MINPIX pixels only
+    if hs * ws < _CONV3R_GN_MINPIX:
+        return False
+    return _CONV3R_GN and not P.SPLIT and any(_lib.lib().avsd_gemm_conv3r_gn_supported(t, hs, ws, cin, c1, rows_per_batch) > 0 for t in CONV3R_TILES)
+
+
+def _heuristic_conv3r(cands, M: int, N: int):
+    """static pick among the admissible resident tiles when the table has no entry: the candidate that wastes the fewest
+    padded columns, then the one closest to one workgroup per CU"""
+    def cost(c):
+        t, sk = c
+        bn = _CONV3R_BN[t - 40]
+        bm = 256 if t in (40, 41, 42, 43, 48) else 128
+        wg = ((M + bm - 1) // bm) * ((N + bn - 1) // bn) * sk
+        pad = ((N + bn - 1) // bn) * bn / N
+        return (round(pad, 2), abs(wg - 256) if wg < 256 else (wg - 256) // 4, sk)
+    return min(cands, key=cost)
+
+
+_CONV3R_GN = os.environ.get("AVSD_CONV3R_GN", "0") != "0"      # measured neutral at 32 x 32, -1 % below: off (profiles/r3_gn_prologue_probe.txt)
+_CONV3R_GN_MINPIX = int(os.environ.get("AVSD_CONV3R_GN_MINPIX", "1024"))
 TILE_8PHASE = 37            # 256 x 256 phase-interleaved tile (csrc/gemm8p.hip): selectable, not a tuner candidate (never the fastest here)
 _TILE_CACHE: dict = {}
 _AUTOTUNE = os.environ.get("AVSD_AUTOTUNE", "0") == "1"
@@ -399,6 +431,8 @@ def gemm(
     m: Optional[int] = None,
     tile: int = 0,
     split_k: int = 1,
+    gn: Optional[tuple] = None,        # CONV3 only: (table [batches, cin, 2] f32 of groupnorm_table, rows_per_batch): the input is
+                                       # the UN-normalised tensor (channel concat [a | a2]); SiLU(GroupNorm(.)) is applied while staging
 ) -> torch.Tensor:
     """out = epilogue(alpha * A' . W^T); see avsd_gemm_bf16 in include/avsd.h."""
     _req(a, P.ACT, "a")
@@ -437,6 +471,10 @@ def gemm(
         n_img, hs, ws, stride, ups = conv[:5]
         pad = conv[5] if len(conv) > 5 else 1
         cin = a.shape[1]
+        if a2 is not None:              # two-source input: only the LDS-resident tiles read it (conv3r.hip)
+            _req(a2, P.ACT, "a2")
+            d.A2, d.lda2, d.k_split = _p(a2), _ld(a2), cin
+            cin += a2.shape[1]
         hin, win = hs << ups, ws << ups
         ho, wo = (hin + 2 - 3) // stride + 1, (win + 2 - 3) // stride + 1
         M = n_img * ho * wo
@@ -493,6 +531,15 @@ def gemm(
     if _XCD_MODE == "n" or (_XCD_MODE == "auto" and N * K > a_bytes):
         d.flags |= XCD_N
     d.batch = 1
+    if gn is not None:
+        if mode != CONV3 or P.SPLIT or ln is not None:
+            raise ValueError("gemm: gn= is the GroupNorm prologue of the 16-bit 3x3 convolution")
+        gtab, grows = gn
+        _req(gtab, F32, "gn table")
+        if not gtab.is_contiguous() or gtab.shape != (M // grows, d.cin, 2):
+            raise ValueError(f"gemm: gn table must be contiguous f32 [{M // grows}, {d.cin}, 2], got {tuple(gtab.shape)}")
+        d.gn_table, d.gn_rows_per_batch = _p(gtab), grows
+        d.flags |= GNFUSE
     ws = None
     if P.SPLIT:
         if master is not None:
@@ -526,16 +573,22 @@ def gemm(
         if not geglu and not two_src_unaligned and ((M + 127) // 128) * ((N + 127) // 128) < 256 and nk >= 16:
             cands = cands + tuple(c for c in (X2_SPLITK_CANDIDATES if P.SPLIT else SPLITK_CANDIDATES) if nk // c[1] >= 4)
         splitk_ok = not geglu and not two_src_unaligned
-        if (_CONV3R and mode == CONV3 and not P.SPLIT and d.stride == 1 and d.ups == 0 and d.pad == 1 and ln is None):
+        if gn is not None or (mode == CONV3 and a2 is not None):
+            cands = conv3r_candidates(d.hs, d.ws, d.cin, M, N, gn=(d.k_split if a2 is not None else d.cin, d.gn_rows_per_batch) if gn is not None else None)
+            if not cands:
+                raise ValueError("gemm: no LDS-resident convolution tile takes this geometry (conv3r_gn_supported tells)")
+        elif (_CONV3R and mode == CONV3 and not P.SPLIT and d.stride == 1 and d.ups == 0 and d.pad == 1 and ln is None):
             cands = cands + conv3r_candidates(d.hs, d.ws, d.cin, M, N)
         # 16-bit convolutions are keyed by the image geometry too: which LDS-resident tiles apply depends on (hs, ws)
         key = (mode, M, N, K, d.flags, d.stride, d.ups, d.pad, int(master is not None))
         if mode == CONV3 and not P.SPLIT:
             key = key + (d.hs, d.ws)
         picked = _pick_tile(key, _launch, cands, warm=(a, a2, res1, res2))
-        if picked is not None and picked[0] in CONV3R_TILES and not (_CONV3R and _lib.lib().avsd_gemm_conv3r_supported(picked[0], d.hs, d.ws, d.cin)):
+        if picked is not None and picked[0] in CONV3R_TILES and not ((_CONV3R or gn is not None or a2 is not None) and _lib.lib().avsd_gemm_conv3r_supported(picked[0], d.hs, d.ws, d.cin)):
             picked = None
         heur = _heuristic_tile_x2 if P.SPLIT else _heuristic_tile
+        if picked is None and (gn is not None or (mode == CONV3 and a2 is not None)):
+            picked = _heuristic_conv3r(cands, M, N)
         tile, split_k = picked if picked is not None else heur(M, N, K, geglu, splitk_ok)
     _set(tile, split_k)
     ev = _TIMER.start() if _TIMER is not None else None
@@ -672,6 +725,35 @@ def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], nb: int, rows_per_ba
     if ev is not None:
         _TIMER.stop(ev, "groupnorm", 0.0, 2.0 * _nbytes(x1, x2) + _nbytes(out))
     return out
+
+
+def groupnorm_table(x1: torch.Tensor, x2: Optional[torch.Tensor], nb: int, rows_per_batch: int, groups: int,
+                    gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
+    """(scale, shift) per (batch, channel) of GroupNorm over the channel concat [x1 | x2]: f32 [nb, C, 2] — the statistics pass
+    and the fold of groupnorm(), without the apply pass; the consumer is gemm(..., mode=CONV3, gn=(table, rows_per_batch))."""
+    _req(x1, P.ACT, "x1")
+    c1 = x1.shape[1]
+    c2 = 0
+    if x2 is not None:
+        _req(x2, P.ACT, "x2")
+        c2 = x2.shape[1]
+    _req(gamma, F32, "gamma")
+    _req(beta, F32, "beta")
+    if P.SPLIT:
+        raise ValueError("groupnorm_table: 16-bit storage only")
+    L = _lib.lib()
+    s = _stream()
+    nchunks = L.avsd_groupnorm_nchunks(nb, rows_per_batch, c1 + c2)
+    partial = torch.empty((L.avsd_groupnorm_scratch_floats(nb, nchunks, groups, c1 + c2),), dtype=F32, device=x1.device)
+    table = torch.empty((nb, c1 + c2, 2), dtype=F32, device=x1.device)
+    ev = _TIMER.start() if _TIMER is not None else None
+    check(L.avsd_groupnorm_stats(_p(x1), _ld(x1), c1, _p(x2), _ld(x2) if x2 is not None else 0, c2, nb, rows_per_batch,
+                                 groups, _p(partial), nchunks, s), "avsd_groupnorm_stats")
+    check(L.avsd_groupnorm_table(_p(partial), nchunks, nb, rows_per_batch, groups, c1 + c2, _p(gamma), _p(beta), float(eps), _p(table), s),
+          "avsd_groupnorm_table")
+    if ev is not None:
+        _TIMER.stop(ev, "groupnorm", 0.0, _nbytes(x1, x2))
+    return table
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,

@@ -1016,8 +1016,13 @@ class AudioUNet3DConditionModel(nn.Module):
             if blk.up is not None:
                 h = _ffconv(st, h, blk.up, hw, ups=1)
                 hw = (hw[0] * 2, hw[1] * 2)
-        a = ops.groupnorm(h.lo, None, B, Fr * hw[0] * hw[1], st.groups, pk.norm_out.g, pk.norm_out.b, st.eps, True)
-        o = _ffconv(st, _Act(a), pk.conv_out, hw, out_f32=True)
+        rows_b = Fr * hw[0] * hw[1]
+        if ops.conv3r_gn_supported(hw[0], hw[1], h.lo.shape[1], h.lo.shape[1], rows_b):      # conv_norm_out as conv_out's prologue
+            tb = ops.groupnorm_table(h.lo, None, B, rows_b, st.groups, pk.norm_out.g, pk.norm_out.b, st.eps)
+            o = _ffconv(st, h, pk.conv_out, hw, out_f32=True, gn=(tb, rows_b))
+        else:
+            a = ops.groupnorm(h.lo, None, B, rows_b, st.groups, pk.norm_out.g, pk.norm_out.b, st.eps, True)
+            o = _ffconv(st, _Act(a), pk.conv_out, hw, out_f32=True)
         return ops.rows_to_ncfhw(o.lo, B, self.config.out_channels, Fr, H, W)
 
 
@@ -1028,7 +1033,8 @@ def _master(st, like: torch.Tensor, cols: int):
 # FFInflatedConv3d (utils.py:34-57): conv GEMM, then the temporal-mix GEMM whose epilogue also adds the
 # time embedding (resnet :173) and the residual / shortcut (resnet :189)
 def _ffconv(st, x: _Act, p, hw, stride=1, ups=0, temb=None, res: Optional[_Act] = None, out_f32=False,
-            x2: Optional[_Act] = None, master=True) -> _Act:
+            x2: Optional[_Act] = None, master=True, gn=None) -> _Act:
+    """gn = (table, rows_per_batch): x (and x2) are un-normalised, the 3x3 convolution applies SiLU(GroupNorm(.)) while staging"""
     n_img = st.B * st.F
     if p.k == 3:
         ho = ((hw[0] << ups) + 2 - 3) // stride + 1
@@ -1041,7 +1047,8 @@ def _ffconv(st, x: _Act, p, hw, stride=1, ups=0, temb=None, res: Optional[_Act] 
     # un-rounded copy for that addition; the 16-bit copy feeds the temporal-mix product
     ym = torch.empty((rows, p.cout), dtype=torch.float32, device=x.lo.device) if (st.f32_stream and _F32_CONV_Y) else None
     if p.k == 3:
-        y = ops.gemm(x.lo, p.w, bias=p.b, mode=ops.CONV3, conv=(n_img, hw[0], hw[1], stride, ups), master=ym)
+        y = ops.gemm(x.lo, p.w, a2=None if (x2 is None or gn is None) else x2.lo, bias=p.b, mode=ops.CONV3,
+                     conv=(n_img, hw[0], hw[1], stride, ups), master=ym, gn=gn)
     else:
         y = ops.gemm(x.lo, p.w, a2=None if x2 is None else x2.lo, bias=p.b, master=ym)
     m = _master(st, y, p.cout) if (master and not out_f32) else None
@@ -1061,9 +1068,22 @@ def _resblock(st, x: _Act, skip: Optional[_Act], p, hw) -> _Act:
     else:
         assert skip is None
         s = x
-    a = ops.groupnorm(x.lo, None if skip is None else skip.lo, st.B, rows_b, st.groups, p.norm1.g, p.norm1.b, st.eps, True)
     tv = st.temb[:, p.temb_off:p.temb_off + p.cout]
-    h = _ffconv(st, _Act(a), p.conv1, hw, temb=tv, master=False)         # feeds GroupNorm only
+    # GroupNorm + SiLU as the prologue of the 3x3 convolution where a resident tile with loader waves takes the geometry
+    # (ops.conv3r_gn_supported: the 32 x 32, 16 x 16 and 8 x 8 levels): statistics + (scale, shift) table, no apply pass, the
+    # normalised tensor (and the skip concat) never written.  Elsewhere (4 x 4: one-launch GroupNorm) the norm stays a kernel.
+    c1 = x.lo.shape[1]
+    cin1 = c1 + (0 if skip is None else skip.lo.shape[1])
+    if ops.conv3r_gn_supported(hw[0], hw[1], cin1, c1, rows_b):
+        t1 = ops.groupnorm_table(x.lo, None if skip is None else skip.lo, st.B, rows_b, st.groups, p.norm1.g, p.norm1.b, st.eps)
+        h = _ffconv(st, x, p.conv1, hw, temb=tv, master=False, x2=skip, gn=(t1, rows_b))
+    else:
+        a = ops.groupnorm(x.lo, None if skip is None else skip.lo, st.B, rows_b, st.groups, p.norm1.g, p.norm1.b, st.eps, True)
+        h = _ffconv(st, _Act(a), p.conv1, hw, temb=tv, master=False)         # feeds GroupNorm only
+    if ops.conv3r_gn_supported(hw[0], hw[1], p.cout, p.cout, rows_b):
+        t2 = ops.groupnorm_table(h.lo, None, st.B, rows_b, st.groups, p.norm2.g, p.norm2.b, st.eps)
+        st.side.join()
+        return _ffconv(st, h, p.conv2, hw, res=s, gn=(t2, rows_b))
     a2 = ops.groupnorm(h.lo, None, st.B, rows_b, st.groups, p.norm2.g, p.norm2.b, st.eps, True)
     st.side.join()
     return _ffconv(st, _Act(a2), p.conv2, hw, res=s)

@@ -33,7 +33,7 @@ extern "C" {
 #define AVSD_ELAUNCH (-2)  /* hipLaunch / runtime error                          */
 #define AVSD_ENODEV (-3)   /* no gfx950 device / wrong architecture              */
 
-#define AVSD_ABI_VERSION 5
+#define AVSD_ABI_VERSION 6
 
 /* ---- library ------------------------------------------------------------------------ */
 int avsd_abi_version(void);
@@ -81,7 +81,7 @@ int avsd_device_info(char* name_host, int len, int* num_cu_host);
  */
 enum { AVSD_GEMM_PLAIN = 0, AVSD_GEMM_TMIX = 1, AVSD_GEMM_CONV3 = 2 };
 enum { AVSD_GEMM_GEGLU = 1, AVSD_GEMM_OUT_F32 = 2, AVSD_GEMM_GELU = 4, AVSD_GEMM_XCD_N = 8, AVSD_GEMM_ROWSTATS = 16,
-       AVSD_GEMM_LNFUSE = 32, AVSD_GEMM_RES1_F32 = 64, AVSD_GEMM_RES2_F32 = 128, AVSD_GEMM_X2 = 256 };
+       AVSD_GEMM_LNFUSE = 32, AVSD_GEMM_RES1_F32 = 64, AVSD_GEMM_RES2_F32 = 128, AVSD_GEMM_X2 = 256, AVSD_GEMM_GNFUSE = 512 };
 #define AVSD_GEMM_MAX_TILE 33
 #define AVSD_GEMM_MAX_TILE_X2 36   /* AVSD_GEMM_X2 also has tiles 34..36 (gemm.hip dispatch_tile_x2) */
 /* 256 x 256 tile with the phase-interleaved main loop (gemm8p.hip): PLAIN single-source or CONV3 with cin % 64 == 0,
@@ -150,11 +150,23 @@ typedef struct avsd_gemm_desc {
    * W.A + Wr.A + W.Ar (three MFMA passes into one f32 accumulator); 16-bit residuals are read as main + rest and the output
    * is written as main = round16(v), rest = round16(v - main).  LDS-direct tiles 4, 7, 11, 12, 13, 24, 25, 34, 35, 36 only. */
   int64_t a_lo, a2_lo, w_lo, out_lo, res1_lo, res2_lo;
+  /* AVSD_GEMM_GNFUSE (CONV3 with an LDS-resident tile that has loader waves, conv3r.hip): A (and A2: the input is the channel
+   * concat [A (k_split channels) | A2 (cin - k_split channels)], k_split % 64 == 0) is the UN-normalised tensor; the loader
+   * waves apply SiLU(x * scale[c] + shift[c]) to each staged chunk in LDS (rounded to 16 bits, exactly what
+   * avsd_groupnorm_apply would have written) before the nine taps read it — GroupNorm + SiLU + conv of
+   * ff_spatio_temp_resnet_3d.py:164-166,178-181 without the normalised tensor ever reaching memory.  gn_table: f32
+   * [batches][cin][2] of avsd_groupnorm_table; a batch is gn_rows_per_batch consecutive rows of A, a multiple of the tile rows. */
+  const float* gn_table;
+  int32_t gn_rows_per_batch;
+  int32_t reserved1;
 } avsd_gemm_desc;
 
 int avsd_gemm_bf16(const avsd_gemm_desc* desc_host, void* stream);
 /* rows per tile of conv3r tile id `tile` if an (hs x ws)-pixel image with cin channels can use it, else 0 */
 int avsd_gemm_conv3r_supported(int tile, int hs, int ws, int cin);
+/* the same for a descriptor with AVSD_GEMM_GNFUSE: only tiles with loader waves (40, 42, 43, 44) qualify, a normalisation batch
+ * must be whole tiles, and a two-source input (c1 != cin channels in the first) needs c1 % 64 == 0 */
+int avsd_gemm_conv3r_gn_supported(int tile, int hs, int ws, int cin, int c1, int rows_per_batch);
 /* sizeof(avsd_gemm_desc) as compiled: lets an FFI binding verify its mirror of the struct. */
 int avsd_sizeof_gemm_desc(void);
 
@@ -247,6 +259,11 @@ int avsd_groupnorm_stats(const void* x1, int ld1, int c1, const void* x2, int ld
 int avsd_groupnorm_apply(const void* x1, int ld1, int c1, const void* x2, int ld2, int c2,
                          int nb, int rows_per_batch, int groups, const float* gamma, const float* beta, float eps,
                          const float* scratch, int nchunks, int act, void* y, int ldy, void* stream);
+/* The fold of the apply step alone: table[b][c] = (scale, shift) as f32 pairs ([nb][channels][2]) from the partials of
+ * avsd_groupnorm_stats — for a consumer that applies act(x * scale + shift) itself while it stages its operand
+ * (avsd_gemm_bf16 with AVSD_GEMM_GNFUSE: the normalised tensor is never written).  Same arithmetic as avsd_groupnorm_apply. */
+int avsd_groupnorm_table(const float* scratch, int nchunks, int nb, int rows_per_batch, int groups, int channels,
+                         const float* gamma, const float* beta, float eps, float* table, void* stream);
 /* One-launch form for SMALL batches: a workgroup keeps whole groups (rows_per_batch rows x the channels of a few groups,
  * <= ~1900 16-byte vectors) in registers between the statistics and the apply: no scratch, no second read of the input.
  * Same arithmetic as the pair above (f32 sums per thread, folded in double in a fixed order; results differ from the pair

@@ -20,8 +20,14 @@ F32 = torch.float32
 
 def gemm(a, w, *, n=None, k=None, a2=None, bias=None, rowvec=None, rows_per_vec=0, res1=None, res2=None, alpha=1.0,
          geglu=False, gelu=False, out_f32=False, out=None, mode=PLAIN, tmix=None, conv=None, m=None, tile=0, split_k=1,
-         rowstats=None, ln=None, master=None):
+         rowstats=None, ln=None, master=None, gn=None):
     assert a.dtype == P.ACT and w.dtype == P.ACT
+    if gn is not None:          # GroupNorm + SiLU prologue of the 3x3 convolution: the staged input is rounded to 16 bits
+        assert mode == CONV3
+        table, rows_b = gn
+        xc = a.float() if a2 is None else torch.cat([a.float(), a2.float()], 1)
+        t = table.repeat_interleave(rows_b, 0)
+        a, a2 = F.silu(xc * t[..., 0] + t[..., 1]).to(P.ACT), None
     wf = w.float()
     if mode == PLAIN:
         x = a.float() if a2 is None else torch.cat([a.float(), a2.float()], 1)
@@ -121,6 +127,25 @@ def groupnorm(x1, x2, nb, rows_per_batch, groups, gamma, beta, eps, act, out=Non
     y = F.group_norm(x.reshape(nb, rows_per_batch, C).permute(0, 2, 1), groups, gamma, beta, eps)
     y = F.silu(y) if act else y
     return y.permute(0, 2, 1).reshape(-1, C).to(P.ACT)
+
+
+def groupnorm_table(x1, x2, nb, rows_per_batch, groups, gamma, beta, eps):
+    x = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], 1)
+    C = x.shape[1]
+    g = x.reshape(nb, rows_per_batch, groups, C // groups).double()
+    mean = g.mean((1, 3))
+    var = (g * g).mean((1, 3)) - mean * mean
+    rstd = (1.0 / torch.sqrt(var.clamp_min(0) + eps)).float().repeat_interleave(C // groups, 1)
+    mean = mean.float().repeat_interleave(C // groups, 1)
+    scale = rstd * gamma
+    return torch.stack([scale, beta - mean * scale], -1).contiguous()
+
+
+def conv3r_gn_supported(hs, ws, cin, c1, rows_per_batch):
+    """mirror of avsd_gemm_conv3r_gn_supported over the tiles with loader waves (256- and 128-row tiles)"""
+    if cin % 64 or 2 * ws > 64 or (c1 != cin and (c1 <= 0 or c1 >= cin or c1 % 64)):
+        return False
+    return any(bm % ws == 0 and ((hs * ws) % bm == 0 or bm % (hs * ws) == 0) and rows_per_batch % bm == 0 for bm in (256, 128))
 
 
 def layernorm(x, gamma, beta, eps=1e-5, pos=None, hw=1, frames=1, out=None):

@@ -237,6 +237,53 @@ def test_gemm_conv3_resident(ops, n_img, hs, ws, cin, cout, split, tile):
     assert torch.equal(o32, ops.gemm(x, wp, bias=b, out_f32=True, mode=ops.CONV3, conv=(n_img, hs, ws, 1, 0), tile=tile, split_k=split))
 
 
+@pytest.mark.parametrize("tile", [40, 42, 43, 44])
+@pytest.mark.parametrize("nb,Fr,hs,ws,c1,c2,cout,split", [
+    (2, 3, 32, 32, 64, 0, 320, 1),       # one chunk: only the prologue transform (every wave)
+    (2, 2, 32, 32, 320, 0, 192, 1),      # five chunks: the loader waves transform chunks 1..4 behind the matrix work
+    (1, 4, 16, 16, 128, 64, 132, 1),     # two sources (the skip concat), three chunks
+    (2, 2, 16, 16, 320, 320, 640, 2),    # two sources, ten chunks in two slices
+    (3, 4, 8, 8, 192, 0, 128, 3),        # whole images per tile, batches of 256 rows
+    (2, 12, 4, 4, 128, 0, 64, 1),        # 192-row batches: no tile fits a batch -> refused
+])
+def test_gemm_conv3_groupnorm_prologue(ops, monkeypatch, nb, Fr, hs, ws, c1, c2, cout, split, tile):
+    """AVSD_GEMM_GNFUSE: SiLU(GroupNorm([x1 | x2])) applied to the staged chunks inside the convolution == the GroupNorm kernels
+    followed by the same convolution tile, bit for bit (same (scale, shift) fold, same f32 formula, same rounding), and both match
+    torch's group_norm -> silu -> conv2d in f32"""
+    from asva_amd import _lib
+    from asva_amd.weights import pack_conv3x3
+
+    monkeypatch.setattr(ops, "_GN_FUSED", False)         # the reference side: the stats + apply pair
+    rows_b = Fr * hs * ws
+    M, cin, groups = nb * rows_b, c1 + c2, 32
+    x1 = rnd(M, c1, seed=1) * 1.7 + 0.3
+    x2 = (rnd(M, c2, seed=5) * 0.6 - 0.2) if c2 else None
+    gamma, beta = 1 + 0.3 * rndf(cin, seed=6), 0.2 * rndf(cin, seed=7)
+    w = rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5)
+    b = rndf(cout, seed=3)
+    res = rnd(M, cout, seed=4)
+    wp = pack_conv3x3(w)
+    conv = (nb * Fr, hs, ws, 1, 0)
+    ok = _lib.lib().avsd_gemm_conv3r_gn_supported(tile, hs, ws, cin, c1, rows_b) > 0
+    assert ops.conv3r_gn_supported(hs, ws, cin, c1, rows_b) == any(
+        _lib.lib().avsd_gemm_conv3r_gn_supported(t, hs, ws, cin, c1, rows_b) > 0 for t in range(40, 50))
+    table = ops.groupnorm_table(x1, x2, nb, rows_b, groups, gamma, beta, 1e-5)
+    if not ok:
+        with pytest.raises((RuntimeError, ValueError)):
+            ops.gemm(x1, wp, a2=x2, bias=b, mode=ops.CONV3, conv=conv, tile=tile, gn=(table, rows_b))
+        return
+    out = ops.gemm(x1, wp, a2=x2, bias=b, res1=res, mode=ops.CONV3, conv=conv, tile=tile, split_k=split, gn=(table, rows_b))
+    normed = ops.groupnorm(x1, x2, nb, rows_b, groups, gamma, beta, 1e-5, True)
+    two = ops.gemm(normed, wp, bias=b, res1=res, mode=ops.CONV3, conv=conv, tile=tile, split_k=split)
+    assert torch.equal(out, two)
+    xi = torch.cat([x1, x2], 1).float() if c2 else x1.float()
+    xi = xi.reshape(nb, Fr, hs, ws, cin).permute(0, 4, 1, 2, 3)                       # the 5-D GroupNorm: pooled over (F, H, W)
+    a = F.silu(F.group_norm(xi, groups, gamma, beta, 1e-5)).permute(0, 2, 1, 3, 4).reshape(nb * Fr, cin, hs, ws)
+    ref = F.conv2d(a, w.float(), b, padding=1).permute(0, 2, 3, 1).reshape(-1, cout) + res.float()
+    assert rel_l2(out, ref) < 6e-3            # + the 16-bit rounding of the normalised activation (as in the two-kernel path)
+    assert torch.equal(out, ops.gemm(x1, wp, a2=x2, bias=b, res1=res, mode=ops.CONV3, conv=conv, tile=tile, split_k=split, gn=(table, rows_b)))
+
+
 def test_gemm_conv3_resident_refuses_other_convolutions(ops):
     from asva_amd.weights import pack_conv3x3
 

@@ -92,6 +92,7 @@ SIGNATURES = {
     "avsd_gemm_bf16": (c_int, [C.POINTER(GemmDesc), c_void_p]),
     "avsd_sizeof_gemm_desc": (c_int, []),
     "avsd_cross_attention_block": (c_int, [C.POINTER(XAttnDesc), c_void_p]),
+    "avsd_gemm_rowpanel_supported": (c_int, [c_int, c_int, c_int]),
     "avsd_gemm_conv3r_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "avsd_gemm_conv3r_gn_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "avsd_cross_attention_block_supported": (c_int, [c_int, c_int, c_int]),

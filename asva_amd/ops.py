@@ -116,6 +116,8 @@ CONV3R_SPLITS = (1, 2, 4, 5, 8, 10)
 _CONV3R = os.environ.get("AVSD_CONV3R", "1") != "0"
 
 
+TILE_ROWPANEL = 50          # csrc/rowpanel.hip: 96-row panels with the activation resident, PLAIN K <= 320 (the C = 320 linear layers)
+_ROWPANEL = os.environ.get("AVSD_ROWPANEL", "0") != "0"    # selectable, not a tuner candidate: 0.8-1.0x of the tuned tiles (profiles/r3_rowpanel_probe.txt)
 _CONV3R_BN = (128, 128, 160, 160, 128, 128, 256, 320, 256, 64)
 
 
@@ -573,6 +575,8 @@ def gemm(
         if not geglu and not two_src_unaligned and ((M + 127) // 128) * ((N + 127) // 128) < 256 and nk >= 16:
             cands = cands + tuple(c for c in (X2_SPLITK_CANDIDATES if P.SPLIT else SPLITK_CANDIDATES) if nk // c[1] >= 4)
         splitk_ok = not geglu and not two_src_unaligned
+        if (_ROWPANEL and mode == PLAIN and a2 is None and not P.SPLIT and M >= 96 * 64 and _lib.lib().avsd_gemm_rowpanel_supported(M, N, K) > 0):
+            cands = cands + ((TILE_ROWPANEL, 1),)
         if gn is not None or (mode == CONV3 and a2 is not None):
             cands = conv3r_candidates(d.hs, d.ws, d.cin, M, N, gn=(d.k_split if a2 is not None else d.cin, d.gn_rows_per_batch) if gn is not None else None)
             if not cands:

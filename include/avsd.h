@@ -92,6 +92,10 @@ enum { AVSD_GEMM_GEGLU = 1, AVSD_GEMM_OUT_F32 = 2, AVSD_GEMM_GELU = 4, AVSD_GEMM
  * nine taps; only the weight tile streams per K tile.  CONV3 descriptors with stride 1, ups 0, pad 1, one source,
  * cin % 64 == 0, image width <= 32 and a tile of whole image rows / whole images (avsd_gemm_conv3r_supported); split_k cuts
  * the channel chunks (split_k <= cin / 64).  No AVSD_GEMM_X2 / GEGLU / LNFUSE.  Other descriptors are refused with these ids. */
+/* Row-panel GEMM (rowpanel.hip): a workgroup owns 96 rows, keeps their activation (K <= 320) resident in LDS and walks N in
+ * 320-column steps streaming only weight tiles; PLAIN single-source descriptors with K <= 320, N % 32 == 0, no split_k, no
+ * AVSD_GEMM_X2 (avsd_gemm_rowpanel_supported).  Every epilogue flag of the other tiles; bit-identical results. */
+#define AVSD_GEMM_TILE_ROWPANEL 50
 #define AVSD_GEMM_TILE_CONV3R_FIRST 40
 #define AVSD_GEMM_TILE_CONV3R_LAST 49
 
@@ -162,6 +166,8 @@ typedef struct avsd_gemm_desc {
 } avsd_gemm_desc;
 
 int avsd_gemm_bf16(const avsd_gemm_desc* desc_host, void* stream);
+/* rows per panel if the row-panel tile takes an M x N x K PLAIN problem, else 0 */
+int avsd_gemm_rowpanel_supported(int M, int N, int K);
 /* rows per tile of conv3r tile id `tile` if an (hs x ws)-pixel image with cin channels can use it, else 0 */
 int avsd_gemm_conv3r_supported(int tile, int hs, int ws, int cin);
 /* the same for a descriptor with AVSD_GEMM_GNFUSE: only tiles with loader waves (40, 42, 43, 44) qualify, a normalisation batch

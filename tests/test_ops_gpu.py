@@ -254,6 +254,8 @@ def test_gemm_conv3_groupnorm_prologue(ops, monkeypatch, nb, Fr, hs, ws, c1, c2,
     from asva_amd.weights import pack_conv3x3
 
     monkeypatch.setattr(ops, "_GN_FUSED", False)         # the reference side: the stats + apply pair
+    monkeypatch.setattr(ops, "_CONV3R_GN", True)         # (the prologue is off by default: profiles/r3_gn_prologue_probe.txt)
+    monkeypatch.setattr(ops, "_CONV3R_GN_MINPIX", 1)
     rows_b = Fr * hs * ws
     M, cin, groups = nb * rows_b, c1 + c2, 32
     x1 = rnd(M, c1, seed=1) * 1.7 + 0.3
@@ -282,6 +284,58 @@ def test_gemm_conv3_groupnorm_prologue(ops, monkeypatch, nb, Fr, hs, ws, c1, c2,
     ref = F.conv2d(a, w.float(), b, padding=1).permute(0, 2, 3, 1).reshape(-1, cout) + res.float()
     assert rel_l2(out, ref) < 6e-3            # + the 16-bit rounding of the normalised activation (as in the two-kernel path)
     assert torch.equal(out, ops.gemm(x1, wp, a2=x2, bias=b, res1=res, mode=ops.CONV3, conv=conv, tile=tile, split_k=split, gn=(table, rows_b)))
+
+
+@pytest.mark.parametrize("M,N,K", [(960, 320, 320), (1000, 960, 320), (96 * 7, 640, 320), (200, 352, 200), (2304, 320, 64), (480, 1280, 256)])
+def test_gemm_rowpanel(ops, M, N, K):
+    """rowpanel.hip (tile 50): 96-row panels with the activation resident, N walked in 320-column steps — every epilogue form,
+    against torch in f32 and bit for bit against a gemm2 tile (same K order, same f32 epilogue)"""
+    a = rnd(M, K, seed=1)
+    w = rnd(N, K, seed=2, scale=K ** -0.5)
+    b = rndf(N, seed=3)
+    res = rnd(M, N, seed=4)
+    T = ops.TILE_ROWPANEL
+    ref = a.float() @ w.float().T + b
+    out = ops.gemm(a, w, bias=b, res1=res, tile=T)
+    assert rel_l2(out, ref + res.float()) < TOL_BF16
+    assert torch.equal(out, ops.gemm(a, w, bias=b, res1=res, tile=6))
+    o32 = ops.gemm(a, w, bias=b, out_f32=True, tile=T)
+    assert rel_l2(o32, ref) < TOL_F32 and torch.equal(o32, ops.gemm(a, w, bias=b, out_f32=True, tile=6))
+    # f32 master + row statistics of the rounded output (the residual-stream producers)
+    st, st6 = torch.empty(M, N // 32, 2, device=dev()), torch.empty(M, N // 32, 2, device=dev())
+    mm, mm6 = torch.empty(M, N, device=dev()), torch.empty(M, N, device=dev())
+    h = ops.gemm(a, w, bias=b, res1=res, rowstats=st, master=mm, tile=T)
+    h6 = ops.gemm(a, w, bias=b, res1=res, rowstats=st6, master=mm6, tile=6)
+    assert torch.equal(h, h6) and torch.equal(st, st6) and torch.equal(mm, mm6)
+    if K % 32 == 0:
+        # LayerNorm fold and GEGLU consumers of a residual stream with K channels
+        from asva_amd.weights import pack_geglu
+        hs = rnd(M, K, seed=5) * 2 + 0.7
+        stats = torch.empty(M, K // 32, 2, device=dev())
+        hb = hs.float().reshape(M, K // 32, 32)
+        stats[..., 0], stats[..., 1] = hb.sum(-1), (hb * hb).sum(-1)
+        g, be = 1 + 0.2 * rndf(K, seed=6), 0.3 * rndf(K, seed=7)
+        wl = 0.05 * rndf(N, K, seed=8)
+        wf = (wl * g).bfloat16()
+        y = ops.gemm(hs, wf, bias=wl @ be + b, ln=(stats, wf.float().sum(1), 1e-5), tile=T)
+        assert rel_l2(y, F.layer_norm(hs.float(), (K,), g, be, 1e-5) @ wl.T + b) < TOL_BF16
+        assert torch.equal(y, ops.gemm(hs, wf, bias=wl @ be + b, ln=(stats, wf.float().sum(1), 1e-5), tile=6))
+        w1 = 0.05 * rndf(2 * N, K, seed=9)
+        b1 = rndf(2 * N, seed=10)
+        wpk, bpk = pack_geglu(w1 * g, w1 @ be + b1)
+        yg = ops.gemm(hs, wpk, bias=bpk, geglu=True, ln=(stats, wpk.float().sum(1), 1e-5), tile=T)
+        tt = F.layer_norm(hs.float(), (K,), g, be, 1e-5) @ w1.T + b1
+        assert rel_l2(yg, tt[:, :N] * F.gelu(tt[:, N:])) < TOL_BF16
+        assert torch.equal(yg, ops.gemm(hs, wpk, bias=bpk, geglu=True, ln=(stats, wpk.float().sum(1), 1e-5), tile=11))
+
+
+def test_gemm_rowpanel_refuses(ops):
+    with pytest.raises(RuntimeError):
+        ops.gemm(rnd(192, 640, seed=1), rnd(320, 640, seed=2), tile=ops.TILE_ROWPANEL)              # K > 320
+    with pytest.raises(RuntimeError):
+        ops.gemm(rnd(192, 320, seed=1), rnd(320, 320, seed=2), tile=ops.TILE_ROWPANEL, split_k=2)   # no split-K
+    with pytest.raises(RuntimeError):
+        ops.gemm(rnd(192, 192, seed=1), rnd(320, 320, seed=2), a2=rnd(192, 128, seed=3), tile=ops.TILE_ROWPANEL)
 
 
 def test_gemm_conv3_resident_refuses_other_convolutions(ops):

@@ -299,7 +299,7 @@ def main():
         # pass each carry ~4 us of command-processor time that the graph-replayed step (and its rocprofv3 trace) does not
         ms = timer.replay_ms(("gemm_plain", "gemm_tmix", "gemm_conv3")) if not a.no_graph else ms_events
         ach = fl / (ms * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<BM,BN,MODE> family (linear / temporal-mix / conv3x3 implicit GEMM)",
+        out["roofline"] = {"bound": "mfma", "kernel": "GEMM family: gemm2_kernel<BM,BN,...,MODE> (linear / temporal-mix / strided conv3x3 implicit GEMM) + conv3r_kernel (conv3x3, input tile resident in LDS)",
                            "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                            "traffic": None, "launches_per_step": launches, "ms_per_step": round(ms, 4),
                            "ms_per_step_event_pairs": round(ms_events, 4),

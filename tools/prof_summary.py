@@ -11,6 +11,10 @@ def short(name: str) -> str:
     if m:
         bm, bn, wm, wn, st, mode, lw = m.groups()
         return f"gemm2<{bm}x{bn},{wm}x{wn}w{'+' + lw + 'L' if lw and lw != '0' else ''},{st}st,{('plain','tmix','conv3')[int(mode)]}>"
+    m = re.search(r"conv3r_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\w+))?>", name)
+    if m:
+        bm, bn, wm, wn, st, lw, gn = m.groups()
+        return f"conv3r<{bm}x{bn},{wm}x{wn}w{'+' + lw + 'L' if lw != '0' else ''},{st}st{',gn' if gn in ('true', '1') else ''}>"
     m = re.search(r"gemm_kernel<(\d+), (\d+), (\d+)>", name)
     if m:
         bm, bn, mode = m.groups()

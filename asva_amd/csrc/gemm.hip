@@ -799,6 +799,8 @@ int launch2(const avsd_gemm_desc& d, hipStream_t s) {
       case 2: hipLaunchKernelGGL(splitk_reduce_kernel<2>, dim3((unsigned)g), dim3(256), 0, s, d); break;
       case 4: hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((unsigned)g), dim3(256), 0, s, d); break;
       case 8: hipLaunchKernelGGL(splitk_reduce_kernel<8>, dim3((unsigned)g), dim3(256), 0, s, d); break;
+      case 3: hipLaunchKernelGGL(splitk_reduce_kernel<3>, dim3((unsigned)g), dim3(256), 0, s, d); break;
+      case 5: hipLaunchKernelGGL(splitk_reduce_kernel<5>, dim3((unsigned)g), dim3(256), 0, s, d); break;
       default: hipLaunchKernelGGL(splitk_reduce_kernel<0>, dim3((unsigned)g), dim3(256), 0, s, d); break;
     }
     AVSD_CHECK_LAUNCH("gemm split-K reduce launch");
@@ -944,6 +946,9 @@ int avsd_gemm_splitk_reduce(const avsd_gemm_desc& d, hipStream_t s) {
     case 2: hipLaunchKernelGGL(splitk_reduce_kernel<2>, dim3((unsigned)g), dim3(256), 0, s, d); break;
     case 4: hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((unsigned)g), dim3(256), 0, s, d); break;
     case 8: hipLaunchKernelGGL(splitk_reduce_kernel<8>, dim3((unsigned)g), dim3(256), 0, s, d); break;
+    case 3: hipLaunchKernelGGL(splitk_reduce_kernel<3>, dim3((unsigned)g), dim3(256), 0, s, d); break;
+    case 5: hipLaunchKernelGGL(splitk_reduce_kernel<5>, dim3((unsigned)g), dim3(256), 0, s, d); break;
+    case 10: hipLaunchKernelGGL(splitk_reduce_kernel<10>, dim3((unsigned)g), dim3(256), 0, s, d); break;
     default: hipLaunchKernelGGL(splitk_reduce_kernel<0>, dim3((unsigned)g), dim3(256), 0, s, d); break;
   }
   AVSD_CHECK_LAUNCH("gemm split-K reduce launch");

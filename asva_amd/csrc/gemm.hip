@@ -1001,7 +1001,8 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
   } else {
     AVSD_REQUIRE(false, "gemm: unknown mode %d", d.mode);
   }
-  if (d.tile >= AVSD_GEMM_TILE_CONV3R_FIRST && d.tile <= AVSD_GEMM_TILE_CONV3R_LAST) {
+  if ((d.tile >= AVSD_GEMM_TILE_CONV3R_FIRST && d.tile <= AVSD_GEMM_TILE_CONV3R_LAST) ||
+      (d.tile >= AVSD_GEMM_TILE_CONV3R2D_FIRST && d.tile <= AVSD_GEMM_TILE_CONV3R2D_LAST)) {
     if (d.split_k > 1) AVSD_REQUIRE(d.splitk_ws != nullptr, "gemm: split_k needs a workspace");
     return avsd_gemm_dispatch_conv3r(d, reinterpret_cast<hipStream_t>(stream));
   }

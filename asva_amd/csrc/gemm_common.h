@@ -104,7 +104,7 @@ __device__ __forceinline__ void epilogue_add_residual(const avsd_gemm_desc& p, f
 // column to the last valid one; only the stores are guarded.  The f32 operation order per element is unchanged.
 template <int FN, int FM>
 __device__ __forceinline__ void epilogue_by_term(const avsd_gemm_desc& p, f32x16 (&acc)[FN][FM], int m_base, int n_base,
-                                                 int lane, int64_t bz, const float (&pre_ln)[2 * FM], bool have_pre) {
+                                                 int lane, int64_t bz, const float (&pre_ln)[2 * FM], bool have_pre, int mstride = 32) {
   const int frow = lane & 31;
   const bool geglu = (p.flags & AVSD_GEMM_GEGLU) != 0;
   const bool out_f32 = (p.flags & AVSD_GEMM_OUT_F32) != 0;
@@ -117,7 +117,7 @@ __device__ __forceinline__ void epilogue_by_term(const avsd_gemm_desc& p, f32x16
   int mrow[FM], mld[FM];
 #pragma unroll
   for (int b = 0; b < FM; ++b) {
-    mrow[b] = m_base + b * 32 + frow;
+    mrow[b] = m_base + b * mstride + frow;
     mld[b] = min(mrow[b], p.M - 1);           // row used for loads: always valid
   }
   const int nmax = p.N - 4;                   // last valid quad start (N % 4 == 0)
@@ -303,7 +303,7 @@ __device__ __forceinline__ void epilogue_by_term(const avsd_gemm_desc& p, f32x16
 // un-rounded f32 result is stored next to the 16-bit one.
 template <int FN, int FM>
 __device__ __forceinline__ void epilogue_by_fragment(const avsd_gemm_desc& p, f32x16 (&acc)[FN][FM], int m_base, int n_base,
-                                         int lane, int64_t bz, const float (&pre_ln)[2 * FM], bool have_pre) {
+                                         int lane, int64_t bz, const float (&pre_ln)[2 * FM], bool have_pre, int mstride = 32) {
   const int frow = lane & 31;
   const bool geglu = (p.flags & AVSD_GEMM_GEGLU) != 0;
   const bool out_f32 = (p.flags & AVSD_GEMM_OUT_F32) != 0;
@@ -318,7 +318,7 @@ __device__ __forceinline__ void epilogue_by_fragment(const avsd_gemm_desc& p, f3
   const int hsel = (lane >> 5) * 4;
 #pragma unroll
   for (int b = 0; b < FM; ++b) {
-    const int m = m_base + b * 32 + frow;
+    const int m = m_base + b * mstride + frow;
     if (m >= p.M) continue;
     const float* rv = p.rowvec ? p.rowvec + (int64_t)(m / p.rows_per_vec) * p.ldv : nullptr;
     // AVSD_GEMM_LNFUSE: LayerNorm statistics of this lane's row of A (rstd, mean * rstd)
@@ -511,11 +511,13 @@ __device__ __forceinline__ void epilogue_by_fragment(const avsd_gemm_desc& p, f3
 // 7-10 % faster on the K = 320 / 640 linear layers.  Bigger wave tiles hold 128-160 accumulator registers and the batched
 // form spills them (4-5x slower, measured): they keep the fragment-at-a-time form, which needs one fragment of temporaries.
 // (TIGHT: the kernel runs under a reduced register budget — the loader-wave tiles of 768 threads get 168 registers.)
+// mstride: rows between the row fragments of a wave (32: consecutive rows; the 2-D convolution tiles pass the image width —
+// fragment b is the tile's b-th image row).
 template <int FN, int FM, bool TIGHT = false>
 __device__ __forceinline__ void epilogue(const avsd_gemm_desc& p, f32x16 (&acc)[FN][FM], int m_base, int n_base,
-                                         int lane, int64_t bz, const float (&pre_ln)[2 * FM], bool have_pre) {
-  if constexpr (FN * FM <= (TIGHT ? 2 : 4)) epilogue_by_term<FN, FM>(p, acc, m_base, n_base, lane, bz, pre_ln, have_pre);
-  else epilogue_by_fragment<FN, FM>(p, acc, m_base, n_base, lane, bz, pre_ln, have_pre);
+                                         int lane, int64_t bz, const float (&pre_ln)[2 * FM], bool have_pre, int mstride = 32) {
+  if constexpr (FN * FM <= (TIGHT ? 2 : 4)) epilogue_by_term<FN, FM>(p, acc, m_base, n_base, lane, bz, pre_ln, have_pre, mstride);
+  else epilogue_by_fragment<FN, FM>(p, acc, m_base, n_base, lane, bz, pre_ln, have_pre, mstride);
 }
 
 // ---- AVSD_GEMM_X2 epilogue: same terms and f32 order as above; 16-bit residuals are read as main + rest, the result is

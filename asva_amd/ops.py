@@ -112,6 +112,8 @@ X2_SPLITK_CANDIDATES = ((34, 2), (34, 4), (35, 2), (35, 4), (36, 2), (36, 4), (4
 # 3x3 stride-1 convolutions with the input tile resident in LDS (csrc/conv3r.hip): tile ids 40-49, geometry-dependent
 # (avsd_gemm_conv3r_supported); split_k cuts the cin / 64 channel chunks
 CONV3R_TILES = tuple(range(40, 50))
+CONV3R2D_TILES = (51, 52, 53, 54)   # rectangular resident tiles (TH rows x 32 pixels) for images wider than 32 pixels: the VAE decoder, cfg 4
+_CONV3R2D_BN = {51: 128, 52: 160, 53: 128, 54: 128}
 CONV3R_SPLITS = (1, 2, 4, 5, 8, 10)
 _CONV3R = os.environ.get("AVSD_CONV3R", "1") != "0"
 
@@ -138,6 +140,16 @@ def conv3r_candidates(hs: int, ws: int, cin: int, M: int, N: int, gn: Optional[t
             if sk > 1 and (wgs >= 256 or (cin // 64) // sk < 2 or (cin // 64) % sk != 0):
                 continue
             out.append((t, sk))
+    if gn is None:
+        for t in CONV3R2D_TILES:
+            bm = _lib.lib().avsd_gemm_conv3r2d_supported(t, hs, ws, cin)
+            if bm <= 0:
+                continue
+            wgs = (M // bm) * ((N + _CONV3R2D_BN[t] - 1) // _CONV3R2D_BN[t])
+            for sk in CONV3R_SPLITS:
+                if sk > 1 and (wgs >= 256 or (cin // 64) // sk < 2 or (cin // 64) % sk != 0):
+                    continue
+                out.append((t, sk))
     return tuple(out)
 
 
@@ -156,8 +168,8 @@ def _heuristic_conv3r(cands, M: int, N: int):
     padded columns, then the one closest to one workgroup per CU"""
     def cost(c):
         t, sk = c
-        bn = _CONV3R_BN[t - 40]
-        bm = 256 if t in (40, 41, 42, 43, 48) else 128
+        bn = _CONV3R_BN[t - 40] if t < 50 else _CONV3R2D_BN[t]
+        bm = 256 if t in (40, 41, 42, 43, 48, 51, 52, 53) else 128
         wg = ((M + bm - 1) // bm) * ((N + bn - 1) // bn) * sk
         pad = ((N + bn - 1) // bn) * bn / N
         return (round(pad, 2), abs(wg - 256) if wg < 256 else (wg - 256) // 4, sk)
@@ -589,6 +601,8 @@ def gemm(
             key = key + (d.hs, d.ws)
         picked = _pick_tile(key, _launch, cands, warm=(a, a2, res1, res2))
         if picked is not None and picked[0] in CONV3R_TILES and not ((_CONV3R or gn is not None or a2 is not None) and _lib.lib().avsd_gemm_conv3r_supported(picked[0], d.hs, d.ws, d.cin)):
+            picked = None
+        if picked is not None and picked[0] in CONV3R2D_TILES and not (_CONV3R and _lib.lib().avsd_gemm_conv3r2d_supported(picked[0], d.hs, d.ws, d.cin)):
             picked = None
         heur = _heuristic_tile_x2 if P.SPLIT else _heuristic_tile
         if picked is None and (gn is not None or (mode == CONV3 and a2 is not None)):

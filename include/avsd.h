@@ -98,6 +98,11 @@ enum { AVSD_GEMM_GEGLU = 1, AVSD_GEMM_OUT_F32 = 2, AVSD_GEMM_GELU = 4, AVSD_GEMM
 #define AVSD_GEMM_TILE_ROWPANEL 50
 #define AVSD_GEMM_TILE_CONV3R_FIRST 40
 #define AVSD_GEMM_TILE_CONV3R_LAST 49
+/* the same convolution with RECTANGULAR resident tiles (TH image rows x 32 pixels + a one-pixel halo, positions outside the image
+ * zero-filled at load time) for images wider than 32 pixels: width % 32 == 0, height % TH == 0 (avsd_gemm_conv3r2d_supported);
+ * otherwise as the ids above, without the GroupNorm prologue. */
+#define AVSD_GEMM_TILE_CONV3R2D_FIRST 51
+#define AVSD_GEMM_TILE_CONV3R2D_LAST 54
 
 typedef struct avsd_gemm_desc {
   const void* A;        /* bf16 */
@@ -170,6 +175,7 @@ int avsd_gemm_bf16(const avsd_gemm_desc* desc_host, void* stream);
 int avsd_gemm_rowpanel_supported(int M, int N, int K);
 /* rows per tile of conv3r tile id `tile` if an (hs x ws)-pixel image with cin channels can use it, else 0 */
 int avsd_gemm_conv3r_supported(int tile, int hs, int ws, int cin);
+int avsd_gemm_conv3r2d_supported(int tile, int hs, int ws, int cin);
 /* the same for a descriptor with AVSD_GEMM_GNFUSE: only tiles with loader waves (40, 42, 43, 44) qualify, a normalisation batch
  * must be whole tiles, and a two-source input (c1 != cin channels in the first) needs c1 % 64 == 0 */
 int avsd_gemm_conv3r_gn_supported(int tile, int hs, int ws, int cin, int c1, int rows_per_batch);

@@ -338,6 +338,46 @@ def test_gemm_rowpanel_refuses(ops):
         ops.gemm(rnd(192, 192, seed=1), rnd(320, 320, seed=2), a2=rnd(192, 128, seed=3), tile=ops.TILE_ROWPANEL)
 
 
+@pytest.mark.parametrize("tile", [51, 52, 53, 54])
+@pytest.mark.parametrize("n_img,hs,ws,cin,cout,split", [
+    (2, 64, 64, 64, 128, 1),        # 2 x 2 (x 8 rows) tiles per image: every border and corner case of the zero-filled halo
+    (1, 32, 96, 128, 132, 2),       # non-square, three tiles per row band, N tail, one chunk per slice
+    (3, 8, 32, 192, 320, 3),        # one tile per image (TH = 8) / two (TH = 4)
+    (1, 128, 128, 64, 64, 1),       # a VAE-sized image
+    (2, 12, 64, 64, 64, 1),         # height 12: only the 4-row tile fits
+])
+def test_gemm_conv3_resident_2d(ops, n_img, hs, ws, cin, cout, split, tile):
+    """conv3r.hip, rectangular tiles (TH image rows x 32 pixels): against F.conv2d in f32 and the tap-major tile 9; full epilogue,
+    split over channel chunks, a two-source input"""
+    from asva_amd import _lib
+    from asva_amd.weights import pack_conv3x3
+
+    bm = _lib.lib().avsd_gemm_conv3r2d_supported(tile, hs, ws, cin)
+    M = n_img * hs * ws
+    x = rnd(M, cin, seed=1)
+    w = rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5)
+    b = rndf(cout, seed=3)
+    res = rnd(M, cout, seed=4)
+    wp = pack_conv3x3(w)
+    conv = (n_img, hs, ws, 1, 0)
+    if bm == 0:
+        with pytest.raises(RuntimeError):
+            ops.gemm(x, wp, bias=b, mode=ops.CONV3, conv=conv, tile=tile)
+        return
+    xi = x.float().reshape(n_img, hs, ws, cin).permute(0, 3, 1, 2)
+    ref = F.conv2d(xi, w.float(), b, padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
+    out = ops.gemm(x, wp, bias=b, res1=res, mode=ops.CONV3, conv=conv, tile=tile, split_k=split)
+    assert rel_l2(out, ref + res.float()) < TOL_BF16
+    o32 = ops.gemm(x, wp, bias=b, out_f32=True, mode=ops.CONV3, conv=conv, tile=tile, split_k=split)
+    assert rel_l2(o32, ref) < TOL_F32
+    assert rel_l2(o32, ops.gemm(x, wp, bias=b, out_f32=True, mode=ops.CONV3, conv=conv, tile=9)) < TOL_F32
+    assert torch.equal(o32, ops.gemm(x, wp, bias=b, out_f32=True, mode=ops.CONV3, conv=conv, tile=tile, split_k=split))
+    if cin >= 128:      # the same input handed over as two sources
+        c1 = 64
+        o2 = ops.gemm(x[:, :c1].contiguous(), wp, a2=x[:, c1:].contiguous(), bias=b, out_f32=True, mode=ops.CONV3, conv=conv, tile=tile, split_k=split)
+        assert torch.equal(o2, o32)
+
+
 def test_gemm_conv3_resident_refuses_other_convolutions(ops):
     from asva_amd.weights import pack_conv3x3
 

@@ -15,6 +15,8 @@ shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [
     (24, 4, 4, 1280, 1280), (24, 4, 4, 2560, 1280),
     (96, 32, 32, 320, 320), (96, 16, 16, 640, 640), (96, 8, 8, 1280, 1280), (96, 4, 4, 1280, 1280),     # 4 clips per forward
     (12, 32, 32, 512, 512),                                                                                   # VAE decoder, first level
+    (12, 64, 64, 512, 512), (12, 128, 128, 512, 256), (12, 128, 128, 256, 256), (12, 256, 256, 256, 128), (12, 256, 256, 128, 128),   # VAE decoder, upper levels
+    (48, 64, 64, 320, 320), (48, 64, 64, 640, 320), (48, 32, 32, 640, 640),                                 # cfg 4 (24 frames, 64 x 64 latents)
 ]
 g = torch.Generator().manual_seed(0)
 for n_img, hs, ws, cin, cout in shapes:

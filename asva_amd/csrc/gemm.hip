@@ -852,6 +852,10 @@ int dispatch_tile(const avsd_gemm_desc& d, int tile, hipStream_t s) {
     // each reads its activation rows once; 5 MFMA waves (96x64 each) + 2 loader waves
     case 32: return launch2<96, 320, 1, 5, 3, MODE, 2>(d, s);   // 156 KB
     case 33: return launch2<96, 320, 1, 5, 2, MODE, 2>(d, s);   // 104 KB
+    // 256 x 160: the geometry the resident convolution does best with on the N = 320 layers (conv3r.hip tile 43) — N = 320 /
+    // 640 / 960 / 1280 in whole column tiles, 98 FLOP per staged byte (128 x 128: 64)
+    case AVSD_GEMM_TILE_256x160_8W: return launch2<256, 160, 8, 1, 3, MODE, 4>(d, s);   // 156 KB, 32x160 wave tiles, 8 MFMA + 4 loader waves
+    case AVSD_GEMM_TILE_256x160_4W: return launch2<256, 160, 4, 1, 3, MODE, 4>(d, s);   // 156 KB, 64x160 wave tiles, 4 MFMA + 4 loader waves
     // (measured and dropped: 128x64 with a 6-deep ring, 128x128 x 5 with loader waves — never the tuner's pick)
     default: return launch<64, 64, MODE>(d, s);
   }
@@ -1018,7 +1022,8 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
   if (d.split_k > 1) {
     AVSD_REQUIRE(d.splitk_ws != nullptr, "gemm: split_k needs a workspace");
     AVSD_REQUIRE(!(d.flags & AVSD_GEMM_GEGLU) && d.batch == 1, "gemm: split_k cannot be combined with GEGLU or batching");
-    AVSD_REQUIRE(d.tile >= 4 && d.tile <= ((d.flags & AVSD_GEMM_X2) ? AVSD_GEMM_MAX_TILE_X2 : AVSD_GEMM_MAX_TILE),
+    AVSD_REQUIRE((d.tile >= 4 && d.tile <= ((d.flags & AVSD_GEMM_X2) ? AVSD_GEMM_MAX_TILE_X2 : AVSD_GEMM_MAX_TILE)) ||
+                     (!(d.flags & AVSD_GEMM_X2) && (d.tile == AVSD_GEMM_TILE_256x160_8W || d.tile == AVSD_GEMM_TILE_256x160_4W)),
                  "gemm: split_k needs an LDS-direct tile (4..33; split precision: ..36), got %d", d.tile);
     AVSD_REQUIRE(d.split_k <= (d.K + 63) / 64, "gemm: split_k (%d) exceeds the number of K tiles", d.split_k);
     AVSD_REQUIRE(!d.splitk_cnt || d.N % 32 == 0, "gemm: the in-launch split-K reduction needs N %% 32 == 0 (got %d)", d.N);
@@ -1054,7 +1059,7 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
       tile = (d.N > 64 && d.M > 2048) ? 2 : 3;
     }
   }
-  if (tile < 1 || tile > AVSD_GEMM_MAX_TILE) tile = pick_tile(d.M, (d.flags & AVSD_GEMM_GEGLU) ? d.N : d.N, d.batch);
+  if (tile < 1 || (tile > AVSD_GEMM_MAX_TILE && tile != AVSD_GEMM_TILE_256x160_8W && tile != AVSD_GEMM_TILE_256x160_4W)) tile = pick_tile(d.M, (d.flags & AVSD_GEMM_GEGLU) ? d.N : d.N, d.batch);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (d.mode) {
     case AVSD_GEMM_PLAIN: return avsd_gemm_dispatch_plain(d, tile, s);

@@ -87,6 +87,9 @@ enum { AVSD_GEMM_GEGLU = 1, AVSD_GEMM_OUT_F32 = 2, AVSD_GEMM_GELU = 4, AVSD_GEMM
 /* 256 x 256 tile with the phase-interleaved main loop (gemm8p.hip): PLAIN single-source or CONV3 with cin % 64 == 0,
  * no split_k, no AVSD_GEMM_X2; other descriptors are refused with this tile id. */
 #define AVSD_GEMM_TILE_8PHASE 37
+/* 256 x 160 LDS-direct tiles with loader waves (gemm.hip dispatch_tile; not with AVSD_GEMM_X2) */
+#define AVSD_GEMM_TILE_256x160_8W 38
+#define AVSD_GEMM_TILE_256x160_4W 39
 /* 3x3 stride-1 pad-1 convolution tiles with the input tile resident in LDS (conv3r.hip): K is walked chunk-major (64 input
  * channels at a time), the BM output rows plus one image row of halo on either side are staged once per chunk and read by all
  * nine taps; only the weight tile streams per K tile.  CONV3 descriptors with stride 1, ups 0, pad 1, one source,

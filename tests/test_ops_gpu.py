@@ -56,7 +56,7 @@ def test_device_is_gfx950():
 
 
 # ---- GEMM ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 0])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 38, 39, 0])
 @pytest.mark.parametrize("M,N,K", [(384, 320, 320), (1000, 640, 1280), (128, 64, 64), (77, 132, 200), (2048, 1280, 768)])
 def test_gemm_plain(ops, tile, M, N, K):
     a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
@@ -166,7 +166,7 @@ def _tmix_ref(y, w, b, B, Fr, hw):
     return (y5 + cat @ w.float().T + b).reshape(B * Fr * hw, C)
 
 
-@pytest.mark.parametrize("tile", [0, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33])
+@pytest.mark.parametrize("tile", [0, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 38, 39])
 @pytest.mark.parametrize("B,Fr,hw,C", [(2, 12, 64, 320), (1, 4, 16, 80), (2, 3, 100, 640)])
 def test_gemm_tmix(ops, B, Fr, hw, C, tile):
     y = rnd(B * Fr * hw, C, seed=1)
@@ -176,7 +176,7 @@ def test_gemm_tmix(ops, B, Fr, hw, C, tile):
     assert rel_l2(out, _tmix_ref(y, w, b, B, Fr, hw)) < TOL_BF16
 
 
-@pytest.mark.parametrize("tile", [0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33])
+@pytest.mark.parametrize("tile", [0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 38, 39])
 @pytest.mark.parametrize("stride,ups", [(1, 0), (2, 0), (1, 1)])
 @pytest.mark.parametrize("n_img,hs,ws,cin,cout", [(3, 16, 16, 64, 128), (2, 8, 12, 320, 320), (4, 5, 7, 8, 4), (2, 32, 32, 4, 320)])
 def test_gemm_conv3x3(ops, stride, ups, n_img, hs, ws, cin, cout, tile):

@@ -101,7 +101,7 @@ def _stream() -> int:
 # candidate is timed with HIP events on the caller's real buffers and the winner is cached for the life of the
 # process (measure, don't guess) — that is how the table is produced; results then depend on timing noise.
 TILE_CANDIDATES = ((4, 1), (6, 1), (7, 1), (8, 1), (9, 1), (3, 1), (11, 1), (12, 1), (13, 1), (14, 1), (15, 1), (16, 1), (17, 1), (18, 1), (19, 1),
-                   (20, 1), (21, 1), (22, 1), (23, 1), (24, 1), (25, 1), (26, 1), (27, 1), (28, 1), (29, 1), (30, 1), (31, 1), (32, 1), (33, 1), (38, 1), (39, 1))
+                   (20, 1), (21, 1), (22, 1), (23, 1), (24, 1), (25, 1), (26, 1), (27, 1), (28, 1), (29, 1), (30, 1), (31, 1), (32, 1), (33, 1), (38, 1))
 # extra (tile, split_k) candidates for GEMMs whose output is too small to fill 256 CUs with big tiles
 SPLITK_CANDIDATES = ((6, 2), (6, 4), (6, 8), (9, 2), (9, 4), (4, 2), (4, 4), (4, 8), (7, 2), (7, 4),
                      (20, 2), (20, 4), (24, 2), (24, 4), (24, 8), (25, 2), (25, 4), (26, 2), (26, 4), (26, 8),

@@ -105,6 +105,7 @@ SIGNATURES = {
     "avsd_groupnorm_stats": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "avsd_groupnorm_apply": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                      c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "avsd_ln_fold": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "avsd_groupnorm_table": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     "avsd_groupnorm_fused_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "avsd_groupnorm_fused": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,

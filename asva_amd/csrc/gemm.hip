@@ -709,7 +709,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const avsd_gemm_desc
       const float2* st = reinterpret_cast<const float2*>(p.ln_stats) + (int64_t)m * p.ln_nblk;
       float sm = 0.f, sq = 0.f;
       for (int j = 0; j < p.ln_nblk; ++j) { const float2 t = st[j]; sm += t.x; sq += t.y; }
-      const float inv_k = 1.0f / (float)(p.ln_nblk * 32);
+      const float inv_k = 1.0f / (float)p.K;
       const float mean = sm * inv_k;
       const float rstd = rsqrtf(fmaxf(sq * inv_k - mean * mean, 0.f) + p.ln_eps);
       const float4 cs = *reinterpret_cast<const float4*>(p.ln_colsum + n);
@@ -979,7 +979,7 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
   if (d.flags & AVSD_GEMM_LNFUSE) {
     AVSD_REQUIRE(d.ln_stats && d.ln_colsum && d.ln_nblk > 0 && d.mode == AVSD_GEMM_PLAIN && !d.A2,
                  "gemm: LNFUSE needs ln_stats, ln_colsum, ln_nblk and a single-source PLAIN operand");
-    AVSD_REQUIRE(d.ln_nblk * 32 == d.K, "gemm: LNFUSE statistics cover %d columns, K = %d", d.ln_nblk * 32, d.K);
+    AVSD_REQUIRE(d.ln_nblk * 32 == d.K || d.ln_nblk == 1, "gemm: LNFUSE statistics are K / 32 pairs per row or one pre-folded pair (got %d for K = %d)", d.ln_nblk, d.K);
     AVSD_REQUIRE(d.batch == 1 || d.batch_stride_a % d.lda == 0, "gemm: LNFUSE batch stride must be whole rows");
   }
   if (d.res1) AVSD_REQUIRE(d.ldr1 % 4 == 0, "gemm: ldr1 must be a multiple of 4");

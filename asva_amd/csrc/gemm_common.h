@@ -24,7 +24,7 @@ __device__ __forceinline__ void ln_row_stats(const avsd_gemm_desc& p, int m, int
     sm += t.x;
     sq += t.y;
   }
-  const float inv_k = 1.0f / (float)(p.ln_nblk * 32);
+  const float inv_k = 1.0f / (float)p.K;       // the ln_nblk pairs of a row cover its K columns (32 each, or pre-folded: avsd_ln_fold)
   const float mean = sm * inv_k;
   const float var = fmaxf(sq * inv_k - mean * mean, 0.f);
   rstd = rsqrtf(var + p.ln_eps);

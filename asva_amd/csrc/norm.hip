@@ -259,6 +259,27 @@ __global__ __launch_bounds__(1024) void gn_table_kernel(const float* partial, in
   }
 }
 
+// ---- LayerNorm row statistics, pre-folded: the K / 32 (sum, sumsq) pairs a ROWSTATS producer wrote per row -> one pair per row,
+// added in the order the consumers' own fold uses (ascending block), so a consumer handed the folded pair (ln_nblk = 1) computes
+// bit-identical mean / rstd.  Worth a launch where a consumer would re-fold the same rows in many column tiles (the GEGLU projection:
+// 20-80 column tiles, +8-10 us per launch, tools/geglu_probe.py).
+__global__ __launch_bounds__(256) void ln_fold_kernel(const float2* stats, int M, int nblk, float2* out) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  const float2* st = stats + (int64_t)m * nblk;
+  float sm = 0.f, sq = 0.f;
+  int j = 0;
+  for (; j + 10 <= nblk; j += 10) {
+    float2 t[10];
+#pragma unroll
+    for (int u = 0; u < 10; ++u) t[u] = st[j + u];
+#pragma unroll
+    for (int u = 0; u < 10; ++u) { sm += t[u].x; sq += t[u].y; }
+  }
+  for (; j < nblk; ++j) { const float2 t = st[j]; sm += t.x; sq += t.y; }
+  out[m] = make_float2(sm, sq);
+}
+
 // ---- LayerNorm: LPR lanes per row (power of two), 64/LPR rows per wave, up to 8 vectors per lane in registers.
 // C = 320/640/1280 -> LPR = 8/16/32 with exactly 5 vectors per lane: every lane busy, 5 loads in flight per lane.
 template <int LPR, bool X2>
@@ -427,6 +448,14 @@ extern "C" int avsd_groupnorm_stats_x2(const void* x1, int ld1, int c1, int64_t 
 extern "C" int avsd_groupnorm_stats(const void* x1, int ld1, int c1, const void* x2, int ld2, int c2, int nb,
                                     int rows_per_batch, int groups, float* scratch, int nchunks, void* stream) {
   return avsd_groupnorm_stats_x2(x1, ld1, c1, 0, x2, ld2, c2, 0, nb, rows_per_batch, groups, scratch, nchunks, stream);
+}
+
+extern "C" int avsd_ln_fold(const float* stats, int M, int nblk, float* out, void* stream) {
+  AVSD_REQUIRE(stats && out && M > 0 && nblk > 0, "ln_fold: bad arguments (M %d, nblk %d)", M, nblk);
+  hipLaunchKernelGGL(ln_fold_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float2*>(stats), M, nblk, reinterpret_cast<float2*>(out));
+  AVSD_CHECK_LAUNCH("ln_fold launch");
+  return AVSD_OK;
 }
 
 extern "C" int avsd_groupnorm_table(const float* scratch, int nchunks, int nb, int rows_per_batch, int groups, int channels,

@@ -536,9 +536,9 @@ def gemm(
         st, colsum, eps = ln
         _req(st, F32, "ln stats")
         _req(colsum, F32, "ln colsum")
-        if not st.is_contiguous() or st.shape[-2:] != (K // 32, 2) or colsum.numel() != N:
+        if not st.is_contiguous() or st.shape[-2:] not in ((K // 32, 2), (1, 2)) or colsum.numel() != N:
             raise ValueError("gemm: ln = (stats [rows, K/32, 2], colsum [N], eps)")
-        d.ln_stats, d.ln_colsum, d.ln_nblk, d.ln_eps = _p(st), _p(colsum), K // 32, float(eps)
+        d.ln_stats, d.ln_colsum, d.ln_nblk, d.ln_eps = _p(st), _p(colsum), st.shape[-2], float(eps)
         d.flags |= LNFUSE
     # XCD banding: the 8 L2s are not shared, so whichever operand is NOT banded is fetched by all 8 of them
     a_bytes = M * (K // 9 if mode == CONV3 else K // 3 if mode == TMIX else K)
@@ -742,6 +742,16 @@ def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], nb: int, rows_per_ba
               "avsd_groupnorm_apply")
     if ev is not None:
         _TIMER.stop(ev, "groupnorm", 0.0, 2.0 * _nbytes(x1, x2) + _nbytes(out))
+    return out
+
+
+def ln_fold(stats: torch.Tensor) -> torch.Tensor:
+    """row statistics [M, K/32, 2] of a ROWSTATS producer -> [M, 1, 2]: the pair a LayerNorm-folding consumer (gemm(ln=...)) would fold
+    itself in every column tile, folded once (same order, same bits)"""
+    _req(stats, F32, "stats")
+    M, nblk = stats.shape[0], stats.shape[1]
+    out = torch.empty((M, 1, 2), dtype=F32, device=stats.device)
+    check(_lib.lib().avsd_ln_fold(_p(stats), M, nblk, _p(out), _stream()), "avsd_ln_fold")
     return out
 
 

@@ -50,6 +50,9 @@ _FUSE_XATTN = os.environ.get("AVSD_FUSE_XATTN", "1") != "0"
 # clips) — the A waves' serial chain (LDS fragment reads, MFMAs, GELU) does not overlap enough to pay for the lost co-residency.
 # Off by default; AVSD_FUSE_FFN=1 switches it on (the packed blob then carries the chunk-major W2).
 _FUSE_FFN = os.environ.get("AVSD_FUSE_FFN", "0") != "0"
+# the GEGLU projection re-folds the K / 32 LayerNorm partials of its rows in each of its 20-80 column tiles (+8-10 us per launch): fold
+# them once in a tiny launch (avsd_ln_fold) and hand it one pair per row
+_LN_PREFOLD = os.environ.get("AVSD_LN_PREFOLD", "1") != "0"
 # Optional (AVSD_SIDE_STREAM=1): independent side work (ResBlock shortcut convolutions, the frame-0 K/V projection of the
 # spatial attention, the time-embedding MLP) on a second HIP stream, forked from and joined back into the main one — parallel
 # branches of the captured hipGraph.  Measured on MI355X: two whole B=1 forwards on two streams take 0.71x their sum
@@ -1197,7 +1200,7 @@ def _transformer(st, x: _Act, p, hw, heads, split: int = 1) -> _Act:
         h = _Act(ops.ffn_block(h.lo, stats[si], p.w1_ln, p.cb1_ln, p.ff2c, p.ff2.b, res=h.res, eps=eps, master=m), m)
     else:
         if fused:
-            g = ops.gemm(h.lo, p.w1_ln, bias=p.b1_ln, geglu=True, ln=(stats[si], p.s1_ln, eps))
+            g = ops.gemm(h.lo, p.w1_ln, bias=p.b1_ln, geglu=True, ln=(ops.ln_fold(stats[si]) if _LN_PREFOLD else stats[si], p.s1_ln, eps))
         else:
             g = ops.gemm(ops.layernorm(h.lo, p.norm3.g, p.norm3.b), p.w1, bias=p.b1, geglu=True)
         h = stream(g, p.ff2.w, p.ff2.b, h, want_stats=False)

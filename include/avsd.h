@@ -147,7 +147,7 @@ typedef struct avsd_gemm_desc {
    * the LayerNorm gain folded in (W' = W * gamma along K), ln_colsum[n] = sum_k W'[n, k], `bias` carries
    * sum_k beta[k] W[n, k] (+ the layer's own bias), and the epilogue computes
    *     v = rstd[m] * (alpha * acc - mean[m] * ln_colsum[n]) + bias[n] + ...
-   * with mean / rstd of row m folded from the ln_nblk (= K / 32) pairs of ln_stats — exactly LayerNorm(A) . W^T + b.
+   * with mean / rstd of row m folded from the ln_nblk (= K / 32, or 1: pre-folded by avsd_ln_fold) pairs of ln_stats — exactly LayerNorm(A) . W^T + b.
    * Batched launches read the statistics of row (batch * batch_stride_a / lda + m). */
   float* rowstats;
   const float* ln_stats;
@@ -293,6 +293,10 @@ int avsd_groupnorm_fused(const void* x1, int ld1, int c1, const void* x2, int ld
 int avsd_groupnorm_nchunks(int nb, int rows_per_batch, int channels);
 int avsd_groupnorm_scratch_floats(int nb, int nchunks, int groups, int channels);
 
+/* Pre-folds the row statistics of AVSD_GEMM_ROWSTATS: stats [M][nblk][2] -> out [M][2] (sum, sumsq over the whole row, added in ascending
+ * block order).  An AVSD_GEMM_LNFUSE consumer given `out` with ln_nblk = 1 computes the same mean / rstd bit for bit without re-folding
+ * nblk pairs per row in every column tile. */
+int avsd_ln_fold(const float* stats, int M, int nblk, float* out, void* stream);
 /* LayerNorm over the last dim (eps 1e-5 in the reference): y = LN(x + pos[f(m)]) with
  * pos == NULL for plain LN; f(m) = (m / hw) % frames.
  * (ff_spatio_audio_temp_transformer_3d.py:300,317,330,354,361) */

@@ -55,7 +55,7 @@ def gemm(a, w, *, n=None, k=None, a2=None, bias=None, rowvec=None, rows_per_vec=
     assert x.shape[1] == wf.shape[1], (x.shape, wf.shape)
     acc = alpha * (x @ wf.T)
     if ln is not None:          # LayerNorm(A) folded in: W carries gamma, bias carries beta . W^T (see avsd.h)
-        acc = _ln_fold(acc, ln, torch.arange(x.shape[0]))
+        acc = _ln_fold(acc, ln, torch.arange(x.shape[0]), x.shape[1])
     if not geglu:
         v = acc
         if bias is not None:
@@ -84,10 +84,9 @@ def gemm(a, w, *, n=None, k=None, a2=None, bias=None, rowvec=None, rows_per_vec=
     return v if out_f32 else v.to(P.ACT)
 
 
-def _ln_fold(acc, ln, rows):
+def _ln_fold(acc, ln, rows, k):
     st, colsum, eps = ln
     st = st.reshape(-1, st.shape[-2], 2)[rows]
-    k = st.shape[1] * 32
     mean = st[..., 0].sum(-1) / k
     rstd = torch.rsqrt((st[..., 1].sum(-1) / k - mean * mean).clamp_min(0) + eps)
     return rstd[:, None] * (acc - mean[:, None] * colsum[None, :])
@@ -107,7 +106,7 @@ def gemm_batched(a, w, *, alpha=1.0, out_f32=False, bias=None, tile=0, ln=None):
         # `a` is a batch of row-views into the tensor the statistics belong to
         assert a.stride(-1) == 1 and a.stride(0) % a.stride(1) == 0
         rows = (torch.arange(a.shape[0])[:, None] * (a.stride(0) // a.stride(1)) + torch.arange(a.shape[1])[None, :]).reshape(-1)
-        v = _ln_fold(v.reshape(-1, v.shape[-1]), ln, rows).reshape(v.shape)
+        v = _ln_fold(v.reshape(-1, v.shape[-1]), ln, rows, a.shape[-1]).reshape(v.shape)
     if bias is not None:
         v = v + bias
     return v if out_f32 else v.to(P.ACT)
@@ -127,6 +126,10 @@ def groupnorm(x1, x2, nb, rows_per_batch, groups, gamma, beta, eps, act, out=Non
     y = F.group_norm(x.reshape(nb, rows_per_batch, C).permute(0, 2, 1), groups, gamma, beta, eps)
     y = F.silu(y) if act else y
     return y.permute(0, 2, 1).reshape(-1, C).to(P.ACT)
+
+
+def ln_fold(stats):
+    return stats.sum(1, keepdim=True)
 
 
 def groupnorm_table(x1, x2, nb, rows_per_batch, groups, gamma, beta, eps):

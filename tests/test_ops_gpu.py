@@ -415,6 +415,10 @@ def test_gemm_layernorm_fusion(ops, tile, split):
     y = ops.gemm(h, wf, bias=bias2, ln=(stats, colsum, 1e-5), tile=tile, split_k=split)
     ref = F.layer_norm(h.float(), (C,), g, be, 1e-5) @ w.T + b
     assert rel_l2(y, ref) < TOL_BF16
+    # statistics pre-folded to one pair per row (avsd_ln_fold): the same bits
+    folded = ops.ln_fold(stats)
+    assert folded.shape == (M, 1, 2)
+    assert torch.equal(y, ops.gemm(h, wf, bias=bias2, ln=(folded, colsum, 1e-5), tile=tile, split_k=split))
     # GEGLU consumer (norm3 -> ff.net.0) and a batched consumer reading a strided subset of rows (norm1 -> to_k/to_v of frame 0)
     from asva_amd.weights import pack_geglu
     w1 = 0.05 * torch.randn(2 * N, C, device=dev())

@@ -21,7 +21,10 @@ for M, C in shapes:
     out_p = torch.empty(M, 8 * C, dtype=torch.bfloat16, device=dev)
     variants = {"plain": lambda t: ops.gemm(h, wp, bias=bp, out=out_p, tile=t),
                 "geglu": lambda t: ops.gemm(h, wp, bias=bp, geglu=True, out=out_g, tile=t),
-                "geglu+ln": lambda t: ops.gemm(h, wp, bias=bp, geglu=True, ln=(stats, cs, 1e-5), out=out_g, tile=t)}
+                "geglu+ln": lambda t: ops.gemm(h, wp, bias=bp, geglu=True, ln=(stats, cs, 1e-5), out=out_g, tile=t),
+                "geglu+ln(prefolded)": lambda t: ops.gemm(h, wp, bias=bp, geglu=True, ln=(folded, cs, 1e-5), out=out_g, tile=t)}
+    folded = ops.ln_fold(stats)
+    print(f"   ln_fold kernel: {ops._time_hot(lambda *_: ops.ln_fold(stats), ()) * 1e3:.1f} us")
     a_l = torch.randn(M, C, device=dev).bfloat16(); w_l = torch.randn(8 * C, C, device=dev).bfloat16()
     torch.matmul(a_l, w_l.t(), out=out_p); torch.cuda.synchronize()
     t_lib = ops._time_hot(lambda tt, sk: torch.matmul(a_l, w_l.t(), out=out_p), (0, 1), reps=8) * 1e3

@@ -71,6 +71,7 @@ const Entry kEntries[] = {
     AVSD_PLAN_ENTRY(avsd_ncfhw_to_rows_x2), AVSD_PLAN_ENTRY(avsd_split_f32),             AVSD_PLAN_ENTRY(avsd_vae_postprocess_x2),
     AVSD_PLAN_ENTRY(avsd_vae_postprocess_u8_x2), AVSD_PLAN_ENTRY(avsd_softmax_rows_x2),
     AVSD_PLAN_ENTRY(avsd_groupnorm_fused),  AVSD_PLAN_ENTRY(avsd_groupnorm_fused_x2),
+    AVSD_PLAN_ENTRY(avsd_groupnorm_table),  AVSD_PLAN_ENTRY(avsd_ln_fold),
 };
 
 struct Reloc {

@@ -92,3 +92,18 @@ def test_plan_bundle_file_format_and_errors(tmp_path):
         path.write_bytes(bad)
         out = ctypes.c_void_p()
         assert h.avsd_plan_bundle_load(str(path).encode(), ctypes.byref(out)) == -1 and msg in h.avsd_last_error(), h.avsd_last_error()
+
+
+def test_every_recordable_entry_point_is_replayable():
+    """asva_amd/plan.py records every launching entry point it sees; csrc/plan.hip replays only those in its table — they must agree"""
+    import re
+    from asva_amd import _lib, plan
+
+    src = open(os.path.join(os.path.dirname(__file__), "..", "asva_amd", "csrc", "plan.hip")).read()
+    table = set(re.findall(r"AVSD_PLAN_ENTRY(?:_DESC)?\((avsd_\w+)", src))
+    recordable = {n for n in _lib.SIGNATURES
+                  if n not in plan._NOT_RECORDED and not n.startswith(("avsd_plan_", "avsd_unet_")) and n != "avsd_vae_decode"}
+    # queries that never launch and so never reach a plan
+    recordable -= {n for n in recordable if n.startswith("avsd_sizeof_") or n.endswith("_supported")}
+    missing = {n for n in recordable if n not in table}
+    assert not missing - {"avsd_gemm_f32"}, sorted(missing)

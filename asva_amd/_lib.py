@@ -95,6 +95,7 @@ SIGNATURES = {
     "avsd_gemm_rowpanel_supported": (c_int, [c_int, c_int, c_int]),
     "avsd_gemm_conv3r_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "avsd_gemm_conv3r2d_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "avsd_gemm_tmixr_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "avsd_gemm_conv3r_gn_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "avsd_cross_attention_block_supported": (c_int, [c_int, c_int, c_int]),
     "avsd_sizeof_xattn_desc": (c_int, []),

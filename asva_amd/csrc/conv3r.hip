@@ -617,6 +617,237 @@ int launch_r2d(const avsd_gemm_desc& d, hipStream_t s) {
   return AVSD_OK;
 }
 
+// ---- temporal-mix GEMM with the (all frames x 32 pixels) tile resident ------------------------------------------------------
+// FFInflatedConv3d's Linear(3C -> C) (utils.py:43-53) reads, for output row (b, f, p), the rows (b, 0, p), (b, max(f - 1, 0), p) and
+// (b, f, p) of its input: a tile of BM consecutive rows (gemm2_kernel<TMIX>) fetches three different row sets for the three K segments.
+// A tile of ALL 12 frames x 32 pixels holds every row its three segments need: each chunk of 64 channels is staged once
+// (12 x 32 positions, position i = f * 32 + px) and read three times — fragment b of wave row wm is frame f = 3 wm + b, its segment-s
+// operand is frame {0, max(f - 1, 0), f}[s] of the same staged image.  The rest is the 2-D convolution kernel above with 3 "taps"
+// per chunk: weight ring, loader waves, double-buffered chunks, split-K over chunks; a wave's fragments lie one FRAME (hw rows) apart
+// in M — the epilogue's `mstride`.  K order chunk-major / segment-minor (other f32 order than the segment-major tiles).
+template <int BN, int WN, int STAGES, int LW>
+__global__ __launch_bounds__(64 * (4 * WN + LW)) void tmixr_kernel(const avsd_gemm_desc p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smemt[];
+  constexpr int F = 12, WM = 4, FM = 3;
+  constexpr int NC = WM * WN;
+  constexpr int NWAVES = LW > 0 ? LW : NC;
+  constexpr int PAC = (F * 32 / 8) / NWAVES;
+  static_assert(PAC * NWAVES * 8 == F * 32, "staged pieces must split evenly over the loading waves");
+  constexpr int A_BYTES = F * 32 * 128;
+  constexpr int W_BYTES = BN * 128;
+  constexpr int PW = (BN / 8) / NWAVES;
+  static_assert(PW * NWAVES * 8 == BN, "weight tile rows must split evenly into 1-KiB pieces per loading wave");
+  static_assert((STAGES - 2) * PW + PAC < 64, "vmcnt is a 6-bit counter");
+  constexpr int FN = BN / WN / 32;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_loader = LW == 0 || wave_all >= NC;
+  const int wave = LW == 0 ? wave_all : (wave_all >= NC ? wave_all - NC : 0);
+  const int wm = wave_all % WM;
+  const int wn = (wave_all / WM) % WN;
+
+  const int hw = p.hw;
+  const int tpb = hw / 32;
+  const int ntm = (p.M / (F * hw)) * tpb;
+  const int ntn = (p.N + BN - 1) / BN;
+  const int nwg = ntm * ntn;
+  const int nsplit = p.split_k > 1 ? p.split_k : 1;
+  int wg, ksplit;
+  {
+    const int total = nwg * nsplit;
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q = total >> 3, r = total & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int c = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    wg = c / nsplit;
+    ksplit = c - wg * nsplit;
+  }
+  const bool nmaj = (p.flags & AVSD_GEMM_XCD_N) != 0;
+  const int tn = nmaj ? wg / ntm : wg % ntn;
+  const int tm = nmaj ? wg % ntm : wg / ntn;
+  const int bb = tm / tpb;
+  const int p0 = (tm - bb * tpb) * 32;
+  const int row00 = bb * F * hw + p0;                          // row of (frame 0, pixel p0)
+
+  const int nchunks = p.cseg >> 6;
+  const int per_split = (nchunks + nsplit - 1) / nsplit;
+  const int c0 = ksplit * per_split;
+  const int c1 = min(nchunks, c0 + per_split);
+  const int nk = max(c1 - c0, 0) * 3;
+
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+
+  static_assert((4 * NWAVES) % 8 == 0, "piece stride must keep the swizzle phase");
+  const int a_i0 = 2 * (wave * 4 + (lane >> 4)) + ((lane & 15) >> 3);
+  const int a_ch8 = (((lane & 15) & 7) ^ ((wave * 4 + (lane >> 4)) & 7)) * 8;
+  int wo[PW];
+  bool wv[PW];
+#pragma unroll
+  for (int j = 0; j < PW; ++j) {
+    const int L = (wave + j * NWAVES) * 4 + (lane >> 4);
+    const int x = (lane & 15) ^ (L & 15);
+    const int n = tn * BN + 2 * L + (x >> 3);
+    wv[j] = n < p.N;
+    wo[j] = n * p.ldw + (x & 7) * 8;
+  }
+  auto issue_a = [&](int chunk) {
+    unsigned char* ab = smemt + (chunk & 1) * A_BYTES;
+    const int coff = a_ch8 + chunk * 64;
+#pragma unroll
+    for (int j = 0; j < PAC; ++j) {
+      const int i = a_i0 + j * 8 * NWAVES;
+      const int row = row00 + (i >> 5) * hw + (i & 31);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(ab + (wave + j * NWAVES) * 1024), 16, (row * p.lda + coff) * 2, 0, 0, 0);
+    }
+  };
+  int i_t = 0, i_chunk = c0, i_seg = 0;
+  auto issue_w = [&]() {
+    unsigned char* sb = smemt + 2 * A_BYTES + (i_t % STAGES) * W_BYTES;
+    const int kbase = i_seg * p.cseg + i_chunk * 64;
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      const unsigned vo = wv[j] ? (unsigned)(wo[j] + kbase) * 2u : OOBR;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(sb + (wave + j * NWAVES) * 1024), 16, (int)vo, 0, 0, 0);
+    }
+    ++i_t;
+    if (++i_seg == 3) { i_seg = 0; ++i_chunk; }
+  };
+  auto wait_tile = [&](int kt) {
+    const int nw = min(STAGES - 2, nk - 1 - kt);
+    bool a = false;
+#pragma unroll
+    for (int d = 1; d <= STAGES - 2; ++d) {
+      const int j = kt - d;
+      if (j >= 0 && j % 3 == 0 && c0 + j / 3 + 1 < c1) a = true;
+    }
+    wait_ring<STAGES - 2, PW, PAC>(nw, a);
+  };
+  static_assert(STAGES - 1 <= 3, "the A chunk issued at segment 0 must precede the W tile waited for at the next chunk's segment 0");
+
+  if (is_loader && nk > 0) {
+    issue_a(c0);
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+      if (s < nk) issue_w();
+  }
+  if (LW > 0 && is_loader) {
+    int seg = 0, chunk = c0;
+    for (int kt = 0; kt < nk; ++kt) {
+      wait_tile(kt);
+      __builtin_amdgcn_s_barrier();
+      if (seg == 0 && chunk + 1 < c1) issue_a(chunk + 1);
+      if (kt + STAGES - 1 < nk) issue_w();
+      if (++seg == 3) { seg = 0; ++chunk; }
+    }
+    return;
+  }
+
+  f32x16 acc[FN][FM];
+#pragma unroll
+  for (int a = 0; a < FN; ++a)
+#pragma unroll
+    for (int b = 0; b < FM; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  int w_line[FN], w_sw[FN], w_hi[FN];
+#pragma unroll
+  for (int a = 0; a < FN; ++a) {
+    const int r = wn * (BN / WN) + a * 32 + (lane & 31);
+    w_line[a] = (r >> 1) * 256;
+    w_sw[a] = (r >> 1) & 15;
+    w_hi[a] = (r & 1) << 3;
+  }
+  const int chalf = lane >> 5;
+
+  int seg = 0, chunk = c0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (LW == 0) wait_tile(kt);
+    __builtin_amdgcn_s_barrier();
+    if (LW == 0) {
+      if (seg == 0 && chunk + 1 < c1) issue_a(chunk + 1);
+      if (kt + STAGES - 1 < nk) issue_w();
+    }
+    const int abuf = (chunk & 1) * A_BYTES;
+    int xa_base[FM], xa_sw[FM];
+#pragma unroll
+    for (int b = 0; b < FM; ++b) {
+      const int f = wm * FM + b;
+      const int g = seg == 0 ? 0 : (seg == 1 ? max(f - 1, 0) : f);
+      const int i = g * 32 + (lane & 31);
+      xa_base[b] = abuf + (i >> 1) * 256 + ((i & 1) << 7);
+      xa_sw[b] = (i >> 1) & 7;
+    }
+    const unsigned char* sW = smemt + 2 * A_BYTES + (kt % STAGES) * W_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int c = ks * 2 + chalf;
+      h16x8 xf[FM], wf[FN];
+#pragma unroll
+      for (int b = 0; b < FM; ++b)
+        xf[b] = *reinterpret_cast<const h16x8*>(smemt + xa_base[b] + ((c ^ xa_sw[b]) << 4));
+#pragma unroll
+      for (int a = 0; a < FN; ++a)
+        wf[a] = *reinterpret_cast<const h16x8*>(sW + w_line[a] + (((w_hi[a] | c) ^ w_sw[a]) << 4));
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FM; ++b)
+          acc[a][b] = mfma32x32x16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    if (++seg == 3) { seg = 0; ++chunk; }
+  }
+
+  const int m_wave = row00 + wm * FM * hw;
+  if (p.split_k > 1) {
+    float* wsl = p.splitk_ws + (int64_t)ksplit * p.M * p.N;
+    const int hsel = (lane >> 5) * 4;
+#pragma unroll
+    for (int b = 0; b < FM; ++b) {
+      const int m = m_wave + b * hw + (lane & 31);
+#pragma unroll
+      for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = tn * BN + wn * (BN / WN) + a * 32 + 8 * q + hsel;
+          if (n < p.N)
+            *reinterpret_cast<float4*>(wsl + (int64_t)m * p.N + n) =
+                make_float4(acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]);
+        }
+    }
+    return;
+  }
+  const float pre_ln[2 * FM] = {};
+  epilogue<FN, FM, (64 * (4 * WN + LW) > 512)>(p, acc, m_wave, tn * BN + wn * (BN / WN), lane, 0, pre_ln, false, hw);
+}
+
+template <int BN, int WN, int STAGES, int LW>
+int launch_tmixr(const avsd_gemm_desc& d, hipStream_t s) {
+  constexpr size_t lds = (size_t)2 * 12 * 32 * 128 + (size_t)STAGES * BN * 128;
+  static_assert(lds <= 160 * 1024, "tile does not fit the 160 KB of LDS");
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tmixr_kernel<BN, WN, STAGES, LW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      avsd_set_error("tmixr: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+      return AVSD_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  const int ntm = (d.M / (12 * d.hw)) * (d.hw / 32), ntn = (d.N + BN - 1) / BN;
+  const int nsplit = d.split_k > 1 ? d.split_k : 1;
+  dim3 grid((unsigned)(ntm * ntn), (unsigned)nsplit, 1);
+  hipLaunchKernelGGL((tmixr_kernel<BN, WN, STAGES, LW>), grid, dim3(64 * (4 * WN + LW)), lds, s, d);
+  AVSD_CHECK_LAUNCH("tmixr launch");
+  if (nsplit > 1) return avsd_gemm_splitk_reduce(d, s);
+  return AVSD_OK;
+}
+
 template <int BM, int BN, int WM, int WN, int STAGES, int LW, bool GN = false>
 int launch_r(const avsd_gemm_desc& d, hipStream_t s) {
   constexpr int NWAVES = LW > 0 ? LW : WM * WN;
@@ -722,4 +953,26 @@ extern "C" int avsd_gemm_conv3r2d_supported(int tile, int hs, int ws, int cin) {
   const int k = tile - AVSD_GEMM_TILE_CONV3R2D_FIRST;
   if (k < 0 || k >= 4 || cin % 64 != 0 || ws <= 0 || hs <= 0 || ws % 32 != 0 || hs % (bm[k] / 32) != 0) return 0;
   return bm[k];
+}
+
+// rows per tile (384 = 12 frames x 32 pixels) if the resident temporal-mix tile `tile` takes this geometry, else 0
+extern "C" int avsd_gemm_tmixr_supported(int tile, int hw, int frames, int cseg) {
+  if (tile < AVSD_GEMM_TILE_TMIXR_FIRST || tile > AVSD_GEMM_TILE_TMIXR_LAST) return 0;
+  return (frames == 12 && hw > 0 && hw % 32 == 0 && cseg > 0 && cseg % 64 == 0) ? 384 : 0;
+}
+
+int avsd_gemm_dispatch_tmixr(const avsd_gemm_desc& d, hipStream_t s) {
+  AVSD_REQUIRE(d.mode == AVSD_GEMM_TMIX && d.batch == 1 && !d.A2 && !d.splitk_cnt &&
+                   !(d.flags & (AVSD_GEMM_X2 | AVSD_GEMM_GEGLU | AVSD_GEMM_LNFUSE | AVSD_GEMM_GNFUSE)),
+               "gemm/tmixr: 16-bit temporal-mix descriptors only (no split precision, GEGLU, LayerNorm fold, batching)");
+  AVSD_REQUIRE(avsd_gemm_tmixr_supported(d.tile, d.hw, d.frames, d.cseg) != 0,
+               "gemm/tmixr: 12 frames, hw %% 32 == 0, cseg %% 64 == 0 (got frames %d, hw %d, cseg %d)", d.frames, d.hw, d.cseg);
+  AVSD_REQUIRE(d.split_k <= 1 || (d.splitk_ws && d.split_k <= d.cseg / 64), "gemm/tmixr: split_k (%d) needs a workspace and <= %d channel chunks", d.split_k, d.cseg / 64);
+  AVSD_REQUIRE((double)d.M * d.lda * 2.0 < 2147483648.0 && (double)d.N * d.ldw * 2.0 < 2147483648.0, "gemm/tmixr: operands must be < 2 GiB");
+  switch (d.tile - AVSD_GEMM_TILE_TMIXR_FIRST) {
+    case 0: return launch_tmixr<128, 2, 3, 0>(d, s);      // 384 x 128: 96x64 wave tiles, 8 waves load and multiply, 144 KB
+    case 1: return launch_tmixr<64, 2, 4, 4>(d, s);       // 384 x 64: 96x32 wave tiles, 128 KB
+    case 2: return launch_tmixr<64, 2, 4, 0>(d, s);       // 384 x 64: 96x32 wave tiles, 8 waves load and multiply
+    default: AVSD_REQUIRE(false, "gemm/tmixr: unknown tile %d", d.tile);
+  }
 }

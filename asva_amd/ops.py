@@ -118,6 +118,24 @@ CONV3R_SPLITS = (1, 2, 4, 5, 8, 10)
 _CONV3R = os.environ.get("AVSD_CONV3R", "1") != "0"
 
 
+TMIXR_TILES = (55, 56, 57)   # temporal-mix GEMM with the (12 frames x 32 pixels) tile resident (csrc/conv3r.hip tmixr_kernel)
+_TMIXR_BN = {55: 128, 56: 64, 57: 64}
+_TMIXR = os.environ.get("AVSD_TMIXR", "0") != "0"     # selectable, not a tuner candidate: 0.71-1.05x of the tuned tiles (profiles/r3_tmixr_probe.txt)
+
+
+def tmixr_candidates(hw: int, frames: int, cseg: int, M: int, N: int):
+    out = []
+    for t in TMIXR_TILES:
+        if _lib.lib().avsd_gemm_tmixr_supported(t, hw, frames, cseg) <= 0:
+            continue
+        wgs = (M // 384) * ((N + _TMIXR_BN[t] - 1) // _TMIXR_BN[t])
+        for sk in (1, 2, 4, 5):
+            if sk > 1 and (wgs >= 256 or (cseg // 64) // sk < 2 or (cseg // 64) % sk != 0):
+                continue
+            out.append((t, sk))
+    return tuple(out)
+
+
 TILE_ROWPANEL = 50          # csrc/rowpanel.hip: 96-row panels with the activation resident, PLAIN K <= 320 (the C = 320 linear layers)
 _ROWPANEL = os.environ.get("AVSD_ROWPANEL", "0") != "0"    # selectable, not a tuner candidate: 0.8-1.0x of the tuned tiles (profiles/r3_rowpanel_probe.txt)
 _CONV3R_BN = (128, 128, 160, 160, 128, 128, 256, 320, 256, 64)
@@ -589,6 +607,8 @@ def gemm(
         splitk_ok = not geglu and not two_src_unaligned
         if (_ROWPANEL and mode == PLAIN and a2 is None and not P.SPLIT and M >= 96 * 64 and _lib.lib().avsd_gemm_rowpanel_supported(M, N, K) > 0):
             cands = cands + ((TILE_ROWPANEL, 1),)
+        if _TMIXR and mode == TMIX and not P.SPLIT:
+            cands = cands + tmixr_candidates(d.hw, d.frames, d.cseg, M, N)
         if gn is not None or (mode == CONV3 and a2 is not None):
             cands = conv3r_candidates(d.hs, d.ws, d.cin, M, N, gn=(d.k_split if a2 is not None else d.cin, d.gn_rows_per_batch) if gn is not None else None)
             if not cands:
@@ -601,6 +621,8 @@ def gemm(
             key = key + (d.hs, d.ws)
         picked = _pick_tile(key, _launch, cands, warm=(a, a2, res1, res2))
         if picked is not None and picked[0] in CONV3R_TILES and not ((_CONV3R or gn is not None or a2 is not None) and _lib.lib().avsd_gemm_conv3r_supported(picked[0], d.hs, d.ws, d.cin)):
+            picked = None
+        if picked is not None and picked[0] in TMIXR_TILES and not (mode == TMIX and _lib.lib().avsd_gemm_tmixr_supported(picked[0], d.hw, d.frames, d.cseg)):
             picked = None
         if picked is not None and picked[0] in CONV3R2D_TILES and not (_CONV3R and _lib.lib().avsd_gemm_conv3r2d_supported(picked[0], d.hs, d.ws, d.cin)):
             picked = None

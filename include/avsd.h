@@ -106,6 +106,11 @@ enum { AVSD_GEMM_GEGLU = 1, AVSD_GEMM_OUT_F32 = 2, AVSD_GEMM_GELU = 4, AVSD_GEMM
  * otherwise as the ids above, without the GroupNorm prologue. */
 #define AVSD_GEMM_TILE_CONV3R2D_FIRST 51
 #define AVSD_GEMM_TILE_CONV3R2D_LAST 54
+/* temporal-mix GEMM with the (12 frames x 32 pixels) tile resident (conv3r.hip, tmixr_kernel): each 64-channel chunk is staged once
+ * and read by the three K segments (frame 0 / previous / current).  TMIX descriptors with 12 frames, hw % 32 == 0, cseg % 64 == 0
+ * (avsd_gemm_tmixr_supported); split_k cuts the channel chunks; no AVSD_GEMM_X2. */
+#define AVSD_GEMM_TILE_TMIXR_FIRST 55
+#define AVSD_GEMM_TILE_TMIXR_LAST 57
 
 typedef struct avsd_gemm_desc {
   const void* A;        /* bf16 */
@@ -179,6 +184,7 @@ int avsd_gemm_rowpanel_supported(int M, int N, int K);
 /* rows per tile of conv3r tile id `tile` if an (hs x ws)-pixel image with cin channels can use it, else 0 */
 int avsd_gemm_conv3r_supported(int tile, int hs, int ws, int cin);
 int avsd_gemm_conv3r2d_supported(int tile, int hs, int ws, int cin);
+int avsd_gemm_tmixr_supported(int tile, int hw, int frames, int cseg);
 /* the same for a descriptor with AVSD_GEMM_GNFUSE: only tiles with loader waves (40, 42, 43, 44) qualify, a normalisation batch
  * must be whole tiles, and a two-source input (c1 != cin channels in the first) needs c1 % 64 == 0 */
 int avsd_gemm_conv3r_gn_supported(int tile, int hs, int ws, int cin, int c1, int rows_per_batch);

@@ -381,6 +381,42 @@ def test_gemm_conv3_resident_2d(ops, n_img, hs, ws, cin, cout, split, tile):
         assert torch.equal(o2, o32)
 
 
+@pytest.mark.parametrize("tile", [55, 56, 57])
+@pytest.mark.parametrize("B,hw,C,N,split", [(2, 64, 320, 320, 1), (1, 32, 128, 132, 2), (3, 96, 64, 64, 1), (2, 32, 640, 640, 5)])
+def test_gemm_tmix_resident(ops, B, hw, C, N, split, tile):
+    """conv3r.hip tmixr_kernel: the temporal-mix GEMM over (12 frames x 32 pixels) tiles, each channel chunk staged once for its
+    three segments — against the f32 statement and the segment-major tile 6; full epilogue (bias, time-embedding row vector, two residuals)"""
+    Fr = 12
+    M = B * Fr * hw
+    y = rnd(M, C, seed=1)
+    w = rnd(N, 3 * C, seed=2, scale=(3 * C) ** -0.5)
+    b = rndf(N, seed=3)
+    res2 = rnd(M, N, seed=4)
+    temb = rndf(B, N, seed=5)
+    y5 = y.float().reshape(B, Fr, hw, C)
+    prev = torch.cat([y5[:, :1], y5[:, :-1]], 1)
+    cat = torch.cat([y5[:, :1].expand_as(y5), prev, y5], -1).reshape(M, 3 * C)
+    ref = cat @ w.float().T + b + temb.repeat_interleave(Fr * hw, 0) + res2.float()
+    kw = dict(bias=b, rowvec=temb, rows_per_vec=Fr * hw, res2=res2, mode=ops.TMIX, tmix=(hw, Fr))
+    if N == C:
+        kw["res1"] = y
+        ref = ref + y.float()
+    out = ops.gemm(y, w, tile=tile, split_k=split, **kw)
+    assert rel_l2(out, ref) < TOL_BF16
+    o32 = ops.gemm(y, w, out_f32=True, tile=tile, split_k=split, **kw)
+    assert rel_l2(o32, ref) < TOL_F32
+    assert rel_l2(o32, ops.gemm(y, w, out_f32=True, tile=6, **kw)) < TOL_F32
+    assert torch.equal(o32, ops.gemm(y, w, out_f32=True, tile=tile, split_k=split, **kw))
+
+
+def test_gemm_tmix_resident_refuses(ops):
+    y = rnd(2 * 4 * 64, 64, seed=1)
+    with pytest.raises(RuntimeError):                 # 4 frames
+        ops.gemm(y, rnd(64, 192, seed=2), mode=ops.TMIX, tmix=(64, 4), tile=55)
+    with pytest.raises(RuntimeError):                 # 16 pixels per frame
+        ops.gemm(rnd(12 * 16, 64, seed=1), rnd(64, 192, seed=2), mode=ops.TMIX, tmix=(16, 12), tile=56)
+
+
 def test_gemm_conv3_resident_refuses_other_convolutions(ops):
     from asva_amd.weights import pack_conv3x3
 

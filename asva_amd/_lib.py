@@ -37,12 +37,11 @@ class GemmDesc(C.Structure):
         ("hs", C.c_int32), ("ws", C.c_int32), ("ho", C.c_int32), ("wo", C.c_int32),
         ("cin", C.c_int32), ("stride", C.c_int32), ("ups", C.c_int32), ("pad", C.c_int32),
         ("tile", C.c_int32),
-        ("split_k", C.c_int32), ("splitk_ws", c_void_p), ("splitk_cnt", c_void_p),
+        ("split_k", C.c_int32), ("splitk_ws", c_void_p),
         ("rowstats", c_void_p), ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("ln_nblk", C.c_int32), ("ln_eps", C.c_float),
         ("out_master", c_void_p), ("ldm", C.c_int32), ("reserved0", C.c_int32),
         ("a_lo", C.c_int64), ("a2_lo", C.c_int64), ("w_lo", C.c_int64), ("out_lo", C.c_int64), ("res1_lo", C.c_int64),
         ("res2_lo", C.c_int64),
-        ("gn_table", c_void_p), ("gn_rows_per_batch", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -65,24 +64,6 @@ class XAttnDesc(C.Structure):
     ]
 
 
-class FfnDesc(C.Structure):
-    """Mirror of `avsd_ffn_desc` (include/avsd.h)."""
-
-    _fields_ = [
-        ("h", c_void_p), ("ldh", C.c_int32), ("res_f32", C.c_int32),
-        ("res", c_void_p), ("ldres", C.c_int32), ("M", C.c_int32),
-        ("C", C.c_int32), ("nh", C.c_int32),
-        ("ln_stats", c_void_p), ("ln_eps", C.c_float), ("ldw1", C.c_int32),
-        ("w1", c_void_p),
-        ("cb1", c_void_p),
-        ("w2c", c_void_p),
-        ("bias2", c_void_p),
-        ("out", c_void_p), ("ldo", C.c_int32), ("ldm", C.c_int32),
-        ("out_master", c_void_p),
-        ("rowstats", c_void_p),
-    ]
-
-
 # name -> (restype, argtypes); exactly the symbols include/avsd.h declares
 SIGNATURES = {
     "avsd_abi_version": (c_int, []),
@@ -92,22 +73,15 @@ SIGNATURES = {
     "avsd_gemm_bf16": (c_int, [C.POINTER(GemmDesc), c_void_p]),
     "avsd_sizeof_gemm_desc": (c_int, []),
     "avsd_cross_attention_block": (c_int, [C.POINTER(XAttnDesc), c_void_p]),
-    "avsd_gemm_rowpanel_supported": (c_int, [c_int, c_int, c_int]),
     "avsd_gemm_conv3r_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "avsd_gemm_conv3r2d_supported": (c_int, [c_int, c_int, c_int, c_int]),
-    "avsd_gemm_tmixr_supported": (c_int, [c_int, c_int, c_int, c_int]),
-    "avsd_gemm_conv3r_gn_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "avsd_cross_attention_block_supported": (c_int, [c_int, c_int, c_int]),
     "avsd_sizeof_xattn_desc": (c_int, []),
-    "avsd_ffn_block": (c_int, [C.POINTER(FfnDesc), c_void_p]),
-    "avsd_ffn_block_supported": (c_int, [c_int, c_int]),
-    "avsd_sizeof_ffn_desc": (c_int, []),
     "avsd_linear_small_m": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "avsd_groupnorm_stats": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "avsd_groupnorm_apply": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                      c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "avsd_ln_fold": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
-    "avsd_groupnorm_table": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     "avsd_groupnorm_fused_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "avsd_groupnorm_fused": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                      c_int, c_void_p, c_int, c_void_p]),
@@ -204,10 +178,6 @@ def lib() -> C.CDLL:
         if handle.avsd_sizeof_xattn_desc() != C.sizeof(XAttnDesc):
             raise AvsdError(
                 f"avsd_xattn_desc layout mismatch: C {handle.avsd_sizeof_xattn_desc()} B vs ctypes {C.sizeof(XAttnDesc)} B"
-            )
-        if handle.avsd_sizeof_ffn_desc() != C.sizeof(FfnDesc):
-            raise AvsdError(
-                f"avsd_ffn_desc layout mismatch: C {handle.avsd_sizeof_ffn_desc()} B vs ctypes {C.sizeof(FfnDesc)} B"
             )
         if handle.avsd_precision().decode() != P.NAME:
             raise AvsdError(f"{path} computes in {handle.avsd_precision().decode()}, expected {P.NAME}")

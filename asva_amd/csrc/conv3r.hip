@@ -52,25 +52,22 @@ __device__ __forceinline__ void wait_ring(int nw, bool a) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int LW, bool GN = false>
+template <int BM, int BN, int WM, int WN, int STAGES, int LW>
 __global__ __launch_bounds__(64 * (WM * WN + LW)) void conv3r_kernel(const avsd_gemm_desc p) {
-  static_assert(!GN || LW > 0, "the GroupNorm prologue runs on the loader waves");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smemr[];
   constexpr int NC = WM * WN;
   constexpr int NWAVES = LW > 0 ? LW : NC;
   constexpr int AR_MAX = BM + HALO_MAX;
   constexpr int PAC = (AR_MAX / 8 + NWAVES - 1) / NWAVES;     // A pieces per loading wave per chunk
-  constexpr int PACT = PAC + (GN ? 1 : 0);                    // + this wave's copy of the chunk's (scale, shift) table
   constexpr int A_BYTES = PAC * NWAVES * 1024;
   constexpr int W_BYTES = BN * 128;
   constexpr int PW = (BN / 8) / NWAVES;
   static_assert(PW * NWAVES * 8 == BN, "weight tile rows must split evenly into 1-KiB pieces per loading wave");
-  static_assert((STAGES - 2) * PW + PACT < 64, "vmcnt is a 6-bit counter");
+  static_assert((STAGES - 2) * PW + PAC < 64, "vmcnt is a 6-bit counter");
   static_assert(STAGES >= 2 && STAGES <= 9, "ring depth");
   constexpr int FM = BM / WM / 32;
   constexpr int FN = BN / WN / 32;
   constexpr int ZERO_OFF = 2 * A_BYTES + STAGES * W_BYTES;    // one zeroed 256-byte line
-  constexpr int TBL_OFF = ZERO_OFF + 256;                     // GN: [2 buffers][NWAVES] x 1 KiB: 64 channels x (scale, shift) f32
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -116,8 +113,6 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void conv3r_kernel(const avsd_
   const bool two = p.A2 != nullptr;
   const int csplit = two ? (p.k_split >> 6) : nchunks;
   const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(two ? p.A2 : p.A), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc((void*)(GN ? (const void*)p.gn_table : p.A), 0, 0x7fffffff, 0x00020000);
-  const int gn_b = GN ? m0 / p.gn_rows_per_batch : 0;        // the tile lies inside one normalisation batch (host-checked)
 
   if (tid < 64) *reinterpret_cast<unsigned*>(smemr + ZERO_OFF + tid * 4) = 0u;
   __syncthreads();                            // (before any load is in flight: this waits for vmcnt(0) too)
@@ -153,34 +148,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void conv3r_kernel(const avsd_
       if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, dst, 16, (int)vo, 0, 0, 0);
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, dst, 16, (int)vo, 0, 0, 0);
     }
-    if constexpr (GN) {      // 64 channels x (scale, shift) = 512 B: lanes 0-31 fetch 16 B each, the rest zero-fill
-      const unsigned vo = lane < 32 ? (unsigned)((gn_b * p.cin + chunk * 64) * 8 + lane * 16) : OOBR;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsT, (lds_ptr_t)(smemr + TBL_OFF + ((chunk & 1) * NWAVES + wave) * 1024), 16, (int)vo, 0, 0, 0);
-    }
   };
-  // GN: SiLU(x * scale[c] + shift[c]) in place on one staged 1-KiB piece `pc` of A buffer `buf`.  Same f32 formula and rounding
-  // as gn_apply_kernel.  (Zero-filled and neighbour rows are transformed too: no valid tap reads them.)  A lane's 8 channels
-  // are the same in every piece a wave handles (the piece stride is even, so the swizzle phase L & 7 does not change): the 16
-  // table values are fetched once per chunk (load_tbl) and stay in registers.
-  float gsc[8], gsh[8];
-  auto load_tbl = [&](int buf, int pc0, int tw) {
-    const int L = pc0 * 4 + (lane >> 4);
-    const int ch = (lane & 7) ^ (L & 7);
-    const float4* tb = reinterpret_cast<const float4*>(smemr + TBL_OFF + (buf * NWAVES + tw) * 1024 + ch * 64);
-    const float4 t0 = tb[0], t1 = tb[1], t2 = tb[2], t3 = tb[3];
-    gsc[0] = t0.x; gsc[1] = t0.z; gsc[2] = t1.x; gsc[3] = t1.z; gsc[4] = t2.x; gsc[5] = t2.z; gsc[6] = t3.x; gsc[7] = t3.z;
-    gsh[0] = t0.y; gsh[1] = t0.w; gsh[2] = t1.y; gsh[3] = t1.w; gsh[4] = t2.y; gsh[5] = t2.w; gsh[6] = t3.y; gsh[7] = t3.w;
-  };
-  auto xform_piece = [&](int buf, int pc) {
-    unsigned char* pp = smemr + buf * A_BYTES + pc * 1024 + lane * 16;
-    const uint4 v = *reinterpret_cast<const uint4*>(pp);
-    float f[8];
-    unpack8(v, f);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = silu_f(fmaf(f[e], gsc[e], gsh[e]));
-    *reinterpret_cast<uint4*>(pp) = pack8(f);
-  };
-  auto lds_drain = [&]() { __builtin_amdgcn_s_waitcnt(0xc07f); asm volatile("" ::: "memory"); };   // lgkmcnt(0)
   int i_t = 0, i_chunk = c0, i_tap = 0;       // next W tile to issue
   auto issue_w = [&]() {
     unsigned char* sb = smemr + 2 * A_BYTES + (i_t % STAGES) * W_BYTES;
@@ -203,7 +171,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void conv3r_kernel(const avsd_
       const int j = kt - d;
       if (j >= 0 && j % 9 == 0 && c0 + j / 9 + 1 < c1) a = true;
     }
-    wait_ring<STAGES - 2, PW, PACT>(nw, a);
+    wait_ring<STAGES - 2, PW, PAC>(nw, a);
   };
 
   if (is_loader && nk > 0) {
@@ -212,43 +180,13 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void conv3r_kernel(const avsd_
     for (int s = 0; s < STAGES - 1; ++s)
       if (s < nk) issue_w();
   }
-  if constexpr (GN) {
-    // first chunk: nothing to hide it behind — every wave of the block transforms a share once the loaders' pieces have landed
-    if (nk > 0) {
-      if (is_loader) wait_vmcnt<(STAGES - 1) * PW>();          // nk >= 9 > STAGES - 1: all prologue W tiles were issued
-      __builtin_amdgcn_s_barrier();
-      static_assert((NC + LW) % 2 == 0, "piece stride must keep the swizzle phase");
-      load_tbl(c0 & 1, wave_all, 0);
-      for (int pc = wave_all; pc < PAC * NWAVES; pc += NC + LW) xform_piece(c0 & 1, pc);
-      lds_drain();
-    }
-  }
   if (LW > 0 && is_loader) {
-    // GN: the pieces of chunk c + 1 (issued at tap 0, landed by the time the W tile of tap STAGES - 1 has) are transformed by the
-    // wave that fetched them, PPI per iteration from tap STAGES - 1 on: hidden beside the MFMA waves' matrix work
-    constexpr int TS = STAGES - 1;
-    constexpr int PPI = (PAC + (9 - TS) - 1) / (9 - TS);
     int tap = 0, chunk = c0;
     for (int kt = 0; kt < nk; ++kt) {
       wait_tile(kt);
       __builtin_amdgcn_s_barrier();
       if (tap == 0 && chunk + 1 < c1) issue_a(chunk + 1);
       if (kt + STAGES - 1 < nk) issue_w();
-      if constexpr (GN) {
-        if (tap >= TS && chunk + 1 < c1) {
-          // above the MFMA waves' s_setprio(1): at equal or lower priority this wave's VALU work waits for issue slots behind
-          // two waves that issue back to back, and its late arrival at the barrier stalls them all
-          __builtin_amdgcn_s_setprio(3);
-          if (tap == TS) load_tbl((chunk + 1) & 1, wave, wave);
-#pragma unroll
-          for (int u = 0; u < PPI; ++u) {
-            const int j = (tap - TS) * PPI + u;
-            if (j < PAC) xform_piece((chunk + 1) & 1, wave + j * NWAVES);
-          }
-          lds_drain();
-          __builtin_amdgcn_s_setprio(0);
-        }
-      }
       if (++tap == 9) { tap = 0; ++chunk; }
     }
     return;
@@ -617,249 +555,17 @@ int launch_r2d(const avsd_gemm_desc& d, hipStream_t s) {
   return AVSD_OK;
 }
 
-// ---- temporal-mix GEMM with the (all frames x 32 pixels) tile resident ------------------------------------------------------
-// FFInflatedConv3d's Linear(3C -> C) (utils.py:43-53) reads, for output row (b, f, p), the rows (b, 0, p), (b, max(f - 1, 0), p) and
-// (b, f, p) of its input: a tile of BM consecutive rows (gemm2_kernel<TMIX>) fetches three different row sets for the three K segments.
-// A tile of ALL 12 frames x 32 pixels holds every row its three segments need: each chunk of 64 channels is staged once
-// (12 x 32 positions, position i = f * 32 + px) and read three times — fragment b of wave row wm is frame f = 3 wm + b, its segment-s
-// operand is frame {0, max(f - 1, 0), f}[s] of the same staged image.  The rest is the 2-D convolution kernel above with 3 "taps"
-// per chunk: weight ring, loader waves, double-buffered chunks, split-K over chunks; a wave's fragments lie one FRAME (hw rows) apart
-// in M — the epilogue's `mstride`.  K order chunk-major / segment-minor (other f32 order than the segment-major tiles).
-template <int BN, int WN, int STAGES, int LW>
-__global__ __launch_bounds__(64 * (4 * WN + LW)) void tmixr_kernel(const avsd_gemm_desc p) {
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smemt[];
-  constexpr int F = 12, WM = 4, FM = 3;
-  constexpr int NC = WM * WN;
-  constexpr int NWAVES = LW > 0 ? LW : NC;
-  constexpr int PAC = (F * 32 / 8) / NWAVES;
-  static_assert(PAC * NWAVES * 8 == F * 32, "staged pieces must split evenly over the loading waves");
-  constexpr int A_BYTES = F * 32 * 128;
-  constexpr int W_BYTES = BN * 128;
-  constexpr int PW = (BN / 8) / NWAVES;
-  static_assert(PW * NWAVES * 8 == BN, "weight tile rows must split evenly into 1-KiB pieces per loading wave");
-  static_assert((STAGES - 2) * PW + PAC < 64, "vmcnt is a 6-bit counter");
-  constexpr int FN = BN / WN / 32;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool is_loader = LW == 0 || wave_all >= NC;
-  const int wave = LW == 0 ? wave_all : (wave_all >= NC ? wave_all - NC : 0);
-  const int wm = wave_all % WM;
-  const int wn = (wave_all / WM) % WN;
-
-  const int hw = p.hw;
-  const int tpb = hw / 32;
-  const int ntm = (p.M / (F * hw)) * tpb;
-  const int ntn = (p.N + BN - 1) / BN;
-  const int nwg = ntm * ntn;
-  const int nsplit = p.split_k > 1 ? p.split_k : 1;
-  int wg, ksplit;
-  {
-    const int total = nwg * nsplit;
-    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
-    const int q = total >> 3, r = total & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int c = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    wg = c / nsplit;
-    ksplit = c - wg * nsplit;
-  }
-  const bool nmaj = (p.flags & AVSD_GEMM_XCD_N) != 0;
-  const int tn = nmaj ? wg / ntm : wg % ntn;
-  const int tm = nmaj ? wg % ntm : wg / ntn;
-  const int bb = tm / tpb;
-  const int p0 = (tm - bb * tpb) * 32;
-  const int row00 = bb * F * hw + p0;                          // row of (frame 0, pixel p0)
-
-  const int nchunks = p.cseg >> 6;
-  const int per_split = (nchunks + nsplit - 1) / nsplit;
-  const int c0 = ksplit * per_split;
-  const int c1 = min(nchunks, c0 + per_split);
-  const int nk = max(c1 - c0, 0) * 3;
-
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
-
-  static_assert((4 * NWAVES) % 8 == 0, "piece stride must keep the swizzle phase");
-  const int a_i0 = 2 * (wave * 4 + (lane >> 4)) + ((lane & 15) >> 3);
-  const int a_ch8 = (((lane & 15) & 7) ^ ((wave * 4 + (lane >> 4)) & 7)) * 8;
-  int wo[PW];
-  bool wv[PW];
-#pragma unroll
-  for (int j = 0; j < PW; ++j) {
-    const int L = (wave + j * NWAVES) * 4 + (lane >> 4);
-    const int x = (lane & 15) ^ (L & 15);
-    const int n = tn * BN + 2 * L + (x >> 3);
-    wv[j] = n < p.N;
-    wo[j] = n * p.ldw + (x & 7) * 8;
-  }
-  auto issue_a = [&](int chunk) {
-    unsigned char* ab = smemt + (chunk & 1) * A_BYTES;
-    const int coff = a_ch8 + chunk * 64;
-#pragma unroll
-    for (int j = 0; j < PAC; ++j) {
-      const int i = a_i0 + j * 8 * NWAVES;
-      const int row = row00 + (i >> 5) * hw + (i & 31);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(ab + (wave + j * NWAVES) * 1024), 16, (row * p.lda + coff) * 2, 0, 0, 0);
-    }
-  };
-  int i_t = 0, i_chunk = c0, i_seg = 0;
-  auto issue_w = [&]() {
-    unsigned char* sb = smemt + 2 * A_BYTES + (i_t % STAGES) * W_BYTES;
-    const int kbase = i_seg * p.cseg + i_chunk * 64;
-#pragma unroll
-    for (int j = 0; j < PW; ++j) {
-      const unsigned vo = wv[j] ? (unsigned)(wo[j] + kbase) * 2u : OOBR;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(sb + (wave + j * NWAVES) * 1024), 16, (int)vo, 0, 0, 0);
-    }
-    ++i_t;
-    if (++i_seg == 3) { i_seg = 0; ++i_chunk; }
-  };
-  auto wait_tile = [&](int kt) {
-    const int nw = min(STAGES - 2, nk - 1 - kt);
-    bool a = false;
-#pragma unroll
-    for (int d = 1; d <= STAGES - 2; ++d) {
-      const int j = kt - d;
-      if (j >= 0 && j % 3 == 0 && c0 + j / 3 + 1 < c1) a = true;
-    }
-    wait_ring<STAGES - 2, PW, PAC>(nw, a);
-  };
-  static_assert(STAGES - 1 <= 3, "the A chunk issued at segment 0 must precede the W tile waited for at the next chunk's segment 0");
-
-  if (is_loader && nk > 0) {
-    issue_a(c0);
-#pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s)
-      if (s < nk) issue_w();
-  }
-  if (LW > 0 && is_loader) {
-    int seg = 0, chunk = c0;
-    for (int kt = 0; kt < nk; ++kt) {
-      wait_tile(kt);
-      __builtin_amdgcn_s_barrier();
-      if (seg == 0 && chunk + 1 < c1) issue_a(chunk + 1);
-      if (kt + STAGES - 1 < nk) issue_w();
-      if (++seg == 3) { seg = 0; ++chunk; }
-    }
-    return;
-  }
-
-  f32x16 acc[FN][FM];
-#pragma unroll
-  for (int a = 0; a < FN; ++a)
-#pragma unroll
-    for (int b = 0; b < FM; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  int w_line[FN], w_sw[FN], w_hi[FN];
-#pragma unroll
-  for (int a = 0; a < FN; ++a) {
-    const int r = wn * (BN / WN) + a * 32 + (lane & 31);
-    w_line[a] = (r >> 1) * 256;
-    w_sw[a] = (r >> 1) & 15;
-    w_hi[a] = (r & 1) << 3;
-  }
-  const int chalf = lane >> 5;
-
-  int seg = 0, chunk = c0;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (LW == 0) wait_tile(kt);
-    __builtin_amdgcn_s_barrier();
-    if (LW == 0) {
-      if (seg == 0 && chunk + 1 < c1) issue_a(chunk + 1);
-      if (kt + STAGES - 1 < nk) issue_w();
-    }
-    const int abuf = (chunk & 1) * A_BYTES;
-    int xa_base[FM], xa_sw[FM];
-#pragma unroll
-    for (int b = 0; b < FM; ++b) {
-      const int f = wm * FM + b;
-      const int g = seg == 0 ? 0 : (seg == 1 ? max(f - 1, 0) : f);
-      const int i = g * 32 + (lane & 31);
-      xa_base[b] = abuf + (i >> 1) * 256 + ((i & 1) << 7);
-      xa_sw[b] = (i >> 1) & 7;
-    }
-    const unsigned char* sW = smemt + 2 * A_BYTES + (kt % STAGES) * W_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      const int c = ks * 2 + chalf;
-      h16x8 xf[FM], wf[FN];
-#pragma unroll
-      for (int b = 0; b < FM; ++b)
-        xf[b] = *reinterpret_cast<const h16x8*>(smemt + xa_base[b] + ((c ^ xa_sw[b]) << 4));
-#pragma unroll
-      for (int a = 0; a < FN; ++a)
-        wf[a] = *reinterpret_cast<const h16x8*>(sW + w_line[a] + (((w_hi[a] | c) ^ w_sw[a]) << 4));
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int a = 0; a < FN; ++a)
-#pragma unroll
-        for (int b = 0; b < FM; ++b)
-          acc[a][b] = mfma32x32x16(wf[a], xf[b], acc[a][b], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    }
-    if (++seg == 3) { seg = 0; ++chunk; }
-  }
-
-  const int m_wave = row00 + wm * FM * hw;
-  if (p.split_k > 1) {
-    float* wsl = p.splitk_ws + (int64_t)ksplit * p.M * p.N;
-    const int hsel = (lane >> 5) * 4;
-#pragma unroll
-    for (int b = 0; b < FM; ++b) {
-      const int m = m_wave + b * hw + (lane & 31);
-#pragma unroll
-      for (int a = 0; a < FN; ++a)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = tn * BN + wn * (BN / WN) + a * 32 + 8 * q + hsel;
-          if (n < p.N)
-            *reinterpret_cast<float4*>(wsl + (int64_t)m * p.N + n) =
-                make_float4(acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]);
-        }
-    }
-    return;
-  }
-  const float pre_ln[2 * FM] = {};
-  epilogue<FN, FM, (64 * (4 * WN + LW) > 512)>(p, acc, m_wave, tn * BN + wn * (BN / WN), lane, 0, pre_ln, false, hw);
-}
-
-template <int BN, int WN, int STAGES, int LW>
-int launch_tmixr(const avsd_gemm_desc& d, hipStream_t s) {
-  constexpr size_t lds = (size_t)2 * 12 * 32 * 128 + (size_t)STAGES * BN * 128;
-  static_assert(lds <= 160 * 1024, "tile does not fit the 160 KB of LDS");
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tmixr_kernel<BN, WN, STAGES, LW>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      avsd_set_error("tmixr: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
-      return AVSD_ELAUNCH;
-    }
-    attr_set = true;
-  }
-  const int ntm = (d.M / (12 * d.hw)) * (d.hw / 32), ntn = (d.N + BN - 1) / BN;
-  const int nsplit = d.split_k > 1 ? d.split_k : 1;
-  dim3 grid((unsigned)(ntm * ntn), (unsigned)nsplit, 1);
-  hipLaunchKernelGGL((tmixr_kernel<BN, WN, STAGES, LW>), grid, dim3(64 * (4 * WN + LW)), lds, s, d);
-  AVSD_CHECK_LAUNCH("tmixr launch");
-  if (nsplit > 1) return avsd_gemm_splitk_reduce(d, s);
-  return AVSD_OK;
-}
-
-template <int BM, int BN, int WM, int WN, int STAGES, int LW, bool GN = false>
+template <int BM, int BN, int WM, int WN, int STAGES, int LW>
 int launch_r(const avsd_gemm_desc& d, hipStream_t s) {
   constexpr int NWAVES = LW > 0 ? LW : WM * WN;
   constexpr int PAC = ((BM + HALO_MAX) / 8 + NWAVES - 1) / NWAVES;
-  constexpr size_t lds = (size_t)2 * PAC * NWAVES * 1024 + (size_t)STAGES * BN * 128 + 256 + (GN ? 2 * NWAVES * 1024 : 0);
-  if (GN) AVSD_REQUIRE(d.gn_rows_per_batch % BM == 0, "gemm/conv3r: a normalisation batch (%d rows) must be whole %d-row tiles", d.gn_rows_per_batch, BM);
+  constexpr size_t lds = (size_t)2 * PAC * NWAVES * 1024 + (size_t)STAGES * BN * 128 + 256;
   static_assert(lds <= 160 * 1024, "tile does not fit the 160 KB of LDS");
   AVSD_REQUIRE(BM % d.ws == 0 && ((d.hs * d.ws) % BM == 0 || BM % (d.hs * d.ws) == 0),
                "gemm/conv3r: a %d-row tile must be whole image rows of one image or whole images (image %d x %d)", BM, d.hs, d.ws);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3r_kernel<BM, BN, WM, WN, STAGES, LW, GN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3r_kernel<BM, BN, WM, WN, STAGES, LW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       avsd_set_error("conv3r: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
@@ -870,7 +576,7 @@ int launch_r(const avsd_gemm_desc& d, hipStream_t s) {
   const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
   const int nsplit = d.split_k > 1 ? d.split_k : 1;
   dim3 grid((unsigned)(ntm * ntn), (unsigned)nsplit, 1);
-  hipLaunchKernelGGL((conv3r_kernel<BM, BN, WM, WN, STAGES, LW, GN>), grid, dim3(64 * (WM * WN + LW)), lds, s, d);
+  hipLaunchKernelGGL((conv3r_kernel<BM, BN, WM, WN, STAGES, LW>), grid, dim3(64 * (WM * WN + LW)), lds, s, d);
   AVSD_CHECK_LAUNCH("conv3r launch");
   if (nsplit > 1) return avsd_gemm_splitk_reduce(d, s);
   return AVSD_OK;
@@ -881,24 +587,12 @@ int launch_r(const avsd_gemm_desc& d, hipStream_t s) {
 // tile ids AVSD_GEMM_TILE_CONV3R_FIRST + k (include/avsd.h)
 int avsd_gemm_dispatch_conv3r(const avsd_gemm_desc& d, hipStream_t s) {
   AVSD_REQUIRE(d.mode == AVSD_GEMM_CONV3 && d.stride == 1 && d.ups == 0 && d.pad == 1 && d.batch == 1 &&
-                   !(d.flags & (AVSD_GEMM_X2 | AVSD_GEMM_GEGLU | AVSD_GEMM_LNFUSE)) && !d.splitk_cnt,
+                   !(d.flags & (AVSD_GEMM_X2 | AVSD_GEMM_GEGLU | AVSD_GEMM_LNFUSE)),
                "gemm/conv3r: stride-1 pad-1 3x3 convolutions only (no upsample fold, split precision, GEGLU, LayerNorm fold, batching)");
   if (d.A2) AVSD_REQUIRE(d.k_split > 0 && d.k_split % 64 == 0 && d.k_split < d.cin && d.lda2 % 8 == 0 && (double)d.M * d.lda2 * 2.0 < 2147483648.0,
                          "gemm/conv3r: a two-source input needs k_split %% 64 == 0 inside cin (got %d of %d)", d.k_split, d.cin);
-  if (d.flags & AVSD_GEMM_GNFUSE) {
-    AVSD_REQUIRE(d.gn_table && d.gn_rows_per_batch > 0 && d.M % d.gn_rows_per_batch == 0,
-                 "gemm/conv3r: GNFUSE needs gn_table and gn_rows_per_batch dividing M (%d)", d.M);
-    AVSD_REQUIRE((double)(d.M / d.gn_rows_per_batch) * d.cin * 8.0 < 2147483648.0, "gemm/conv3r: (scale, shift) table too large");
-    switch (d.tile - AVSD_GEMM_TILE_CONV3R_FIRST) {
-      case 0: return launch_r<256, 128, 4, 2, 3, 4, true>(d, s);
-      case 2: return launch_r<256, 160, 4, 1, 3, 4, true>(d, s);
-      case 3: return launch_r<256, 160, 8, 1, 3, 4, true>(d, s);
-      case 4: return launch_r<128, 128, 2, 2, 4, 2, true>(d, s);
-      default: AVSD_REQUIRE(false, "gemm/conv3r: tile %d has no loader waves for the GroupNorm prologue (40, 42, 43, 44 do)", d.tile);
-    }
-  }
   if (d.tile >= AVSD_GEMM_TILE_CONV3R2D_FIRST && d.tile <= AVSD_GEMM_TILE_CONV3R2D_LAST) {
-    AVSD_REQUIRE(d.cin % 64 == 0 && !(d.flags & AVSD_GEMM_GNFUSE), "gemm/conv3r2d: cin %% 64 == 0, no GroupNorm prologue (got cin %d)", d.cin);
+    AVSD_REQUIRE(d.cin % 64 == 0, "gemm/conv3r2d: cin %% 64 == 0 (got cin %d)", d.cin);
     AVSD_REQUIRE(d.split_k <= 1 || d.split_k <= d.cin / 64, "gemm/conv3r2d: split_k (%d) exceeds the %d channel chunks", d.split_k, d.cin / 64);
     AVSD_REQUIRE((double)d.M * d.lda * 2.0 < 2147483648.0 && (double)d.N * d.ldw * 2.0 < 2147483648.0, "gemm/conv3r2d: operands must be < 2 GiB");
     switch (d.tile - AVSD_GEMM_TILE_CONV3R2D_FIRST) {
@@ -914,37 +608,21 @@ int avsd_gemm_dispatch_conv3r(const avsd_gemm_desc& d, hipStream_t s) {
   AVSD_REQUIRE((double)d.M * d.lda * 2.0 < 2147483648.0 && (double)d.N * d.ldw * 2.0 < 2147483648.0, "gemm/conv3r: operands must be < 2 GiB");
   switch (d.tile - AVSD_GEMM_TILE_CONV3R_FIRST) {
     case 0: return launch_r<256, 128, 4, 2, 3, 4>(d, s);     // 128 KB: 64x64 wave tiles, 4 loader waves
-    case 1: return launch_r<256, 128, 4, 2, 4, 0>(d, s);     // 144 KB: 8 waves load and multiply
     case 2: return launch_r<256, 160, 4, 1, 3, 4>(d, s);     // 140 KB: 64x160 wave tiles (N = 320 in two column tiles)
     case 3: return launch_r<256, 160, 8, 1, 3, 4>(d, s);     // 140 KB: 32x160 wave tiles, 12 waves
     case 4: return launch_r<128, 128, 2, 2, 4, 2>(d, s);     // 112 KB: 64x64 wave tiles
-    case 5: return launch_r<128, 128, 2, 4, 4, 0>(d, s);     // 112 KB: 8 waves, 64x32 wave tiles
-    case 6: return launch_r<128, 256, 2, 4, 3, 0>(d, s);     // 144 KB
-    case 7: return launch_r<128, 320, 2, 2, 2, 0>(d, s);     // 128 KB: full-row tile for N = 320, 64x160 wave tiles
     case 8: return launch_r<256, 256, 4, 2, 2, 0>(d, s);     // 144 KB: 64x128 wave tiles
-    case 9: return launch_r<128, 64, 2, 2, 4, 0>(d, s);      // 80 KB: two blocks per CU
     default: AVSD_REQUIRE(false, "gemm/conv3r: unknown tile %d", d.tile);
   }
 }
 
-// rows per tile of a GNFUSE-capable tile (loader waves), else 0
-extern "C" int avsd_gemm_conv3r_gn_supported(int tile, int hs, int ws, int cin, int c1, int rows_per_batch);
 // largest BM the image geometry admits for tile id `tile` (0 = unsupported): lets a host enumerate candidates
 extern "C" int avsd_gemm_conv3r_supported(int tile, int hs, int ws, int cin) {
-  static const int bm[10] = {256, 256, 256, 256, 128, 128, 128, 128, 256, 128};
+  static const int bm[10] = {256, 0, 256, 256, 128, 0, 0, 0, 256, 0};     // 0: measured and dropped (41, 45, 46, 47, 49 were never the tuner's pick)
   const int k = tile - AVSD_GEMM_TILE_CONV3R_FIRST;
-  if (k < 0 || k >= 10 || cin % 64 != 0 || ws <= 0 || hs <= 0 || 2 * ws > HALO_MAX) return 0;
+  if (k < 0 || k >= 10 || bm[k] == 0 || cin % 64 != 0 || ws <= 0 || hs <= 0 || 2 * ws > HALO_MAX) return 0;
   const int b = bm[k];
   return (b % ws == 0 && ((hs * ws) % b == 0 || b % (hs * ws) == 0)) ? b : 0;
-}
-
-extern "C" int avsd_gemm_conv3r_gn_supported(int tile, int hs, int ws, int cin, int c1, int rows_per_batch) {
-  const int k = tile - AVSD_GEMM_TILE_CONV3R_FIRST;
-  if (!(k == 0 || k == 2 || k == 3 || k == 4)) return 0;
-  const int b = avsd_gemm_conv3r_supported(tile, hs, ws, cin);
-  if (b == 0 || rows_per_batch <= 0 || rows_per_batch % b != 0) return 0;
-  if (c1 != cin && (c1 <= 0 || c1 >= cin || c1 % 64 != 0)) return 0;
-  return b;
 }
 
 // rows per tile of 2-D tile id `tile` (TH image rows x 32 pixels) if the image geometry admits it, else 0
@@ -953,26 +631,4 @@ extern "C" int avsd_gemm_conv3r2d_supported(int tile, int hs, int ws, int cin) {
   const int k = tile - AVSD_GEMM_TILE_CONV3R2D_FIRST;
   if (k < 0 || k >= 4 || cin % 64 != 0 || ws <= 0 || hs <= 0 || ws % 32 != 0 || hs % (bm[k] / 32) != 0) return 0;
   return bm[k];
-}
-
-// rows per tile (384 = 12 frames x 32 pixels) if the resident temporal-mix tile `tile` takes this geometry, else 0
-extern "C" int avsd_gemm_tmixr_supported(int tile, int hw, int frames, int cseg) {
-  if (tile < AVSD_GEMM_TILE_TMIXR_FIRST || tile > AVSD_GEMM_TILE_TMIXR_LAST) return 0;
-  return (frames == 12 && hw > 0 && hw % 32 == 0 && cseg > 0 && cseg % 64 == 0) ? 384 : 0;
-}
-
-int avsd_gemm_dispatch_tmixr(const avsd_gemm_desc& d, hipStream_t s) {
-  AVSD_REQUIRE(d.mode == AVSD_GEMM_TMIX && d.batch == 1 && !d.A2 && !d.splitk_cnt &&
-                   !(d.flags & (AVSD_GEMM_X2 | AVSD_GEMM_GEGLU | AVSD_GEMM_LNFUSE | AVSD_GEMM_GNFUSE)),
-               "gemm/tmixr: 16-bit temporal-mix descriptors only (no split precision, GEGLU, LayerNorm fold, batching)");
-  AVSD_REQUIRE(avsd_gemm_tmixr_supported(d.tile, d.hw, d.frames, d.cseg) != 0,
-               "gemm/tmixr: 12 frames, hw %% 32 == 0, cseg %% 64 == 0 (got frames %d, hw %d, cseg %d)", d.frames, d.hw, d.cseg);
-  AVSD_REQUIRE(d.split_k <= 1 || (d.splitk_ws && d.split_k <= d.cseg / 64), "gemm/tmixr: split_k (%d) needs a workspace and <= %d channel chunks", d.split_k, d.cseg / 64);
-  AVSD_REQUIRE((double)d.M * d.lda * 2.0 < 2147483648.0 && (double)d.N * d.ldw * 2.0 < 2147483648.0, "gemm/tmixr: operands must be < 2 GiB");
-  switch (d.tile - AVSD_GEMM_TILE_TMIXR_FIRST) {
-    case 0: return launch_tmixr<128, 2, 3, 0>(d, s);      // 384 x 128: 96x64 wave tiles, 8 waves load and multiply, 144 KB
-    case 1: return launch_tmixr<64, 2, 4, 4>(d, s);       // 384 x 64: 96x32 wave tiles, 128 KB
-    case 2: return launch_tmixr<64, 2, 4, 0>(d, s);       // 384 x 64: 96x32 wave tiles, 8 waves load and multiply
-    default: AVSD_REQUIRE(false, "gemm/tmixr: unknown tile %d", d.tile);
-  }
 }

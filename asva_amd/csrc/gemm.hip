@@ -608,49 +608,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm2_kernel(const avsd_g
                 make_float4(acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]);
         }
     }
-    if (p.splitk_cnt == nullptr) return;      // two-launch form: splitk_reduce_kernel folds the slabs
-    // ---- in-launch reduction by the last-arriving slice of this tile (cdna_hip_programming.md 5, split-K recipe): plain slab
-    // stores -> every wave drains -> barrier -> one lane: agent-scope release, drain again (the compiler may drop the wait
-    // behind buffer_wbl2), relaxed agent-scope ticket.  The slice that draws the last ticket acquires (one lane + barrier) and
-    // folds ALL slabs in slice order — the same f32 order as splitk_reduce_kernel, so both forms are bit-identical and
-    // independent of arrival order — then runs the epilogue.  It also zeroes the ticket word for the next launch on the
-    // stream (the words start at zero: ops allocates them once, zero-filled).
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    volatile int* flag = reinterpret_cast<volatile int*>(smem2);     // the ring is dead; all LDS stays one object
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      *flag = __hip_atomic_fetch_add(p.splitk_cnt + wg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (*flag != nsplit - 1) return;
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      __hip_atomic_store(p.splitk_cnt + wg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int a = 0; a < FN; ++a)
-#pragma unroll
-      for (int b = 0; b < FM; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    for (int sl = 0; sl < nsplit; ++sl) {
-      const float* slab = p.splitk_ws + (int64_t)sl * p.M * p.N;
-#pragma unroll
-      for (int b = 0; b < FM; ++b) {
-        const int m = min(tm * BM + wm * (BM / WM) + b * 32 + (lane & 31), p.M - 1);
-#pragma unroll
-        for (int a = 0; a < FN; ++a)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int n = min(tn * BN + wn * (BN / WN) + a * 32 + 8 * q + hsel, p.N - 4);
-            const float4 v = *reinterpret_cast<const float4*>(slab + (int64_t)m * p.N + n);
-            acc[a][b][4 * q] += v.x; acc[a][b][4 * q + 1] += v.y; acc[a][b][4 * q + 2] += v.z; acc[a][b][4 * q + 3] += v.w;
-          }
-      }
-    }
+    return;      // splitk_reduce_kernel folds the slabs and applies the epilogue
   }
   if constexpr (X2) epilogue_x2<FN, FM>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
   else epilogue<FN, FM, (64 * (WM * WN + LW) > 512)>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
@@ -658,8 +616,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm2_kernel(const avsd_g
 
 // out = epilogue(sum_s ws[s]) for split-K launches: one thread per 4 consecutive columns.  S = the slice count (2 / 4 / 8:
 // all slab loads of a thread are issued before the first add — the kernel is one memory round trip deep instead of S;
-// 7.4 -> ~4 us per launch, 73 launches per step) or 0 (any count, one load at a time).  The sum runs in slice order either
-// way: bit-identical to the in-launch form above.
+// 7.4 -> ~4 us per launch, 73 launches per step) or 0 (any count, one load at a time).  The sum runs in slice order.
 template <int S>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const avsd_gemm_desc p) {
   const int nq = p.N / 4;
@@ -791,7 +748,7 @@ int launch2(const avsd_gemm_desc& d, hipStream_t s) {
   dim3 grid((unsigned)(ntm * ntn), (unsigned)nsplit, (unsigned)d.batch);
   hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM, WN, STAGES, MODE, LW, X2>), grid, dim3(64 * (WM * WN + LW)), lds, s, d);
   AVSD_CHECK_LAUNCH("gemm2 launch");
-  if (nsplit > 1 && d.splitk_cnt == nullptr) {
+  if (nsplit > 1) {
     const int64_t total = (int64_t)d.M * (d.N / 4);
     int64_t g = (total + 255) / 256;
     if (g > 2048) g = 2048;
@@ -816,22 +773,17 @@ int dispatch_tile(const avsd_gemm_desc& d, int tile, hipStream_t s) {
     case 3: return launch<64, 64, MODE>(d, s);
     // v2 (LDS-direct ring): BM, BN, waves M x N, stages
     case 4: return launch2<128, 64, 2, 2, 3, MODE>(d, s);
-    case 5: return launch2<128, 128, 2, 2, 3, MODE>(d, s);
     case 6: return launch2<128, 128, 2, 4, 3, MODE>(d, s);
     case 7: return launch2<64, 64, 2, 2, 4, MODE>(d, s);
     case 8: return launch2<256, 64, 4, 2, 3, MODE>(d, s);
     case 9: return launch2<256, 128, 4, 2, 3, MODE>(d, s);
-    case 10: return launch2<128, 64, 2, 2, 4, MODE>(d, s);
     case 11: return launch2<128, 128, 2, 2, 2, MODE>(d, s);   // 64 KB: two 4-wave blocks per CU, 64x64 wave tiles
     case 12: return launch2<128, 64, 2, 2, 2, MODE>(d, s);    // 48 KB: three blocks per CU
     case 13: return launch2<64, 64, 2, 2, 2, MODE>(d, s);     // 32 KB: five blocks per CU (short-K GEMMs)
     case 14: return launch2<256, 128, 4, 2, 2, MODE>(d, s);   // 96 KB
     // full-row tiles for N = 320 / 640 / 1280 layers: the activation tile is fetched from L2 once per block
-    case 15: return launch2<128, 320, 2, 2, 2, MODE>(d, s);   // 112 KB, 4 waves, 64x160 wave tiles
-    case 16: return launch2<64, 320, 2, 2, 3, MODE>(d, s);    // 144 KB, 4 waves, 32x160 wave tiles
     case 17: return launch2<128, 320, 4, 2, 2, MODE>(d, s);   // 112 KB, 8 waves, 32x160 wave tiles
     // 256-row tiles for the widest layers: (BM + BN) / (BM * BN) global->LDS bytes per MFMA is what the texture path pays
-    case 18: return launch2<256, 256, 4, 2, 2, MODE>(d, s);   // 128 KB, 8 waves, 64x128 wave tiles
     case 19: return launch2<256, 320, 4, 2, 2, MODE>(d, s);   // 144 KB, 8 waves, 64x160 wave tiles
     // the same tiles with 2 extra loader waves (LW): the MFMA waves issue no loads
     case 20: return launch2<256, 128, 4, 2, 3, MODE, 4>(d, s);
@@ -840,24 +792,22 @@ int dispatch_tile(const avsd_gemm_desc& d, int tile, hipStream_t s) {
     case 23: return launch2<128, 320, 4, 2, 2, MODE, 4>(d, s);
     case 24: return launch2<128, 64, 2, 2, 3, MODE, 2>(d, s);
     case 25: return launch2<64, 64, 2, 2, 4, MODE, 2>(d, s);
-    case 26: return launch2<128, 128, 2, 4, 3, MODE, 2>(d, s);
-    case 27: return launch2<256, 64, 4, 2, 3, MODE, 2>(d, s);
-    case 28: return launch2<64, 320, 2, 2, 3, MODE, 2>(d, s);
     // deep rings for the weight-streaming low-resolution layers (M = 384 / 1536, K up to 23040): what bounds them is the
     // bytes in flight per CU against the ~2 us HBM round trip, so the ring takes all of LDS
-    case 29: return launch2<128, 128, 2, 4, 5, MODE>(d, s);     // 160 KB, 4 tiles (128 KB) in flight
     case 30: return launch2<128, 128, 2, 4, 4, MODE>(d, s);     // 128 KB
     case 31: return launch2<128, 256, 2, 4, 3, MODE>(d, s);     // 144 KB, weight-heavy tile
     // 96-row full-row tiles: the top-level layers (M = 24576 per clip, N = 320) are exactly ONE wave of 256 workgroups,
     // each reads its activation rows once; 5 MFMA waves (96x64 each) + 2 loader waves
     case 32: return launch2<96, 320, 1, 5, 3, MODE, 2>(d, s);   // 156 KB
-    case 33: return launch2<96, 320, 1, 5, 2, MODE, 2>(d, s);   // 104 KB
     // 256 x 160: the geometry the resident convolution does best with on the N = 320 layers (conv3r.hip tile 43) — N = 320 /
     // 640 / 960 / 1280 in whole column tiles, 98 FLOP per staged byte (128 x 128: 64)
     case AVSD_GEMM_TILE_256x160_8W: return launch2<256, 160, 8, 1, 3, MODE, 4>(d, s);   // 156 KB, 32x160 wave tiles, 8 MFMA + 4 loader waves
-    case AVSD_GEMM_TILE_256x160_4W: return launch2<256, 160, 4, 1, 3, MODE, 4>(d, s);   // 156 KB, 64x160 wave tiles, 4 MFMA + 4 loader waves
-    // (measured and dropped: 128x64 with a 6-deep ring, 128x128 x 5 with loader waves — never the tuner's pick)
-    default: return launch<64, 64, MODE>(d, s);
+    // (built, measured and dropped — never the tuner's pick on MI355X: 128x128 x 3 on 4 waves (5), 128x64 x 4 (10), the 128x320 / 64x320
+    //  4-wave full-row tiles (15, 16), 256x256 (18), 128x128 / 256x64 / 64x320 with loader waves (26-28), the 5-deep 128x128 ring (29),
+    //  96x320 x 2 (33), 256x160 on 4 MFMA waves (39))
+    default:
+      avsd_set_error("gemm: tile id %d is not built (gemm.hip dispatch_tile)", tile);
+      return AVSD_EINVAL;
   }
 }
 
@@ -865,10 +815,8 @@ int dispatch_tile(const avsd_gemm_desc& d, int tile, hipStream_t s) {
 template <int MODE>
 int dispatch_tile_x2(const avsd_gemm_desc& d, int tile, hipStream_t s) {
   switch (tile) {
-    case 4: return launch2<128, 64, 2, 2, 3, MODE, 0, true>(d, s);     // 144 KB
     case 7: return launch2<64, 64, 2, 2, 4, MODE, 0, true>(d, s);      // 128 KB
     case 11: return launch2<128, 128, 2, 2, 2, MODE, 0, true>(d, s);   // 128 KB
-    case 12: return launch2<128, 64, 2, 2, 2, MODE, 0, true>(d, s);    // 96 KB
     case 13: return launch2<64, 64, 2, 2, 2, MODE, 0, true>(d, s);     // 64 KB: two blocks per CU
     case 24: return launch2<128, 64, 2, 2, 3, MODE, 2, true>(d, s);    // 144 KB, loader waves
     case 25: return launch2<64, 64, 2, 2, 4, MODE, 2, true>(d, s);     // 128 KB, loader waves
@@ -877,7 +825,7 @@ int dispatch_tile_x2(const avsd_gemm_desc& d, int tile, hipStream_t s) {
     case 35: return launch2<256, 64, 4, 2, 2, MODE, 0, true>(d, s);    // 160 KB, 8 waves
     case 36: return launch2<128, 192, 2, 2, 2, MODE, 0, true>(d, s);   // 160 KB, 64x96 wave tiles
     default:
-      avsd_set_error("gemm: AVSD_GEMM_X2 runs on tiles 4, 7, 11, 12, 13, 24, 25, 34, 35, 36 (got %d)", tile);
+      avsd_set_error("gemm: AVSD_GEMM_X2 runs on tiles 7, 11, 13, 24, 25, 34, 35, 36 (got %d)", tile);
       return AVSD_EINVAL;
   }
 }
@@ -925,7 +873,6 @@ int avsd_gemm_dispatch_tmix(const avsd_gemm_desc& d, int tile, hipStream_t s) { 
 int avsd_gemm_dispatch_conv3(const avsd_gemm_desc& d, int tile, hipStream_t s) { return dispatch_tile<AVSD_GEMM_CONV3>(d, tile, s); }
 #endif
 
-int avsd_gemm_dispatch_8phase(const avsd_gemm_desc& d, hipStream_t s);      // gemm8p.hip
 int avsd_gemm_dispatch_x2_plain(const avsd_gemm_desc& d, int tile, hipStream_t s);
 int avsd_gemm_dispatch_x2_tmix(const avsd_gemm_desc& d, int tile, hipStream_t s);
 int avsd_gemm_dispatch_x2_conv3(const avsd_gemm_desc& d, int tile, hipStream_t s);
@@ -939,8 +886,6 @@ int avsd_gemm_dispatch_x2_conv3(const avsd_gemm_desc& d, int tile, hipStream_t s
 
 #if !defined(AVSD_GEMM_TU) || AVSD_GEMM_TU == 3
 int avsd_gemm_dispatch_conv3r(const avsd_gemm_desc& d, hipStream_t s);      // conv3r.hip
-int avsd_gemm_dispatch_rowpanel(const avsd_gemm_desc& d, hipStream_t s);    // rowpanel.hip
-int avsd_gemm_dispatch_tmixr(const avsd_gemm_desc& d, hipStream_t s);       // conv3r.hip
 
 // the reduce / epilogue launch of a split-K GEMM, for kernels outside this file that write the same slabs (conv3r.hip)
 int avsd_gemm_splitk_reduce(const avsd_gemm_desc& d, hipStream_t s) {
@@ -1011,24 +956,13 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
     if (d.split_k > 1) AVSD_REQUIRE(d.splitk_ws != nullptr, "gemm: split_k needs a workspace");
     return avsd_gemm_dispatch_conv3r(d, reinterpret_cast<hipStream_t>(stream));
   }
-  if (d.tile >= AVSD_GEMM_TILE_TMIXR_FIRST && d.tile <= AVSD_GEMM_TILE_TMIXR_LAST) return avsd_gemm_dispatch_tmixr(d, reinterpret_cast<hipStream_t>(stream));
-  if (d.tile == AVSD_GEMM_TILE_ROWPANEL) return avsd_gemm_dispatch_rowpanel(d, reinterpret_cast<hipStream_t>(stream));
-  if (d.tile == AVSD_GEMM_TILE_8PHASE) {
-    AVSD_REQUIRE(!(d.flags & AVSD_GEMM_X2) && d.split_k <= 1 && !d.A2 &&
-                     (d.mode == AVSD_GEMM_PLAIN || (d.mode == AVSD_GEMM_CONV3 && d.cin % 64 == 0)),
-                 "gemm: the 8-phase tile takes PLAIN single-source or CONV3 (cin %% 64 == 0) operands, no split_k, no split precision");
-    const double a_rows8 = d.mode == AVSD_GEMM_CONV3 ? (double)(d.M / (d.ho * d.wo)) * d.hs * d.ws : (double)d.M;
-    AVSD_REQUIRE(a_rows8 * d.lda * 2.0 < 2147483648.0 && (double)d.N * d.ldw * 2.0 < 2147483648.0, "gemm: the 8-phase tile addresses operands < 2 GiB");
-    return avsd_gemm_dispatch_8phase(d, reinterpret_cast<hipStream_t>(stream));
-  }
   if (d.split_k > 1) {
     AVSD_REQUIRE(d.splitk_ws != nullptr, "gemm: split_k needs a workspace");
     AVSD_REQUIRE(!(d.flags & AVSD_GEMM_GEGLU) && d.batch == 1, "gemm: split_k cannot be combined with GEGLU or batching");
     AVSD_REQUIRE((d.tile >= 4 && d.tile <= ((d.flags & AVSD_GEMM_X2) ? AVSD_GEMM_MAX_TILE_X2 : AVSD_GEMM_MAX_TILE)) ||
-                     (!(d.flags & AVSD_GEMM_X2) && (d.tile == AVSD_GEMM_TILE_256x160_8W || d.tile == AVSD_GEMM_TILE_256x160_4W)),
+                     (!(d.flags & AVSD_GEMM_X2) && d.tile == AVSD_GEMM_TILE_256x160_8W),
                  "gemm: split_k needs an LDS-direct tile (4..33; split precision: ..36), got %d", d.tile);
     AVSD_REQUIRE(d.split_k <= (d.K + 63) / 64, "gemm: split_k (%d) exceeds the number of K tiles", d.split_k);
-    AVSD_REQUIRE(!d.splitk_cnt || d.N % 32 == 0, "gemm: the in-launch split-K reduction needs N %% 32 == 0 (got %d)", d.N);
   }
   if (d.flags & AVSD_GEMM_X2) {
     AVSD_REQUIRE(d.a_lo != 0 && d.w_lo != 0 && (!d.A2 || d.a2_lo != 0), "gemm/x2: A, A2 and W need their rest-plane offsets");
@@ -1036,7 +970,7 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
     AVSD_REQUIRE(!d.res1 || (d.flags & AVSD_GEMM_RES1_F32) || d.res1_lo != 0, "gemm/x2: a 16-bit res1 needs res1_lo");
     AVSD_REQUIRE(!d.res2 || (d.flags & AVSD_GEMM_RES2_F32) || d.res2_lo != 0, "gemm/x2: a 16-bit res2 needs res2_lo");
     AVSD_REQUIRE(((d.a_lo | d.a2_lo | d.w_lo | d.out_lo | d.res1_lo | d.res2_lo) & 7) == 0, "gemm/x2: plane offsets must be multiples of 8 elements");
-    AVSD_REQUIRE(!d.out_master && !d.splitk_cnt, "gemm/x2: no f32 master, no in-launch split-K reduction");
+    AVSD_REQUIRE(!d.out_master, "gemm/x2: no f32 master (the planes carry 16 bits)");
     AVSD_REQUIRE(d.mode != AVSD_GEMM_PLAIN || !d.A2 || d.k_split % 64 == 0, "gemm/x2: a two-source A needs k_split %% 64 == 0 (got %d)", d.k_split);
     const double a_rows = d.mode == AVSD_GEMM_CONV3 ? (double)(d.M / (d.ho * d.wo)) * d.hs * d.ws : (double)d.M;
     AVSD_REQUIRE(a_rows * d.lda * 2.0 < 2147483648.0 && (double)d.N * d.ldw * 2.0 < 2147483648.0, "gemm/x2: operands must be < 2 GiB per plane");
@@ -1061,7 +995,7 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
       tile = (d.N > 64 && d.M > 2048) ? 2 : 3;
     }
   }
-  if (tile < 1 || (tile > AVSD_GEMM_MAX_TILE && tile != AVSD_GEMM_TILE_256x160_8W && tile != AVSD_GEMM_TILE_256x160_4W)) tile = pick_tile(d.M, (d.flags & AVSD_GEMM_GEGLU) ? d.N : d.N, d.batch);
+  if (tile < 1 || (tile > AVSD_GEMM_MAX_TILE && tile != AVSD_GEMM_TILE_256x160_8W)) tile = pick_tile(d.M, (d.flags & AVSD_GEMM_GEGLU) ? d.N : d.N, d.batch);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (d.mode) {
     case AVSD_GEMM_PLAIN: return avsd_gemm_dispatch_plain(d, tile, s);

@@ -201,64 +201,6 @@ __global__ __launch_bounds__(1024) void gn_apply_kernel(const h16_t* x1, int ld1
   }
 }
 
-// ---- GroupNorm (scale, shift) table ------------------------------------------------------------------------------------
-// The fold of gn_apply_kernel as its own launch, for consumers that apply the normalisation themselves while they stage
-// their operand (conv3r.hip, AVSD_GEMM_GNFUSE): table[b][c] = (rstd * gamma[c], beta[c] - mean * rstd * gamma[c]).
-// Same arithmetic and order as gn_apply_kernel (double fold of the chunk partials, f32 scale / shift), so
-// act(x * scale + shift) of the consumer equals gn_apply's output bit for bit.  grid (nb), 1024 threads.
-__global__ __launch_bounds__(1024) void gn_table_kernel(const float* partial, int nchunks, int groups, int C, int rows_per_batch,
-                                                       float eps, const float* gamma, const float* beta, float2* table) {
-  __shared__ float smean[64], srstd[64];
-  const int cg = C / groups;
-  const int tid = threadIdx.x;
-  const int b = blockIdx.x;
-  {
-    const int lpg = min(1024 / groups, 64);
-    const int g = min(tid / lpg, groups - 1), sub = tid % lpg;
-    const bool gvalid = tid / lpg < groups;
-    double a = 0.0, q = 0.0;
-    const float2* base = reinterpret_cast<const float2*>(partial) + (int64_t)b * nchunks * groups + g;
-    int k = sub;
-    for (; k + 15 * lpg < nchunks; k += 16 * lpg) {
-      float2 u[16];
-#pragma unroll
-      for (int t = 0; t < 16; ++t) u[t] = base[(int64_t)(k + t * lpg) * groups];
-#pragma unroll
-      for (int t = 0; t < 16; ++t) { a += (double)u[t].x; q += (double)u[t].y; }
-    }
-    for (; k + 3 * lpg < nchunks; k += 4 * lpg) {
-      float2 u[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) u[t] = base[(int64_t)(k + t * lpg) * groups];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) { a += (double)u[t].x; q += (double)u[t].y; }
-    }
-    for (; k < nchunks; k += lpg) {
-      const float2 u = base[(int64_t)k * groups];
-      a += (double)u.x;
-      q += (double)u.y;
-    }
-    for (int off = lpg >> 1; off > 0; off >>= 1) {
-      a += __shfl_xor(a, off, 64);
-      q += __shfl_xor(q, off, 64);
-    }
-    if (sub == 0 && gvalid) {
-      const double n = (double)rows_per_batch * cg;
-      const double mean = a / n;
-      double var = q / n - mean * mean;
-      if (var < 0.0) var = 0.0;
-      smean[g] = (float)mean;
-      srstd[g] = (float)(1.0 / sqrt(var + (double)eps));
-    }
-  }
-  __syncthreads();
-  for (int c = tid; c < C; c += 1024) {
-    const int gg = c / cg;
-    const float sc = srstd[gg] * gamma[c];
-    table[(int64_t)b * C + c] = make_float2(sc, beta[c] - smean[gg] * sc);
-  }
-}
-
 // ---- LayerNorm row statistics, pre-folded: the K / 32 (sum, sumsq) pairs a ROWSTATS producer wrote per row -> one pair per row,
 // added in the order the consumers' own fold uses (ascending block), so a consumer handed the folded pair (ln_nblk = 1) computes
 // bit-identical mean / rstd.  Worth a launch where a consumer would re-fold the same rows in many column tiles (the GEGLU projection:
@@ -455,18 +397,6 @@ extern "C" int avsd_ln_fold(const float* stats, int M, int nblk, float* out, voi
   hipLaunchKernelGGL(ln_fold_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      reinterpret_cast<const float2*>(stats), M, nblk, reinterpret_cast<float2*>(out));
   AVSD_CHECK_LAUNCH("ln_fold launch");
-  return AVSD_OK;
-}
-
-extern "C" int avsd_groupnorm_table(const float* scratch, int nchunks, int nb, int rows_per_batch, int groups, int channels,
-                                    const float* gamma, const float* beta, float eps, float* table, void* stream) {
-  AVSD_REQUIRE(scratch && gamma && beta && table, "groupnorm_table: null pointer");
-  AVSD_REQUIRE(groups >= 4 && groups <= 64 && (groups & (groups - 1)) == 0 && channels > 0 && channels % groups == 0 && channels <= 4096,
-               "groupnorm_table: groups (%d) must be a power of two in 4..64 dividing the channels (%d <= 4096)", groups, channels);
-  AVSD_REQUIRE(nb > 0 && rows_per_batch > 0 && nchunks > 0, "groupnorm_table: bad batch geometry nb=%d rows=%d nchunks=%d", nb, rows_per_batch, nchunks);
-  hipLaunchKernelGGL(gn_table_kernel, dim3((unsigned)nb), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), scratch, nchunks, groups,
-                     channels, rows_per_batch, eps, gamma, beta, reinterpret_cast<float2*>(table));
-  AVSD_CHECK_LAUNCH("groupnorm_table launch");
   return AVSD_OK;
 }
 

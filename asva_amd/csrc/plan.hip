@@ -58,7 +58,7 @@ struct Entry {
 #define AVSD_PLAN_ENTRY_DESC(fn, T) {#fn, [](const RArg* a, int n) { return call(&fn, a, n, #fn); }, sizeof(T)}
 // every entry point that launches work (the queries and the plan API itself are not recordable)
 const Entry kEntries[] = {
-    AVSD_PLAN_ENTRY_DESC(avsd_gemm_bf16, avsd_gemm_desc), AVSD_PLAN_ENTRY_DESC(avsd_cross_attention_block, avsd_xattn_desc), AVSD_PLAN_ENTRY_DESC(avsd_ffn_block, avsd_ffn_desc), AVSD_PLAN_ENTRY(avsd_linear_small_m),
+    AVSD_PLAN_ENTRY_DESC(avsd_gemm_bf16, avsd_gemm_desc), AVSD_PLAN_ENTRY_DESC(avsd_cross_attention_block, avsd_xattn_desc), AVSD_PLAN_ENTRY(avsd_linear_small_m),
     AVSD_PLAN_ENTRY(avsd_groupnorm_stats),  AVSD_PLAN_ENTRY(avsd_groupnorm_apply),       AVSD_PLAN_ENTRY(avsd_layernorm),
     AVSD_PLAN_ENTRY(avsd_softmax_rows),     AVSD_PLAN_ENTRY(avsd_attention),             AVSD_PLAN_ENTRY(avsd_attention_fp8),
     AVSD_PLAN_ENTRY(avsd_temporal_attention), AVSD_PLAN_ENTRY(avsd_ncfhw_to_rows),       AVSD_PLAN_ENTRY(avsd_rows_to_ncfhw),
@@ -71,7 +71,7 @@ const Entry kEntries[] = {
     AVSD_PLAN_ENTRY(avsd_ncfhw_to_rows_x2), AVSD_PLAN_ENTRY(avsd_split_f32),             AVSD_PLAN_ENTRY(avsd_vae_postprocess_x2),
     AVSD_PLAN_ENTRY(avsd_vae_postprocess_u8_x2), AVSD_PLAN_ENTRY(avsd_softmax_rows_x2),
     AVSD_PLAN_ENTRY(avsd_groupnorm_fused),  AVSD_PLAN_ENTRY(avsd_groupnorm_fused_x2),
-    AVSD_PLAN_ENTRY(avsd_groupnorm_table),  AVSD_PLAN_ENTRY(avsd_ln_fold),
+    AVSD_PLAN_ENTRY(avsd_ln_fold),
 };
 
 struct Reloc {

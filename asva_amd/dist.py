@@ -57,6 +57,19 @@ def gather_metrics(values: Sequence[float], device=None) -> List[List[float]]:
     return [o.tolist() for o in out]
 
 
+def bit_checksum(t: torch.Tensor) -> float:
+    """order-independent checksum of the BITS of a tensor (sum of its 32-bit words mod 2^52, exact in the float64 row of
+    gather_metrics): two ranks that computed the same clip bit for bit report the same number."""
+    w = t.detach().contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    return float(int(w.sum().item()) & ((1 << 52) - 1))
+
+
+def clip_seed(clip_id: int, base: int = 1000) -> int:
+    """inputs are seeded by CLIP id, never by rank (the reference seeds per clip: pipeline_audio_cond_animation.py:431-447), so a
+    clip gives the same result whichever rank it lands on"""
+    return base + int(clip_id)
+
+
 def barrier():
     if dist.is_initialized():
         dist.barrier()

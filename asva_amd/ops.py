@@ -14,10 +14,10 @@ import torch
 
 from . import _lib
 from . import precision as P
-from ._lib import FfnDesc, GemmDesc, XAttnDesc, check
+from ._lib import GemmDesc, XAttnDesc, check
 
 PLAIN, TMIX, CONV3 = 0, 1, 2
-GEGLU, OUT_F32, GELU, XCD_N, ROWSTATS, LNFUSE, RES1_F32, RES2_F32, X2, GNFUSE = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
+GEGLU, OUT_F32, GELU, XCD_N, ROWSTATS, LNFUSE, RES1_F32, RES2_F32, X2 = 1, 2, 4, 8, 16, 32, 64, 128, 256
 _XCD_MODE = os.environ.get("AVSD_XCD_MODE", "auto")     # auto | m | n  (which operand each XCD's L2 fetches once)
 F32 = torch.float32      # (16-bit storage dtype: P.ACT, asva_amd/precision.py)
 
@@ -100,56 +100,32 @@ def _stream() -> int:
 # AVSD_AUTOTUNE=1 / set_autotune(True) switches on the measuring tuner for shapes missing from the table: every
 # candidate is timed with HIP events on the caller's real buffers and the winner is cached for the life of the
 # process (measure, don't guess) — that is how the table is produced; results then depend on timing noise.
-TILE_CANDIDATES = ((4, 1), (6, 1), (7, 1), (8, 1), (9, 1), (3, 1), (11, 1), (12, 1), (13, 1), (14, 1), (15, 1), (16, 1), (17, 1), (18, 1), (19, 1),
-                   (20, 1), (21, 1), (22, 1), (23, 1), (24, 1), (25, 1), (26, 1), (27, 1), (28, 1), (29, 1), (30, 1), (31, 1), (32, 1), (33, 1), (38, 1))
+TILE_CANDIDATES = ((4, 1), (6, 1), (7, 1), (8, 1), (9, 1), (3, 1), (11, 1), (12, 1), (13, 1), (14, 1), (17, 1), (19, 1),
+                   (20, 1), (21, 1), (22, 1), (23, 1), (24, 1), (25, 1), (30, 1), (31, 1), (32, 1), (38, 1))
 # extra (tile, split_k) candidates for GEMMs whose output is too small to fill 256 CUs with big tiles
 SPLITK_CANDIDATES = ((6, 2), (6, 4), (6, 8), (9, 2), (9, 4), (4, 2), (4, 4), (4, 8), (7, 2), (7, 4),
-                     (20, 2), (20, 4), (24, 2), (24, 4), (24, 8), (25, 2), (25, 4), (26, 2), (26, 4), (26, 8),
-                     (29, 2), (29, 4), (29, 8), (30, 2), (30, 4), (30, 8), (31, 2), (31, 4), (31, 8))
+                     (20, 2), (20, 4), (24, 2), (24, 4), (24, 8), (25, 2), (25, 4),
+                     (30, 2), (30, 4), (30, 8), (31, 2), (31, 4), (31, 8))
 # split precision (AVSD_GEMM_X2): the tiles whose doubled LDS stage fits (gemm.hip dispatch_tile_x2)
-X2_TILE_CANDIDATES = ((4, 1), (7, 1), (11, 1), (12, 1), (13, 1), (24, 1), (25, 1), (34, 1), (35, 1), (36, 1))
-X2_SPLITK_CANDIDATES = ((34, 2), (34, 4), (35, 2), (35, 4), (36, 2), (36, 4), (4, 2), (4, 4), (4, 8), (7, 2), (7, 4), (7, 8), (11, 2), (11, 4), (24, 2), (24, 4), (24, 8), (25, 2), (25, 4), (25, 8))
+X2_TILE_CANDIDATES = ((7, 1), (11, 1), (13, 1), (24, 1), (25, 1), (34, 1), (35, 1), (36, 1))
+X2_SPLITK_CANDIDATES = ((34, 2), (34, 4), (35, 2), (35, 4), (36, 2), (36, 4), (7, 2), (7, 4), (7, 8), (11, 2), (11, 4), (24, 2), (24, 4), (24, 8), (25, 2), (25, 4), (25, 8))
 # 3x3 stride-1 convolutions with the input tile resident in LDS (csrc/conv3r.hip): tile ids 40-49, geometry-dependent
 # (avsd_gemm_conv3r_supported); split_k cuts the cin / 64 channel chunks
-CONV3R_TILES = tuple(range(40, 50))
+CONV3R_TILES = (40, 42, 43, 44, 48)
 CONV3R2D_TILES = (51, 52, 53, 54)   # rectangular resident tiles (TH rows x 32 pixels) for images wider than 32 pixels: the VAE decoder, cfg 4
 _CONV3R2D_BN = {51: 128, 52: 160, 53: 128, 54: 128}
 CONV3R_SPLITS = (1, 2, 4, 5, 8, 10)
 _CONV3R = os.environ.get("AVSD_CONV3R", "1") != "0"
 
 
-TMIXR_TILES = (55, 56, 57)   # temporal-mix GEMM with the (12 frames x 32 pixels) tile resident (csrc/conv3r.hip tmixr_kernel)
-_TMIXR_BN = {55: 128, 56: 64, 57: 64}
-_TMIXR = os.environ.get("AVSD_TMIXR", "0") != "0"     # selectable, not a tuner candidate: 0.71-1.05x of the tuned tiles (profiles/r3_tmixr_probe.txt)
-
-
-def tmixr_candidates(hw: int, frames: int, cseg: int, M: int, N: int):
-    out = []
-    for t in TMIXR_TILES:
-        if _lib.lib().avsd_gemm_tmixr_supported(t, hw, frames, cseg) <= 0:
-            continue
-        wgs = (M // 384) * ((N + _TMIXR_BN[t] - 1) // _TMIXR_BN[t])
-        for sk in (1, 2, 4, 5):
-            if sk > 1 and (wgs >= 256 or (cseg // 64) // sk < 2 or (cseg // 64) % sk != 0):
-                continue
-            out.append((t, sk))
-    return tuple(out)
-
-
-TILE_ROWPANEL = 50          # csrc/rowpanel.hip: 96-row panels with the activation resident, PLAIN K <= 320 (the C = 320 linear layers)
-_ROWPANEL = os.environ.get("AVSD_ROWPANEL", "0") != "0"    # selectable, not a tuner candidate: 0.8-1.0x of the tuned tiles (profiles/r3_rowpanel_probe.txt)
 _CONV3R_BN = (128, 128, 160, 160, 128, 128, 256, 320, 256, 64)
 
 
-def conv3r_candidates(hs: int, ws: int, cin: int, M: int, N: int, gn: Optional[tuple] = None):
-    """(tile, split_k) pairs of the LDS-resident convolution tiles that fit this image geometry and leave >= 2 chunks per slice;
-    gn = (channels of the first source, rows per normalisation batch): only the tiles that carry the GroupNorm prologue"""
+def conv3r_candidates(hs: int, ws: int, cin: int, M: int, N: int, one_d_only: bool = False):
+    """(tile, split_k) pairs of the LDS-resident convolution tiles that fit this image geometry and leave >= 2 chunks per slice"""
     out = []
     for t in CONV3R_TILES:
-        if gn is not None:
-            bm = _lib.lib().avsd_gemm_conv3r_gn_supported(t, hs, ws, cin, gn[0], gn[1])
-        else:
-            bm = _lib.lib().avsd_gemm_conv3r_supported(t, hs, ws, cin)
+        bm = _lib.lib().avsd_gemm_conv3r_supported(t, hs, ws, cin)
         if bm <= 0:
             continue
         bn = _CONV3R_BN[t - 40]
@@ -158,7 +134,7 @@ def conv3r_candidates(hs: int, ws: int, cin: int, M: int, N: int, gn: Optional[t
             if sk > 1 and (wgs >= 256 or (cin // 64) // sk < 2 or (cin // 64) % sk != 0):
                 continue
             out.append((t, sk))
-    if gn is None:
+    if not one_d_only:
         for t in CONV3R2D_TILES:
             bm = _lib.lib().avsd_gemm_conv3r2d_supported(t, hs, ws, cin)
             if bm <= 0:
@@ -169,16 +145,6 @@ def conv3r_candidates(hs: int, ws: int, cin: int, M: int, N: int, gn: Optional[t
                     continue
                 out.append((t, sk))
     return tuple(out)
-
-
-def conv3r_gn_supported(hs: int, ws: int, cin: int, c1: int, rows_per_batch: int) -> bool:
-    """can a 3x3 stride-1 convolution over (hs x ws)-pixel images take GroupNorm + SiLU as its prologue (gemm(..., gn=))?"""
-    # measured (tools/gn_prologue_bench.py, profiles/r3_gn_prologue_probe.txt): the prologue costs the convolution 6-16 us (the first
-    # chunk is transformed before any matrix work; later chunks take VALU issue slots beside the MFMA waves) and saves the apply
-    # pass — 10-17 us at 32 x 32, 3-13 us at 16 x 16, < 3 us at 8 x 8: it pays on images of >= _CONV3R_GN_MINPIX pixels only
-    if hs * ws < _CONV3R_GN_MINPIX:
-        return False
-    return _CONV3R_GN and not P.SPLIT and any(_lib.lib().avsd_gemm_conv3r_gn_supported(t, hs, ws, cin, c1, rows_per_batch) > 0 for t in CONV3R_TILES)
 
 
 def _heuristic_conv3r(cands, M: int, N: int):
@@ -194,9 +160,6 @@ def _heuristic_conv3r(cands, M: int, N: int):
     return min(cands, key=cost)
 
 
-_CONV3R_GN = os.environ.get("AVSD_CONV3R_GN", "0") != "0"      # measured neutral at 32 x 32, -1 % below: off (profiles/r3_gn_prologue_probe.txt)
-_CONV3R_GN_MINPIX = int(os.environ.get("AVSD_CONV3R_GN_MINPIX", "1024"))
-TILE_8PHASE = 37            # 256 x 256 phase-interleaved tile (csrc/gemm8p.hip): selectable, not a tuner candidate (never the fastest here)
 _TILE_CACHE: dict = {}
 _AUTOTUNE = os.environ.get("AVSD_AUTOTUNE", "0") == "1"
 
@@ -274,7 +237,7 @@ def _heuristic_tile_x2(M: int, N: int, K: int, geglu: bool, splitk_ok: bool):
     if N >= 128 and tiles(128, 128) >= 224:
         return 11, 1
     if tiles(128, 64) >= 224:
-        return (24 if nk >= 16 else 12), 1
+        return 24, 1
     t64 = tiles(64, 64)
     if t64 >= 160 or not splitk_ok or geglu or nk < 8:
         return (25 if nk >= 8 else 13), 1
@@ -356,23 +319,6 @@ def _pick_tile(key, launch, candidates=TILE_CANDIDATES, warm=None):
         best = min(cold, key=cold.get)
     _TILE_CACHE[key] = best
     return best
-
-
-# Optional in-launch split-K reduction (avsd_gemm_desc.splitk_cnt, AVSD_SPLITK_INLAUNCH=1): one zero-filled ticket buffer per
-# device, shared by every launch (they are ordered on one stream; the last arriver of a tile leaves its word zero again).
-# Bit-identical to the separate splitk_reduce launch (tests/test_ops_gpu.py), 79 launches fewer per step — and slower on
-# MI355X: 70.8 vs 75.4 steps/s.  Every slice pays an agent-scope release that writes its freshly dirtied 64-KB slab back
-# (~6 us) and the last arriver reads the other slabs alone, against a 7-us reduce kernel that runs chip-wide.  Off by default.
-_SPLITK_INLAUNCH = os.environ.get("AVSD_SPLITK_INLAUNCH", "0") != "0"
-_SPLITK_TICKETS: dict = {}
-_SPLITK_MAX_TILES = 1 << 16
-
-
-def _splitk_tickets(device) -> torch.Tensor:
-    t = _SPLITK_TICKETS.get(device)
-    if t is None:
-        t = _SPLITK_TICKETS[device] = torch.zeros(_SPLITK_MAX_TILES, dtype=torch.int32, device=device)
-    return t
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -463,8 +409,6 @@ def gemm(
     m: Optional[int] = None,
     tile: int = 0,
     split_k: int = 1,
-    gn: Optional[tuple] = None,        # CONV3 only: (table [batches, cin, 2] f32 of groupnorm_table, rows_per_batch): the input is
-                                       # the UN-normalised tensor (channel concat [a | a2]); SiLU(GroupNorm(.)) is applied while staging
 ) -> torch.Tensor:
     """out = epilogue(alpha * A' . W^T); see avsd_gemm_bf16 in include/avsd.h."""
     _req(a, P.ACT, "a")
@@ -475,10 +419,14 @@ def gemm(
         # un-rounded f32 partial for the second's epilogue — the same sum
         if res1 is not None and res2 is not None:
             raise ValueError("gemm: split precision with an unaligned two-source A supports one residual")
+        if gelu or geglu or rowstats is not None or ln is not None or master is not None or n is not None or k is not None or m is not None \
+                or tile or split_k != 1:
+            # (GELU would be applied to the second partial alone; the other options are not forwarded by this two-launch form)
+            raise ValueError("gemm: split precision with an unaligned two-source A takes bias / rowvec / one residual / alpha only")
         k1 = a.shape[1]
         part = gemm(a, w[:, :k1], alpha=alpha, out_f32=True)
         return gemm(a2, w[:, k1:], bias=bias, rowvec=rowvec, rows_per_vec=rows_per_vec, res1=part, res2=res1 if res1 is not None else res2,
-                    alpha=alpha, gelu=gelu, out_f32=out_f32, out=out)
+                    alpha=alpha, out_f32=out_f32, out=out)
     d = GemmDesc()
     N = w.shape[0] if n is None else n
     lda = _ld(a)
@@ -563,15 +511,6 @@ def gemm(
     if _XCD_MODE == "n" or (_XCD_MODE == "auto" and N * K > a_bytes):
         d.flags |= XCD_N
     d.batch = 1
-    if gn is not None:
-        if mode != CONV3 or P.SPLIT or ln is not None:
-            raise ValueError("gemm: gn= is the GroupNorm prologue of the 16-bit 3x3 convolution")
-        gtab, grows = gn
-        _req(gtab, F32, "gn table")
-        if not gtab.is_contiguous() or gtab.shape != (M // grows, d.cin, 2):
-            raise ValueError(f"gemm: gn table must be contiguous f32 [{M // grows}, {d.cin}, 2], got {tuple(gtab.shape)}")
-        d.gn_table, d.gn_rows_per_batch = _p(gtab), grows
-        d.flags |= GNFUSE
     ws = None
     if P.SPLIT:
         if master is not None:
@@ -589,10 +528,6 @@ def gemm(
             if ws is None or ws.numel() < sk * M * N:
                 ws = torch.empty((sk * M * N,), dtype=F32, device=a.device)
             d.splitk_ws = _p(ws)
-            tiles = ((M + 63) // 64) * ((N + 63) // 64)
-            d.splitk_cnt = _p(_splitk_tickets(a.device)) if (_SPLITK_INLAUNCH and not P.SPLIT and N % 32 == 0 and tiles <= _SPLITK_MAX_TILES) else None
-        else:
-            d.splitk_cnt = None
 
     if tile == 0:
         def _launch(t, sk):
@@ -605,29 +540,28 @@ def gemm(
         if not geglu and not two_src_unaligned and ((M + 127) // 128) * ((N + 127) // 128) < 256 and nk >= 16:
             cands = cands + tuple(c for c in (X2_SPLITK_CANDIDATES if P.SPLIT else SPLITK_CANDIDATES) if nk // c[1] >= 4)
         splitk_ok = not geglu and not two_src_unaligned
-        if (_ROWPANEL and mode == PLAIN and a2 is None and not P.SPLIT and M >= 96 * 64 and _lib.lib().avsd_gemm_rowpanel_supported(M, N, K) > 0):
-            cands = cands + ((TILE_ROWPANEL, 1),)
-        if _TMIXR and mode == TMIX and not P.SPLIT:
-            cands = cands + tmixr_candidates(d.hw, d.frames, d.cseg, M, N)
-        if gn is not None or (mode == CONV3 and a2 is not None):
-            cands = conv3r_candidates(d.hs, d.ws, d.cin, M, N, gn=(d.k_split if a2 is not None else d.cin, d.gn_rows_per_batch) if gn is not None else None)
+        two_src_conv = mode == CONV3 and a2 is not None           # only the LDS-resident tiles read a second source
+        if two_src_conv:
+            cands = conv3r_candidates(d.hs, d.ws, d.cin, M, N)
             if not cands:
-                raise ValueError("gemm: no LDS-resident convolution tile takes this geometry (conv3r_gn_supported tells)")
+                raise ValueError("gemm: no LDS-resident convolution tile takes this two-source geometry")
         elif (_CONV3R and mode == CONV3 and not P.SPLIT and d.stride == 1 and d.ups == 0 and d.pad == 1 and ln is None):
             cands = cands + conv3r_candidates(d.hs, d.ws, d.cin, M, N)
         # 16-bit convolutions are keyed by the image geometry too: which LDS-resident tiles apply depends on (hs, ws)
         key = (mode, M, N, K, d.flags, d.stride, d.ups, d.pad, int(master is not None))
         if mode == CONV3 and not P.SPLIT:
             key = key + (d.hs, d.ws)
+        if two_src_conv:
+            key = key + ("a2", d.k_split)                         # a table entry of the one-source shape may name a tile that never reads A2
         picked = _pick_tile(key, _launch, cands, warm=(a, a2, res1, res2))
-        if picked is not None and picked[0] in CONV3R_TILES and not ((_CONV3R or gn is not None or a2 is not None) and _lib.lib().avsd_gemm_conv3r_supported(picked[0], d.hs, d.ws, d.cin)):
+        if picked is not None and picked[0] in CONV3R_TILES and not ((_CONV3R or two_src_conv) and _lib.lib().avsd_gemm_conv3r_supported(picked[0], d.hs, d.ws, d.cin)):
             picked = None
-        if picked is not None and picked[0] in TMIXR_TILES and not (mode == TMIX and _lib.lib().avsd_gemm_tmixr_supported(picked[0], d.hw, d.frames, d.cseg)):
+        if picked is not None and picked[0] in CONV3R2D_TILES and not ((_CONV3R or two_src_conv) and _lib.lib().avsd_gemm_conv3r2d_supported(picked[0], d.hs, d.ws, d.cin)):
             picked = None
-        if picked is not None and picked[0] in CONV3R2D_TILES and not (_CONV3R and _lib.lib().avsd_gemm_conv3r2d_supported(picked[0], d.hs, d.ws, d.cin)):
+        if picked is not None and two_src_conv and picked not in cands:
             picked = None
         heur = _heuristic_tile_x2 if P.SPLIT else _heuristic_tile
-        if picked is None and (gn is not None or (mode == CONV3 and a2 is not None)):
+        if picked is None and two_src_conv:
             picked = _heuristic_conv3r(cands, M, N)
         tile, split_k = picked if picked is not None else heur(M, N, K, geglu, splitk_ok)
     _set(tile, split_k)
@@ -777,35 +711,6 @@ def ln_fold(stats: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def groupnorm_table(x1: torch.Tensor, x2: Optional[torch.Tensor], nb: int, rows_per_batch: int, groups: int,
-                    gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
-    """(scale, shift) per (batch, channel) of GroupNorm over the channel concat [x1 | x2]: f32 [nb, C, 2] — the statistics pass
-    and the fold of groupnorm(), without the apply pass; the consumer is gemm(..., mode=CONV3, gn=(table, rows_per_batch))."""
-    _req(x1, P.ACT, "x1")
-    c1 = x1.shape[1]
-    c2 = 0
-    if x2 is not None:
-        _req(x2, P.ACT, "x2")
-        c2 = x2.shape[1]
-    _req(gamma, F32, "gamma")
-    _req(beta, F32, "beta")
-    if P.SPLIT:
-        raise ValueError("groupnorm_table: 16-bit storage only")
-    L = _lib.lib()
-    s = _stream()
-    nchunks = L.avsd_groupnorm_nchunks(nb, rows_per_batch, c1 + c2)
-    partial = torch.empty((L.avsd_groupnorm_scratch_floats(nb, nchunks, groups, c1 + c2),), dtype=F32, device=x1.device)
-    table = torch.empty((nb, c1 + c2, 2), dtype=F32, device=x1.device)
-    ev = _TIMER.start() if _TIMER is not None else None
-    check(L.avsd_groupnorm_stats(_p(x1), _ld(x1), c1, _p(x2), _ld(x2) if x2 is not None else 0, c2, nb, rows_per_batch,
-                                 groups, _p(partial), nchunks, s), "avsd_groupnorm_stats")
-    check(L.avsd_groupnorm_table(_p(partial), nchunks, nb, rows_per_batch, groups, c1 + c2, _p(gamma), _p(beta), float(eps), _p(table), s),
-          "avsd_groupnorm_table")
-    if ev is not None:
-        _TIMER.stop(ev, "groupnorm", 0.0, _nbytes(x1, x2))
-    return table
-
-
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
               pos: Optional[torch.Tensor] = None, hw: int = 1, frames: int = 1,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -931,59 +836,6 @@ def cross_attention_block(h: torch.Tensor, stats: torch.Tensor, wq: torch.Tensor
                                                                          "avsd_cross_attention_block"),
                           (h, stats, wq, q_colsum, q_bias, k, vt, wo, o_bias, res, out, master, rowstats))
         _TIMER.stop(ev, "cross_attention_block", 4.0 * M * Cc * Cc + 4.0 * M * lk * Cc, _nbytes(h, out, res, master) + 4.0 * Cc * Cc)
-    return out
-
-
-def ffn_block_supported(C: int, nh: int, M: int) -> bool:
-    return not P.SPLIT and bool(_lib.lib().avsd_ffn_block_supported(C, nh)) and M % 96 == 0
-
-
-def ffn_fold_terms(colsum1: torch.Tensor, bias1: torch.Tensor) -> torch.Tensor:
-    """[2 nh] colsum and bias of the packed GEGLU projection -> cb1 [nh / 16, 2, 32] (one 256-byte record per 16-feature chunk)"""
-    return torch.stack([colsum1.float().reshape(-1, 32), bias1.float().reshape(-1, 32)], 1).contiguous()
-
-
-def ffn_block(h: torch.Tensor, stats: torch.Tensor, w1: torch.Tensor, cb1: torch.Tensor, w2c: torch.Tensor,
-              bias2: torch.Tensor, *, res: torch.Tensor, eps: float = 1e-5, master: Optional[torch.Tensor] = None,
-              rowstats: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out = res + W2 . (value * gelu(gate)) + bias2 with [value | gate] = LN(h) . W1^T + bias1 in one launch; see
-    avsd_ffn_block (include/avsd.h).  w1 [2 nh, C] LayerNorm-folded + GEGLU-packed, cb1 = ffn_fold_terms(colsum, bias),
-    w2c [nh / 16, C, 16] chunk-major W2."""
-    _req(h, P.ACT, "h")
-    _req(w1, P.ACT, "w1")
-    _req(w2c, P.ACT, "w2c")
-    _req(stats, F32, "stats")
-    _req(cb1, F32, "cb1")
-    M, Cc = h.shape
-    nh = w1.shape[0] // 2
-    if not cb1.is_contiguous() or cb1.numel() != 4 * nh:
-        raise ValueError("ffn_block: cb1 must be contiguous f32 [nh / 16, 2, 32]")
-    if not w2c.is_contiguous() or tuple(w2c.shape) != (nh // 16, Cc, 16) or not stats.is_contiguous() or stats.shape != (M, Cc // 32, 2):
-        raise ValueError("ffn_block: w2c must be contiguous [nh/16, C, 16] and stats contiguous f32 [M, C/32, 2]")
-    if out is None:
-        out = torch.empty((M, Cc), dtype=P.ACT, device=h.device)
-    d = FfnDesc()
-    d.h, d.ldh = _p(h), _ld(h)
-    _req(res, F32 if res.dtype == F32 else P.ACT, "res")
-    d.res, d.ldres, d.res_f32 = _p(res), _ld(res), int(res.dtype == F32)
-    d.M, d.C, d.nh = M, Cc, nh
-    d.ln_stats, d.ln_eps = _p(stats), float(eps)
-    d.w1, d.ldw1, d.cb1 = _p(w1), _ld(w1), _p(cb1)
-    d.w2c, d.bias2 = _p(w2c), _p(bias2)
-    d.out, d.ldo = _p(out), _ld(out)
-    if master is not None:
-        _req(master, F32, "master")
-        d.out_master, d.ldm = _p(master), _ld(master)
-    if rowstats is not None:
-        _req(rowstats, F32, "rowstats")
-        d.rowstats = _p(rowstats)
-    ev = _TIMER.start() if _TIMER is not None else None
-    check(_lib.lib().avsd_ffn_block(C.byref(d), _stream()), "avsd_ffn_block")
-    if ev is not None:
-        dc = FfnDesc.from_buffer_copy(d)
-        _TIMER.add_replay("ffn_block", lambda dc=dc: check(_lib.lib().avsd_ffn_block(C.byref(dc), _stream()), "avsd_ffn_block"),
-                          (h, stats, w1, cb1, w2c, bias2, res, out, master, rowstats))
-        _TIMER.stop(ev, "ffn_block", 2.0 * M * Cc * 3 * nh, _nbytes(h, out, res, master) + 2.0 * 3 * nh * Cc)
     return out
 
 

@@ -40,7 +40,7 @@ CONST, INPUT, OUTPUT = 1, 2, 3
 MAGIC = b"AVSDPLN1"
 _NOT_RECORDED = {"avsd_abi_version", "avsd_precision", "avsd_last_error", "avsd_device_info", "avsd_sizeof_gemm_desc",
                  "avsd_sizeof_xattn_desc", "avsd_cross_attention_block_supported", "avsd_groupnorm_nchunks",
-                 "avsd_groupnorm_scratch_floats", "avsd_groupnorm_fused_supported", "avsd_gemm_conv3r_supported", "avsd_gemm_conv3r_gn_supported", "avsd_gemm_rowpanel_supported", "avsd_gemm_conv3r2d_supported", "avsd_gemm_tmixr_supported"}
+                 "avsd_groupnorm_scratch_floats", "avsd_groupnorm_fused_supported", "avsd_gemm_conv3r_supported", "avsd_gemm_conv3r2d_supported"}
 
 
 def _ptr_fields(struct_type) -> List[Tuple[str, int]]:
@@ -113,8 +113,6 @@ class Recorder:
 
     @contextlib.contextmanager
     def record(self, plan: str):
-        if os.environ.get("AVSD_SIDE_STREAM", "0") != "0":
-            raise RuntimeError("plans are recorded on one stream (AVSD_SIDE_STREAM must be off)")
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("record a plan eagerly, not under graph capture")
         if self._live is None:

@@ -45,20 +45,9 @@ _F32_RES = os.environ.get("AVSD_F32_RESIDUAL", "0") != "0"
 # Per model: `unet.fp8_attention = True` (optionally `unet.fp8_scales = (q, k, v)` per-tensor scales, default 1.0).
 _ATTN_FP8 = os.environ.get("AVSD_ATTN_FP8", "0") != "0"
 _FUSE_XATTN = os.environ.get("AVSD_FUSE_XATTN", "1") != "0"
-# GEGLU feed-forward as ONE launch where the kernel is built (C = 320, avsd_ffn_block).  Measured on MI355X (tools/ffn_bench.py,
-# profiles/r3_ffn_probe.txt): 141 us against 127-130 us for the two GEMMs on the 24576-row layer of one clip (485 vs 481 us at four
-# clips) — the A waves' serial chain (LDS fragment reads, MFMAs, GELU) does not overlap enough to pay for the lost co-residency.
-# Off by default; AVSD_FUSE_FFN=1 switches it on (the packed blob then carries the chunk-major W2).
-_FUSE_FFN = os.environ.get("AVSD_FUSE_FFN", "0") != "0"
 # the GEGLU projection re-folds the K / 32 LayerNorm partials of its rows in each of its 20-80 column tiles (+8-10 us per launch): fold
 # them once in a tiny launch (avsd_ln_fold) and hand it one pair per row
 _LN_PREFOLD = os.environ.get("AVSD_LN_PREFOLD", "1") != "0"
-# Optional (AVSD_SIDE_STREAM=1): independent side work (ResBlock shortcut convolutions, the frame-0 K/V projection of the
-# spatial attention, the time-embedding MLP) on a second HIP stream, forked from and joined back into the main one — parallel
-# branches of the captured hipGraph.  Measured on MI355X: two whole B=1 forwards on two streams take 0.71x their sum
-# (tools/two_chain_probe.py), but these short branches cost more in cross-queue fork/join dependencies than they hide:
-# 74.5 vs 75.7 steps/s with them.  Off by default.
-_SIDE_STREAM = os.environ.get("AVSD_SIDE_STREAM", "0") != "0"
 # Classifier-free-guidance branches that share latents, timestep AND text conditioning (audio-only guidance: text [t, t],
 # pipeline_audio_cond_animation.py:155) are identical until the first audio cross-attention: conv_in, the first ResBlock and the
 # first transformer's GroupNorm / proj_in / first-frame attention are computed once and replicated (the reference computes them
@@ -70,38 +59,6 @@ _F32_CONV_Y = os.environ.get("AVSD_F32_CONV_Y", "1") != "0"      # with the f32 
 def _replicate(a: "_Act", r: int) -> "_Act":
     """rows of all branches = r copies of the shared rows, branch-major like torch.cat([latents] * r) (pure data movement)"""
     return _Act(ops.copy(a.lo, rep=r), None if a.hi is None else ops.copy(a.hi, rep=r))     # (ops.copy moves both planes of a split tensor)
-
-
-class _Side:
-    """fork / join of a side stream; no-op without a CUDA device (CPU contract emulation) or when switched off"""
-
-    def __init__(self, enabled: bool):
-        self.on = bool(enabled) and torch.cuda.is_available() and not getattr(ops, "EMULATED", False)
-        self.stream = None
-        self.pending = False
-        self._ctx = None
-
-    def __enter__(self):
-        if not self.on:
-            return self
-        if self.stream is None:
-            self.stream = torch.cuda.Stream()
-        self.stream.wait_stream(torch.cuda.current_stream())          # fork: everything issued so far happens first
-        self._ctx = torch.cuda.stream(self.stream)
-        self._ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self.on:
-            self._ctx.__exit__(*exc)
-            self._ctx = None
-            self.pending = True
-        return False
-
-    def join(self):
-        if self.on and self.pending:
-            torch.cuda.current_stream().wait_stream(self.stream)
-            self.pending = False   # audio / text cross-attention as one launch where the kernel is built
 
 
 def _xa_fill(kv: torch.Tensor, n_kv: int, rows: int, C: int, idx: Optional[torch.Tensor], old=None):
@@ -436,10 +393,6 @@ class Packer:
         if p.audio:
             p.norm_audio = self.aff(b.norm_audio)
             p.attn_audio = self.attn(b.attn_audio, False, b.norm_audio)
-        if _FUSE_FFN and not P.SPLIT and p.dim == 320:      # the fused feed-forward kernel reads W2 chunk-major: [nh / 16][C][16] (avsd_ffn_block)
-            w2 = b.ff.net[2].weight.detach().float()
-            p.ff2c = reg(to_act(w2.reshape(w2.shape[0], w2.shape[1] // 16, 16).permute(1, 0, 2).contiguous()))
-            p.cb1_ln = reg(ops.ffn_fold_terms(from_act(w1_ln).sum(1), b1_ln))
         return p
 
     def block(self, m: _Block):
@@ -968,18 +921,13 @@ class AudioUNet3DConditionModel(nn.Module):
             raise ValueError(f"conditioning was prepared for batch {cond.batch} x {cond.frames} frames, sample has {B} x {Fr}")
         if t.numel() not in (1, B):
             raise ValueError("timestep must be a scalar or have one entry per batch element")
-        side = getattr(self, "_side", None)
-        if side is None or side.on != (_SIDE_STREAM and torch.cuda.is_available() and not getattr(ops, "EMULATED", False)):
-            side = self._side = _Side(_SIDE_STREAM)
-        # -- time embedding: sinusoid -> MLP -> all ResBlock time_emb_proj at once (:657-681, resnet :170); on the side
-        #    stream: it only meets the main path at conv1's epilogue of the first ResBlock
+        # -- time embedding: sinusoid -> MLP -> all ResBlock time_emb_proj at once (:657-681, resnet :170)
         ch0 = self.config.block_out_channels[0]
-        with side:
-            e = ops.timestep_embedding(t, ch0)
-            e = ops.linear_small_m(e, pk.t1.w, pk.t1.b, act_out=True)
-            e = ops.linear_small_m(e, pk.t2.w, pk.t2.b)
-            temb = ops.linear_small_m(e, pk.temb_w, pk.temb_b, act_in=True)          # [1 or B, sum(Cout)]
-        st = _Pk(B=B, F=Fr, side=side, temb=temb, temb_rows=(Fr if (t.numel() == B and B > 1) else B * Fr), cond=cond, tr_i=0,
+        e = ops.timestep_embedding(t, ch0)
+        e = ops.linear_small_m(e, pk.t1.w, pk.t1.b, act_out=True)
+        e = ops.linear_small_m(e, pk.t2.w, pk.t2.b)
+        temb = ops.linear_small_m(e, pk.temb_w, pk.temb_b, act_in=True)          # [1 or B, sum(Cout)]
+        st = _Pk(B=B, F=Fr, temb=temb, temb_rows=(Fr if (t.numel() == B and B > 1) else B * Fr), cond=cond, tr_i=0,
                  groups=self.config.norm_num_groups, eps=float(self.config.norm_eps),
                  heads=_per_block(self.config.attention_head_dim, nblk), fuse_ln=getattr(self, "fuse_layernorm", _FUSE_LN),
                  f32_stream=getattr(self, "f32_residual", _F32_RES) and not P.SPLIT,     # split planes already carry 16 bits
@@ -992,7 +940,6 @@ class AudioUNet3DConditionModel(nn.Module):
         h = _Act(ops.ncfhw_to_rows(x32, cpad=pk.conv_in.cin, rep=rep // pre))
         hw = (H, W)
         h = _ffconv(st, h, pk.conv_in, hw)
-        side.join()                                # time embedding ready
         skips = [h]
         for i, blk in enumerate(pk.down):
             for j, r in enumerate(blk.resnets):
@@ -1020,12 +967,8 @@ class AudioUNet3DConditionModel(nn.Module):
                 h = _ffconv(st, h, blk.up, hw, ups=1)
                 hw = (hw[0] * 2, hw[1] * 2)
         rows_b = Fr * hw[0] * hw[1]
-        if ops.conv3r_gn_supported(hw[0], hw[1], h.lo.shape[1], h.lo.shape[1], rows_b):      # conv_norm_out as conv_out's prologue
-            tb = ops.groupnorm_table(h.lo, None, B, rows_b, st.groups, pk.norm_out.g, pk.norm_out.b, st.eps)
-            o = _ffconv(st, h, pk.conv_out, hw, out_f32=True, gn=(tb, rows_b))
-        else:
-            a = ops.groupnorm(h.lo, None, B, rows_b, st.groups, pk.norm_out.g, pk.norm_out.b, st.eps, True)
-            o = _ffconv(st, _Act(a), pk.conv_out, hw, out_f32=True)
+        a = ops.groupnorm(h.lo, None, B, rows_b, st.groups, pk.norm_out.g, pk.norm_out.b, st.eps, True)
+        o = _ffconv(st, _Act(a), pk.conv_out, hw, out_f32=True)
         return ops.rows_to_ncfhw(o.lo, B, self.config.out_channels, Fr, H, W)
 
 
@@ -1036,8 +979,7 @@ def _master(st, like: torch.Tensor, cols: int):
 # FFInflatedConv3d (utils.py:34-57): conv GEMM, then the temporal-mix GEMM whose epilogue also adds the
 # time embedding (resnet :173) and the residual / shortcut (resnet :189)
 def _ffconv(st, x: _Act, p, hw, stride=1, ups=0, temb=None, res: Optional[_Act] = None, out_f32=False,
-            x2: Optional[_Act] = None, master=True, gn=None) -> _Act:
-    """gn = (table, rows_per_batch): x (and x2) are un-normalised, the 3x3 convolution applies SiLU(GroupNorm(.)) while staging"""
+            x2: Optional[_Act] = None, master=True) -> _Act:
     n_img = st.B * st.F
     if p.k == 3:
         ho = ((hw[0] << ups) + 2 - 3) // stride + 1
@@ -1050,8 +992,7 @@ def _ffconv(st, x: _Act, p, hw, stride=1, ups=0, temb=None, res: Optional[_Act] 
     # un-rounded copy for that addition; the 16-bit copy feeds the temporal-mix product
     ym = torch.empty((rows, p.cout), dtype=torch.float32, device=x.lo.device) if (st.f32_stream and _F32_CONV_Y) else None
     if p.k == 3:
-        y = ops.gemm(x.lo, p.w, a2=None if (x2 is None or gn is None) else x2.lo, bias=p.b, mode=ops.CONV3,
-                     conv=(n_img, hw[0], hw[1], stride, ups), master=ym, gn=gn)
+        y = ops.gemm(x.lo, p.w, bias=p.b, mode=ops.CONV3, conv=(n_img, hw[0], hw[1], stride, ups), master=ym)
     else:
         y = ops.gemm(x.lo, p.w, a2=None if x2 is None else x2.lo, bias=p.b, master=ym)
     m = _master(st, y, p.cout) if (master and not out_f32) else None
@@ -1066,29 +1007,14 @@ def _ffconv(st, x: _Act, p, hw, stride=1, ups=0, temb=None, res: Optional[_Act] 
 def _resblock(st, x: _Act, skip: Optional[_Act], p, hw) -> _Act:
     rows_b = st.F * hw[0] * hw[1]
     if p.shortcut is not None:
-        with st.side:                                                    # independent of the main path until conv2's epilogue
-            s = _ffconv(st, x, p.shortcut, hw, x2=skip)
+        s = _ffconv(st, x, p.shortcut, hw, x2=skip)
     else:
         assert skip is None
         s = x
     tv = st.temb[:, p.temb_off:p.temb_off + p.cout]
-    # GroupNorm + SiLU as the prologue of the 3x3 convolution where a resident tile with loader waves takes the geometry
-    # (ops.conv3r_gn_supported: the 32 x 32, 16 x 16 and 8 x 8 levels): statistics + (scale, shift) table, no apply pass, the
-    # normalised tensor (and the skip concat) never written.  Elsewhere (4 x 4: one-launch GroupNorm) the norm stays a kernel.
-    c1 = x.lo.shape[1]
-    cin1 = c1 + (0 if skip is None else skip.lo.shape[1])
-    if ops.conv3r_gn_supported(hw[0], hw[1], cin1, c1, rows_b):
-        t1 = ops.groupnorm_table(x.lo, None if skip is None else skip.lo, st.B, rows_b, st.groups, p.norm1.g, p.norm1.b, st.eps)
-        h = _ffconv(st, x, p.conv1, hw, temb=tv, master=False, x2=skip, gn=(t1, rows_b))
-    else:
-        a = ops.groupnorm(x.lo, None if skip is None else skip.lo, st.B, rows_b, st.groups, p.norm1.g, p.norm1.b, st.eps, True)
-        h = _ffconv(st, _Act(a), p.conv1, hw, temb=tv, master=False)         # feeds GroupNorm only
-    if ops.conv3r_gn_supported(hw[0], hw[1], p.cout, p.cout, rows_b):
-        t2 = ops.groupnorm_table(h.lo, None, st.B, rows_b, st.groups, p.norm2.g, p.norm2.b, st.eps)
-        st.side.join()
-        return _ffconv(st, h, p.conv2, hw, res=s, gn=(t2, rows_b))
+    a = ops.groupnorm(x.lo, None if skip is None else skip.lo, st.B, rows_b, st.groups, p.norm1.g, p.norm1.b, st.eps, True)
+    h = _ffconv(st, _Act(a), p.conv1, hw, temb=tv, master=False)         # feeds GroupNorm only
     a2 = ops.groupnorm(h.lo, None, st.B, rows_b, st.groups, p.norm2.g, p.norm2.b, st.eps, True)
-    st.side.join()
     return _ffconv(st, _Act(a2), p.conv2, hw, res=s)
 
 
@@ -1148,11 +1074,9 @@ def _transformer(st, x: _Act, p, hw, heads, split: int = 1) -> _Act:
     # 1. first-frame attention: Q from every frame, K/V projected for frame 0 only (utils.py:133-143)
     a1 = p.attn1
     if fused:
-        with st.side:                                                    # K/V of frame 0 beside the Q projection
-            kv = ops.gemm_batched(h.lo.view(B, Fr * L, C)[:, :L], a1.wkv_ln.unsqueeze(0).expand(B, 2 * C, C), bias=a1.bkv_ln,
-                                  ln=(stats[si], a1.skv_ln, eps)).view(B * L, 2 * C)
+        kv = ops.gemm_batched(h.lo.view(B, Fr * L, C)[:, :L], a1.wkv_ln.unsqueeze(0).expand(B, 2 * C, C), bias=a1.bkv_ln,
+                              ln=(stats[si], a1.skv_ln, eps)).view(B * L, 2 * C)
         q = ops.gemm(h.lo, a1.wq_ln, bias=a1.bq_ln, ln=(stats[si], a1.sq_ln, eps))
-        st.side.join()
     else:
         n1 = ops.layernorm(h.lo, p.norm1.g, p.norm1.b)
         q = ops.gemm(n1, a1.wq)
@@ -1195,15 +1119,11 @@ def _transformer(st, x: _Act, p, hw, heads, split: int = 1) -> _Act:
     o = ops.temporal_attention(qkv, b=B, frames=Fr, hw=L, heads=heads)
     h = stream(o, p.attn_temp.wo, p.attn_temp.bo, h)
     # 5. GEGLU feed-forward, activation fused in the first GEMM's epilogue (:361-371)
-    if fused and _FUSE_FFN and getattr(p, "ff2c", None) is not None and ops.ffn_block_supported(C, p.w1_ln.shape[0] // 2, M):
-        m = _master(st, h.lo, C)            # one launch: the M x 4C hidden tensor never exists
-        h = _Act(ops.ffn_block(h.lo, stats[si], p.w1_ln, p.cb1_ln, p.ff2c, p.ff2.b, res=h.res, eps=eps, master=m), m)
+    if fused:
+        g = ops.gemm(h.lo, p.w1_ln, bias=p.b1_ln, geglu=True, ln=(ops.ln_fold(stats[si]) if _LN_PREFOLD else stats[si], p.s1_ln, eps))
     else:
-        if fused:
-            g = ops.gemm(h.lo, p.w1_ln, bias=p.b1_ln, geglu=True, ln=(ops.ln_fold(stats[si]) if _LN_PREFOLD else stats[si], p.s1_ln, eps))
-        else:
-            g = ops.gemm(ops.layernorm(h.lo, p.norm3.g, p.norm3.b), p.w1, bias=p.b1, geglu=True)
-        h = stream(g, p.ff2.w, p.ff2.b, h, want_stats=False)
+        g = ops.gemm(ops.layernorm(h.lo, p.norm3.g, p.norm3.b), p.w1, bias=p.b1, geglu=True)
+    h = stream(g, p.ff2.w, p.ff2.b, h, want_stats=False)
     return stream(h.lo, p.proj_out.w, p.proj_out.b, x, want_stats=False)
 
 

@@ -33,7 +33,7 @@ extern "C" {
 #define AVSD_ELAUNCH (-2)  /* hipLaunch / runtime error                          */
 #define AVSD_ENODEV (-3)   /* no gfx950 device / wrong architecture              */
 
-#define AVSD_ABI_VERSION 6
+#define AVSD_ABI_VERSION 7
 
 /* ---- library ------------------------------------------------------------------------ */
 int avsd_abi_version(void);
@@ -81,37 +81,27 @@ int avsd_device_info(char* name_host, int len, int* num_cu_host);
  */
 enum { AVSD_GEMM_PLAIN = 0, AVSD_GEMM_TMIX = 1, AVSD_GEMM_CONV3 = 2 };
 enum { AVSD_GEMM_GEGLU = 1, AVSD_GEMM_OUT_F32 = 2, AVSD_GEMM_GELU = 4, AVSD_GEMM_XCD_N = 8, AVSD_GEMM_ROWSTATS = 16,
-       AVSD_GEMM_LNFUSE = 32, AVSD_GEMM_RES1_F32 = 64, AVSD_GEMM_RES2_F32 = 128, AVSD_GEMM_X2 = 256, AVSD_GEMM_GNFUSE = 512 };
+       AVSD_GEMM_LNFUSE = 32, AVSD_GEMM_RES1_F32 = 64, AVSD_GEMM_RES2_F32 = 128, AVSD_GEMM_X2 = 256 };
 #define AVSD_GEMM_MAX_TILE 33
 #define AVSD_GEMM_MAX_TILE_X2 36   /* AVSD_GEMM_X2 also has tiles 34..36 (gemm.hip dispatch_tile_x2) */
-/* 256 x 256 tile with the phase-interleaved main loop (gemm8p.hip): PLAIN single-source or CONV3 with cin % 64 == 0,
- * no split_k, no AVSD_GEMM_X2; other descriptors are refused with this tile id. */
-#define AVSD_GEMM_TILE_8PHASE 37
-/* 256 x 160 LDS-direct tiles with loader waves (gemm.hip dispatch_tile; not with AVSD_GEMM_X2) */
+/* 256 x 160 LDS-direct tile, 8 MFMA + 4 loader waves (gemm.hip dispatch_tile; not with AVSD_GEMM_X2) */
 #define AVSD_GEMM_TILE_256x160_8W 38
-#define AVSD_GEMM_TILE_256x160_4W 39
 /* 3x3 stride-1 pad-1 convolution tiles with the input tile resident in LDS (conv3r.hip): K is walked chunk-major (64 input
  * channels at a time), the BM output rows plus one image row of halo on either side are staged once per chunk and read by all
  * nine taps; only the weight tile streams per K tile.  CONV3 descriptors with stride 1, ups 0, pad 1, one source,
  * cin % 64 == 0, image width <= 32 and a tile of whole image rows / whole images (avsd_gemm_conv3r_supported); split_k cuts
  * the channel chunks (split_k <= cin / 64).  No AVSD_GEMM_X2 / GEGLU / LNFUSE.  Other descriptors are refused with these ids. */
-/* Row-panel GEMM (rowpanel.hip): a workgroup owns 96 rows, keeps their activation (K <= 320) resident in LDS and walks N in
- * 320-column steps streaming only weight tiles; PLAIN single-source descriptors with K <= 320, N % 32 == 0, no split_k, no
- * AVSD_GEMM_X2 (avsd_gemm_rowpanel_supported).  Every epilogue flag of the other tiles; bit-identical results. */
-#define AVSD_GEMM_TILE_ROWPANEL 50
+/* 4-wave tiles with a hand-scheduled (inline-asm) main loop, register-staged operands (gemm4.hip): 60 = 256 x 256, 61 = 256 x 128,
+ * 62 = 128 x 256, 63 = 128 x 128.  PLAIN single-source descriptors with K % 64 == 0, no AVSD_GEMM_X2; every epilogue flag; split_k. */
+#define AVSD_GEMM_TILE_ASM_FIRST 60
+#define AVSD_GEMM_TILE_ASM_LAST 63
 #define AVSD_GEMM_TILE_CONV3R_FIRST 40
 #define AVSD_GEMM_TILE_CONV3R_LAST 49
 /* the same convolution with RECTANGULAR resident tiles (TH image rows x 32 pixels + a one-pixel halo, positions outside the image
  * zero-filled at load time) for images wider than 32 pixels: width % 32 == 0, height % TH == 0 (avsd_gemm_conv3r2d_supported);
- * otherwise as the ids above, without the GroupNorm prologue. */
+ * otherwise as the ids above. */
 #define AVSD_GEMM_TILE_CONV3R2D_FIRST 51
 #define AVSD_GEMM_TILE_CONV3R2D_LAST 54
-/* temporal-mix GEMM with the (12 frames x 32 pixels) tile resident (conv3r.hip, tmixr_kernel): each 64-channel chunk is staged once
- * and read by the three K segments (frame 0 / previous / current).  TMIX descriptors with 12 frames, hw % 32 == 0, cseg % 64 == 0
- * (avsd_gemm_tmixr_supported); split_k cuts the channel chunks; no AVSD_GEMM_X2. */
-#define AVSD_GEMM_TILE_TMIXR_FIRST 55
-#define AVSD_GEMM_TILE_TMIXR_LAST 57
-
 typedef struct avsd_gemm_desc {
   const void* A;        /* bf16 */
   const void* A2;       /* bf16 or NULL */
@@ -141,10 +131,6 @@ typedef struct avsd_gemm_desc {
    * Deterministic (no atomics).  split_k <= 1 disables it.  Not combinable with GEGLU or batch > 1. */
   int32_t split_k;
   float* splitk_ws;
-  /* optional: one zero-initialised int32 ticket per output tile (>= ceil(M/64) * ceil(N/64) words).  When given, the slice
-   * of a tile that arrives last folds the slabs itself (same order, same bits) and applies the epilogue: one launch instead
-   * of two; it leaves the words zero again.  Launches that share the words must be ordered on one stream. */
-  int32_t* splitk_cnt;
   /* LayerNorm folded into the GEMMs around it (ff_spatio_audio_temp_transformer_3d.py:300-371: every LayerNorm there
    * feeds linear layers only).  Producer side, AVSD_GEMM_ROWSTATS: besides `out`, the epilogue writes for every row m and
    * every 32-column block j the pair (sum, sum of squares) of the bf16-ROUNDED outputs to rowstats[(m * N/32 + j) * 2]
@@ -165,29 +151,14 @@ typedef struct avsd_gemm_desc {
   /* AVSD_GEMM_X2 (split precision, see "split-precision storage" below): every 16-bit operand is a pair of planes; these are
    * the ELEMENT offsets from each main plane to its rest plane (same strides).  The product is accumulated as
    * W.A + Wr.A + W.Ar (three MFMA passes into one f32 accumulator); 16-bit residuals are read as main + rest and the output
-   * is written as main = round16(v), rest = round16(v - main).  LDS-direct tiles 4, 7, 11, 12, 13, 24, 25, 34, 35, 36 only. */
+   * is written as main = round16(v), rest = round16(v - main).  LDS-direct tiles 7, 11, 13, 24, 25, 34, 35, 36 only. */
   int64_t a_lo, a2_lo, w_lo, out_lo, res1_lo, res2_lo;
-  /* AVSD_GEMM_GNFUSE (CONV3 with an LDS-resident tile that has loader waves, conv3r.hip): A (and A2: the input is the channel
-   * concat [A (k_split channels) | A2 (cin - k_split channels)], k_split % 64 == 0) is the UN-normalised tensor; the loader
-   * waves apply SiLU(x * scale[c] + shift[c]) to each staged chunk in LDS (rounded to 16 bits, exactly what
-   * avsd_groupnorm_apply would have written) before the nine taps read it — GroupNorm + SiLU + conv of
-   * ff_spatio_temp_resnet_3d.py:164-166,178-181 without the normalised tensor ever reaching memory.  gn_table: f32
-   * [batches][cin][2] of avsd_groupnorm_table; a batch is gn_rows_per_batch consecutive rows of A, a multiple of the tile rows. */
-  const float* gn_table;
-  int32_t gn_rows_per_batch;
-  int32_t reserved1;
 } avsd_gemm_desc;
 
 int avsd_gemm_bf16(const avsd_gemm_desc* desc_host, void* stream);
-/* rows per panel if the row-panel tile takes an M x N x K PLAIN problem, else 0 */
-int avsd_gemm_rowpanel_supported(int M, int N, int K);
 /* rows per tile of conv3r tile id `tile` if an (hs x ws)-pixel image with cin channels can use it, else 0 */
 int avsd_gemm_conv3r_supported(int tile, int hs, int ws, int cin);
 int avsd_gemm_conv3r2d_supported(int tile, int hs, int ws, int cin);
-int avsd_gemm_tmixr_supported(int tile, int hw, int frames, int cseg);
-/* the same for a descriptor with AVSD_GEMM_GNFUSE: only tiles with loader waves (40, 42, 43, 44) qualify, a normalisation batch
- * must be whole tiles, and a two-source input (c1 != cin channels in the first) needs c1 % 64 == 0 */
-int avsd_gemm_conv3r_gn_supported(int tile, int hs, int ws, int cin, int c1, int rows_per_batch);
 /* sizeof(avsd_gemm_desc) as compiled: lets an FFI binding verify its mirror of the struct. */
 int avsd_sizeof_gemm_desc(void);
 
@@ -226,35 +197,6 @@ int avsd_cross_attention_block_supported(int C, int heads, int lk_pad);
 int avsd_cross_attention_block(const avsd_xattn_desc* desc_host, void* stream);
 int avsd_sizeof_xattn_desc(void);
 
-/* ---- fused GEGLU feed-forward block -----------------------------------------------------------------------------------
- * One launch for the last residual update of BasicTransformerBlock (ff_spatio_audio_temp_transformer_3d.py:361-371; diffusers
- * FeedForward with GEGLU):    out = res + W2 . (value * gelu_erf(gate)) + bias2 ,   [value | gate] = LayerNorm(h) . W1^T + bias1
- * h [M][C] is the 16-bit residual stream with the row statistics `ln_stats` [M][C/32][2] of AVSD_GEMM_ROWSTATS; w1 is the
- * LayerNorm-folded GEGLU projection exactly as AVSD_GEMM_LNFUSE + AVSD_GEMM_GEGLU take it ([2 nh][ldw1], rows packed per 32 as
- * [16 value | 16 gate]) and cb1 its ln_colsum and bias, interleaved per 32-row block: cb1[j][0][c] = colsum[32 j + c],
- * cb1[j][1][c] = bias[32 j + c] ([nh/16][2][32] f32: one 256-byte record per chunk); w2c is the output projection W2 [C][nh] re-laid chunk-major, w2c[j][n][k] = W2[n][16 j + k]
- * ([nh/16][C][16]: every 16-feature chunk one contiguous block); `res` is h again (16-bit) or its f32 master (res_f32).
- * The M x nh hidden tensor is never written: the 96-row activation tile stays in LDS while the hidden dimension is walked in
- * 16-feature chunks (ffn.hip).  Outputs like avsd_gemm_bf16: `out` 16-bit [M][ldo], optional `out_master` f32, `rowstats`.
- * Built for C = 320 (SD1.5 level 0: M = 24576 rows per clip = 256 workgroups of 96 rows); avsd_ffn_block_supported() tells, other
- * widths run the two GEMMs.  M % 96 == 0. */
-typedef struct avsd_ffn_desc {
-  const void* h;        int32_t ldh;   int32_t res_f32;
-  const void* res;      int32_t ldres; int32_t M;
-  int32_t C, nh;
-  const float* ln_stats; float ln_eps; int32_t ldw1;
-  const void* w1;
-  const float* cb1;
-  const void* w2c;
-  const float* bias2;
-  void* out;            int32_t ldo;   int32_t ldm;
-  float* out_master;
-  float* rowstats;
-} avsd_ffn_desc;
-int avsd_ffn_block_supported(int C, int nh);
-int avsd_ffn_block(const avsd_ffn_desc* desc_host, void* stream);
-int avsd_sizeof_ffn_desc(void);
-
 /* out[M, N] (f32) = act_out( act_in(x[M, K] f32) . W[N, K]^T + bias ), M <= 16.
  * act: 0 none, 1 SiLU.  Time-embedding MLP and the per-ResBlock time_emb_proj
  * (audio_cond_unet_3d_condition.py:673-680, ff_spatio_temp_resnet_3d.py:170), and the
@@ -280,11 +222,6 @@ int avsd_groupnorm_stats(const void* x1, int ld1, int c1, const void* x2, int ld
 int avsd_groupnorm_apply(const void* x1, int ld1, int c1, const void* x2, int ld2, int c2,
                          int nb, int rows_per_batch, int groups, const float* gamma, const float* beta, float eps,
                          const float* scratch, int nchunks, int act, void* y, int ldy, void* stream);
-/* The fold of the apply step alone: table[b][c] = (scale, shift) as f32 pairs ([nb][channels][2]) from the partials of
- * avsd_groupnorm_stats — for a consumer that applies act(x * scale + shift) itself while it stages its operand
- * (avsd_gemm_bf16 with AVSD_GEMM_GNFUSE: the normalised tensor is never written).  Same arithmetic as avsd_groupnorm_apply. */
-int avsd_groupnorm_table(const float* scratch, int nchunks, int nb, int rows_per_batch, int groups, int channels,
-                         const float* gamma, const float* beta, float eps, float* table, void* stream);
 /* One-launch form for SMALL batches: a workgroup keeps whole groups (rows_per_batch rows x the channels of a few groups,
  * <= ~1900 16-byte vectors) in registers between the statistics and the apply: no scratch, no second read of the input.
  * Same arithmetic as the pair above (f32 sums per thread, folded in double in a fixed order; results differ from the pair

@@ -20,14 +20,8 @@ F32 = torch.float32
 
 def gemm(a, w, *, n=None, k=None, a2=None, bias=None, rowvec=None, rows_per_vec=0, res1=None, res2=None, alpha=1.0,
          geglu=False, gelu=False, out_f32=False, out=None, mode=PLAIN, tmix=None, conv=None, m=None, tile=0, split_k=1,
-         rowstats=None, ln=None, master=None, gn=None):
+         rowstats=None, ln=None, master=None):
     assert a.dtype == P.ACT and w.dtype == P.ACT
-    if gn is not None:          # GroupNorm + SiLU prologue of the 3x3 convolution: the staged input is rounded to 16 bits
-        assert mode == CONV3
-        table, rows_b = gn
-        xc = a.float() if a2 is None else torch.cat([a.float(), a2.float()], 1)
-        t = table.repeat_interleave(rows_b, 0)
-        a, a2 = F.silu(xc * t[..., 0] + t[..., 1]).to(P.ACT), None
     wf = w.float()
     if mode == PLAIN:
         x = a.float() if a2 is None else torch.cat([a.float(), a2.float()], 1)
@@ -132,25 +126,6 @@ def ln_fold(stats):
     return stats.sum(1, keepdim=True)
 
 
-def groupnorm_table(x1, x2, nb, rows_per_batch, groups, gamma, beta, eps):
-    x = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], 1)
-    C = x.shape[1]
-    g = x.reshape(nb, rows_per_batch, groups, C // groups).double()
-    mean = g.mean((1, 3))
-    var = (g * g).mean((1, 3)) - mean * mean
-    rstd = (1.0 / torch.sqrt(var.clamp_min(0) + eps)).float().repeat_interleave(C // groups, 1)
-    mean = mean.float().repeat_interleave(C // groups, 1)
-    scale = rstd * gamma
-    return torch.stack([scale, beta - mean * scale], -1).contiguous()
-
-
-def conv3r_gn_supported(hs, ws, cin, c1, rows_per_batch):
-    """mirror of avsd_gemm_conv3r_gn_supported over the tiles with loader waves (256- and 128-row tiles)"""
-    if cin % 64 or 2 * ws > 64 or (c1 != cin and (c1 <= 0 or c1 >= cin or c1 % 64)):
-        return False
-    return any(bm % ws == 0 and ((hs * ws) % bm == 0 or bm % (hs * ws) == 0) and rows_per_batch % bm == 0 for bm in (256, 128))
-
-
 def layernorm(x, gamma, beta, eps=1e-5, pos=None, hw=1, frames=1, out=None):
     v = x.float()
     if pos is not None:
@@ -187,22 +162,6 @@ def attention(q, k, v, *, bq, lq, lk, kv_rows, heads, q_per_kv, frames, key_inde
 
 def cross_attention_block_supported(C, heads, lk_pad, M, L):
     return C == 320 and heads == 8 and lk_pad in (32, 64, 96) and M % 128 == 0 and L % 128 == 0
-
-
-def ffn_block_supported(C, nh, M):
-    return C == 320 and nh % 16 == 0 and M % 96 == 0
-
-
-def ffn_fold_terms(colsum1, bias1):
-    return torch.stack([colsum1.float().reshape(-1, 32), bias1.float().reshape(-1, 32)], 1).contiguous()
-
-
-def ffn_block(h, stats, w1, cb1, w2c, bias2, *, res, eps=1e-5, master=None, rowstats=None, out=None):
-    """same rounding point as the fused kernel: the hidden activations are rounded to the storage type once"""
-    colsum1, bias1 = cb1[:, 0].reshape(-1), cb1[:, 1].reshape(-1)
-    g = gemm(h, w1, bias=bias1, geglu=True, ln=(stats, colsum1, eps))
-    w2 = w2c.permute(1, 0, 2).reshape(w2c.shape[1], -1)
-    return gemm(g, w2, bias=bias2, res1=res, master=master, rowstats=rowstats, out=out)
 
 
 def cross_attention_block(h, stats, wq, q_colsum, q_bias, k, vt, lk, wo, o_bias, *, res, heads, L, q_per_kv, eps=1e-5, scale=None,

@@ -89,9 +89,8 @@ def _pack(holder, prefix, fn):
 
 
 def _state(gold, f32_stream, fuse_ln=True, **kw):
-    from asva_amd.unet import _Pk, _Side
+    from asva_amd.unet import _Pk
 
-    kw.setdefault("side", _Side(True))
     return _Pk(B=gold["B"], F=gold["F"], temb=None, temb_rows=gold["F"], cond=None, tr_i=0, groups=32, eps=1e-5, heads=(8,),
                fuse_ln=fuse_ln, f32_stream=f32_stream, fp8=None, **kw)
 

@@ -52,12 +52,17 @@ def _worker(rank, world, port, q):
     mine = adist.shard_clips(5, rank, world)
     eng = DenoiseEngine(unet, DDIMScheduler(), audio_guidance_scale=4.0)
     finals = {}
+    # the witness clip (id 0) on EVERY rank, as bench.py does: same seed-by-clip-id inputs, weights from the broadcast
+    gen = torch.Generator().manual_seed(adist.clip_seed(0, base=100))
+    wlat = torch.randn(1, 4, *g["sample"].shape[2:], generator=gen)
+    eng.set_conditioning(g["text"][:1], g["audio"][1:2], g["audio"][:1], audio_segment_mask(wlat.shape[2]), wlat.shape[2])
+    witness = adist.bit_checksum(eng.run(wlat, 1))
     for ci in mine:
-        gen = torch.Generator().manual_seed(100 + ci)
+        gen = torch.Generator().manual_seed(adist.clip_seed(ci, base=100))
         lat = torch.randn(1, 4, *g["sample"].shape[2:], generator=gen)
         eng.set_conditioning(g["text"][:1], g["audio"][1:2], g["audio"][:1], audio_segment_mask(lat.shape[2]), lat.shape[2])
         finals[ci] = float(eng.run(lat, 2).double().sum())
-    rows = adist.gather_metrics([float(len(mine)), float(checksum % 1000003), sum(finals.values())])
+    rows = adist.gather_metrics([float(len(mine)), float(checksum % 1000003), sum(finals.values()), witness])
     adist.barrier()
     q.put((rank, mine, checksum, finals, rows))
     dist.destroy_process_group()
@@ -80,7 +85,18 @@ def test_two_rank_sharded_denoise_with_weight_broadcast():
     assert cs0 == cs1 and cs0 != 0                       # the meta replica holds rank 0's packed bytes after ONE broadcast
     assert rows0 == rows1 and [r[0] for r in rows0] == [3.0, 2.0]     # all-gather: every rank sees every rank's metrics
     assert rows0[0][1] == rows0[1][1]
+    assert rows0[0][3] == rows0[1][3] and rows0[0][3] > 0   # both ranks computed the witness clip bit for bit (bench.py's self-check)
     assert all(map(lambda v: v == v, list(fin0.values()) + list(fin1.values())))   # finite
+
+
+def test_bit_checksum_sees_one_flipped_bit():
+    from asva_amd.dist import bit_checksum, clip_seed
+
+    t = torch.randn(3, 5)
+    u = t.clone()
+    u.view(torch.int32)[1, 2] ^= 1
+    assert bit_checksum(t) == bit_checksum(t.clone()) and bit_checksum(t) != bit_checksum(u)
+    assert clip_seed(3) == 1003 and clip_seed(3, base=7) == 10
 
 
 def test_shard_clips_partition():

@@ -484,3 +484,16 @@ def test_split_precision_twin_storage_and_packing():
     finally:
         P.set_split(False)
         U.ops = old_ops
+
+
+def test_product_filler_matches_the_reference_side_filler():
+    """asva_amd/filler.py (what bench.py fills its parity model with) and oracle/filler.py (what filled the REFERENCE model when
+    the goldens were generated) are two statements of one rule: identical bits for every kind of parameter."""
+    from asva_amd import filler as prod
+    from oracle import filler as ref
+
+    for name, shape in (("conv_in.weight", (320, 4, 3, 3)), ("conv_in.bias", (320,)), ("down_blocks.0.resnets.0.norm1.weight", (320,)),
+                        ("mid_block.attentions.0.transformer_blocks.0.ff.net.0.proj.weight", (10240, 1280)),
+                        ("up_blocks.3.resnets.2.conv1.conv_temp.weight", (320, 960))):
+        assert torch.equal(prod.fill_tensor(name, shape), ref.fill_tensor(name, shape)), name
+    assert torch.equal(prod.seeded_randn(7, 3, 5), ref.seeded_randn(7, 3, 5))

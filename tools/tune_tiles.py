@@ -16,7 +16,6 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if "--extend" not in sys.argv:
     os.environ.setdefault("AVSD_TILE_CACHE", "/nonexistent")    # start from an empty table (--extend: keep the shipped one, add what is missing)
-os.environ["AVSD_SIDE_STREAM"] = "0"                            # the measuring tuner times on one stream
 import torch  # noqa: E402
 
 import bench  # noqa: E402

@@ -886,6 +886,7 @@ int avsd_gemm_dispatch_x2_conv3(const avsd_gemm_desc& d, int tile, hipStream_t s
 
 #if !defined(AVSD_GEMM_TU) || AVSD_GEMM_TU == 3
 int avsd_gemm_dispatch_conv3r(const avsd_gemm_desc& d, hipStream_t s);      // conv3r.hip
+int avsd_gemm_dispatch_asm(const avsd_gemm_desc& d, hipStream_t s);         // gemm4.hip
 
 // the reduce / epilogue launch of a split-K GEMM, for kernels outside this file that write the same slabs (conv3r.hip)
 int avsd_gemm_splitk_reduce(const avsd_gemm_desc& d, hipStream_t s) {
@@ -956,6 +957,7 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
     if (d.split_k > 1) AVSD_REQUIRE(d.splitk_ws != nullptr, "gemm: split_k needs a workspace");
     return avsd_gemm_dispatch_conv3r(d, reinterpret_cast<hipStream_t>(stream));
   }
+  if (d.tile >= AVSD_GEMM_TILE_ASM_FIRST && d.tile <= AVSD_GEMM_TILE_ASM_LAST) return avsd_gemm_dispatch_asm(d, reinterpret_cast<hipStream_t>(stream));
   if (d.split_k > 1) {
     AVSD_REQUIRE(d.splitk_ws != nullptr, "gemm: split_k needs a workspace");
     AVSD_REQUIRE(!(d.flags & AVSD_GEMM_GEGLU) && d.batch == 1, "gemm: split_k cannot be combined with GEGLU or batching");

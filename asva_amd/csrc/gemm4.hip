@@ -41,13 +41,7 @@ constexpr int ROWB = 144;          // LDS row pitch: 64 values + 8 pad = 144 B -
 #define AVSD_MFMA_OP "v_mfma_f32_32x32x16_bf16"
 #endif
 
-#define G4_MFMA(ACC, WF, XF) asm volatile(AVSD_MFMA_OP " %0, %1, %2, %0" : "+a"(ACC) : "v"(WF), "v"(XF))
-#define G4_DSREAD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
-#define G4_DSWRITE(ADDR, SRC, OFF) asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(ADDR), "v"(SRC), "n"(OFF) : "memory")
-#define G4_GLOAD(DST, VOFF, RSRC) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(DST) : "v"(VOFF), "s"(RSRC) : "memory")
-#define G4_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory")
-#define G4_WAIT_LGKM(N) asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(N) : "memory")
-#define G4_BARRIER() asm volatile("s_barrier" ::: "memory")
+#include "gemm4_loops.inc"
 
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
@@ -63,15 +57,10 @@ template <int FM, int FN, int MODE>
 __global__ __launch_bounds__(256, 1) void gemm4_kernel(const avsd_gemm_desc p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem4[];
   constexpr int BM = 64 * FM, BN = 64 * FN;
-  constexpr int NA = BM / 32, NW = BN / 32;          // 16-byte global loads per thread per K tile (A rows, W rows)
-  constexpr int NL = NA + NW;
-  constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;
-  constexpr int NMF = FM * FN;                        // MFMAs per k-step
-  constexpr int NFR = FM + FN;                        // fragment reads per k-step
-  constexpr int WPK = (NL + 2) / 3;                   // write + reload pairs per k-step (k-steps 0..2)
-  static_assert(MODE == AVSD_GEMM_PLAIN, "gemm4: PLAIN operands");
-  static_assert(2 * NL - 1 < 64 && WPK < 16, "vmcnt is a 6-bit, lgkmcnt a 4-bit counter");
-  static_assert((NA > NW ? NA : NW) * 32 * ROWB < 65536, "ds offset field is 16 bits");
+  constexpr int A_BYTES = BM * ROWB;
+  static_assert(MODE == AVSD_GEMM_PLAIN || MODE == AVSD_GEMM_TMIX, "gemm4: PLAIN or TMIX operands");
+  constexpr int NA = BM / 32;
+  constexpr int STAGE = (BM + BN) * ROWB;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -100,143 +89,72 @@ __global__ __launch_bounds__(256, 1) void gemm4_kernel(const avsd_gemm_desc p) {
   const int kt0 = ksplit * per_split;
   const int nk = max(min(nk_all, kt0 + per_split) - kt0, 0);
 
-  // buffer descriptors in scalar registers (operands of the load statements)
+  // buffer descriptors (scalar registers): num_records = the rows that exist, so rows past M / N read as zeros
+  // (TMIX: every source row of a valid output row is a valid row; rows past M get an offset past num_records below)
   const unsigned long long pa = (unsigned long long)p.A, pw = (unsigned long long)p.W;
-  const u32x4 rsA = {(unsigned)pa, (unsigned)(pa >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u};
-  const u32x4 rsW = {(unsigned)pw, (unsigned)(pw >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u};
+  const u32x4 rsA = {(unsigned)pa, (unsigned)(pa >> 32) & 0xffffu, (unsigned)p.M * (unsigned)p.lda * 2u, 0x00020000u};
+  const u32x4 rsW = {(unsigned)pw, (unsigned)(pw >> 32) & 0xffffu, (unsigned)p.N * (unsigned)p.ldw * 2u, 0x00020000u};
 
-  // ---- staging: thread t moves the 16-byte vector (row (t >> 3) + 32 i, k-chunk t & 7) of each operand tile ---------------
+  // staging: thread t moves the 16-byte vector (row (t >> 3) + 32 i, k-chunk t & 7) of each operand tile; fragment row
+  // wm/wn * (32 F) + 32 b + (lane & 31), 16-byte chunk 2 ks + (lane >> 5)
   const int srow = tid >> 3, sch = tid & 7;
-  unsigned va[NA], vw[NW];                 // byte offsets of this thread's vectors in the NEXT tile to load
-#pragma unroll
-  for (int i = 0; i < NA; ++i) {
-    const int m = tm * BM + srow + 32 * i;
-    va[i] = m < p.M ? (unsigned)(m * p.lda + kt0 * BK + sch * 8) * 2u : 0x80000000u;       // rows past M: zero-filled by the bounds check
-  }
-#pragma unroll
-  for (int i = 0; i < NW; ++i) {
-    const int n = tn * BN + srow + 32 * i;
-    vw[i] = n < p.N ? (unsigned)(n * p.ldw + kt0 * BK + sch * 8) * 2u : 0x80000000u;
-  }
-  // LDS byte addresses per stage (the 16-bit offset field of the ds instructions cannot span a 72-KB stage): vector i of a tile
-  // at + i * 32 * ROWB; fragment row wm/wn * (32 F) + 32 b + (lane & 31), 16-byte chunk 2 ks + (lane >> 5)
-  unsigned wr_a[2], wr_w[2], rd_a[2], rd_w[2];
-#pragma unroll
-  for (int st = 0; st < 2; ++st) {
-    wr_a[st] = (unsigned)(st * STAGE + srow * ROWB + sch * 16);
-    wr_w[st] = wr_a[st] + A_BYTES;
-    rd_a[st] = (unsigned)(st * STAGE + (wm * 32 * FM + (lane & 31)) * ROWB + (lane >> 5) * 16);
-    rd_w[st] = (unsigned)(st * STAGE + A_BYTES + (wn * 32 * FN + (lane & 31)) * ROWB + (lane >> 5) * 16);
-  }
+  const unsigned va0 = (unsigned)((tm * BM + srow) * p.lda + kt0 * BK + sch * 8) * 2u;
+  const unsigned vw0 = (unsigned)((tn * BN + srow) * p.ldw + kt0 * BK + sch * 8) * 2u;
+  const unsigned wr0 = (unsigned)(srow * ROWB + sch * 16);
+  const unsigned rda0 = (unsigned)((wm * 32 * FM + (lane & 31)) * ROWB + (lane >> 5) * 16);
+  const unsigned rdw0 = (unsigned)(A_BYTES + (wn * 32 * FN + (lane & 31)) * ROWB + (lane >> 5) * 16);
+  const unsigned sa = 32u * (unsigned)p.lda * 2u, sw = 32u * (unsigned)p.ldw * 2u;
 
   f32x16 acc[FN][FM];
+  if constexpr (MODE == AVSD_GEMM_TMIX) {
+    // temporal-mix A operand (utils.py:43-53): K segment s of output row (b, f, p) reads row (b, {0, max(f - 1, 0), f}[s], p).  Per 16-byte
+    // vector of this thread: its byte offset in the first tile of this K slice and the two jumps it takes, on top of the regular
+    // +128 bytes per K tile, when the tile index crosses a segment boundary.  The asm loop fetches them from the second LDS stage
+    // (unused until its first write, which follows these reads in the same wave's in-order LDS queue).
+    const int tps = p.cseg / BK;                                   // K tiles per segment
+    const int seg0 = kt0 / tps, col0 = (kt0 - seg0 * tps) * BK;
+    unsigned* tbl = reinterpret_cast<unsigned*>(smem4 + STAGE) + tid * (3 * NA);
 #pragma unroll
-  for (int a = 0; a < FN; ++a)
-#pragma unroll
-    for (int b = 0; b < FM; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  u32x4 g[2][NL];                         // staging registers of two K tiles in flight
-  h16x8 xf[2][FM], wf[2][FN];             // fragments of two k-steps
-
-  int t_load = 0;                         // index (from kt0) of the next tile to load
-  // after the loads of a tile are issued its offsets advance by one K tile — except past the end of K, where the last tile
-  // is loaded again (never consumed: keeps the loop uniform and every address inside the tensors)
-  auto advance = [&]() {
-    ++t_load;
-    const unsigned inc = t_load < nk ? BK * 2u : 0u;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) va[i] += inc;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) vw[i] += inc;
-  };
-  auto load_one = [&g, &va, &vw, &rsA, &rsW](auto s_c, auto j_c) {
-    constexpr int S = decltype(s_c)::value, J = decltype(j_c)::value;
-    if constexpr (J < NA) G4_GLOAD(g[S][J], va[J], rsA);
-    else G4_GLOAD(g[S][J], vw[J - NA], rsW);
-  };
-  auto write_one = [&g, &wr_a, &wr_w](auto s_c, auto st_c, auto j_c) {
-    constexpr int S = decltype(s_c)::value, ST = decltype(st_c)::value, J = decltype(j_c)::value;
-    if constexpr (J < NA) G4_DSWRITE(wr_a[ST], g[S][J], J * 32 * ROWB);
-    else G4_DSWRITE(wr_w[ST], g[S][J], (J - NA) * 32 * ROWB);
-  };
-  // fragment read R (0 .. FM + FN - 1) of k-step KS from LDS stage ST into fragment set FS
-  auto frag_read = [&xf, &wf, &rd_a, &rd_w](auto fs_c, auto st_c, auto ks_c, auto r_c) {
-    constexpr int FS = decltype(fs_c)::value, ST = decltype(st_c)::value, KS = decltype(ks_c)::value, R = decltype(r_c)::value;
-    if constexpr (R < FM) G4_DSREAD(xf[FS][R], rd_a[ST], R * 32 * ROWB + KS * 32);
-    else G4_DSREAD(wf[FS][R - FM], rd_w[ST], (R - FM) * 32 * ROWB + KS * 32);
-  };
-  using c0 = std::integral_constant<int, 0>;
-  using c1 = std::integral_constant<int, 1>;
-
-  // ---- prologue: tiles 0 and 1 in flight, tile 0 to LDS stage 0, tile 2 issued, fragments of k-step 0 ------------------------
-  if (nk > 0) {
-  static_for<NL>([&](auto j) { load_one(c0{}, j); });
-  advance();
-  static_for<NL>([&](auto j) { load_one(c1{}, j); });
-  advance();
-  G4_WAIT_VM(NL);                               // tile 0 landed (tile 1 may still be in flight)
-  static_for<NL>([&](auto j) { write_one(c0{}, c0{}, j); });
-  static_for<NL>([&](auto j) { load_one(c0{}, j); });
-  advance();
-  G4_WAIT_LGKM(0);
-  G4_BARRIER();
-  static_for<NFR>([&](auto r) { frag_read(c0{}, c0{}, c0{}, r); });
-  G4_WAIT_LGKM(0);
-
-  // One K tile: CS = LDS stage of the tile being multiplied (its successor goes to CS ^ 1 from staging set GS).
-  auto tile = [&acc, &xf, &wf, &load_one, &write_one, &frag_read, &advance](auto cs_c, auto gs_c) {
-    constexpr int CS = decltype(cs_c)::value;
-    static_for<4>([&acc, &xf, &wf, &load_one, &write_one, &frag_read, &advance, cs_c, gs_c](auto ks_c) {
-      constexpr int CS = decltype(cs_c)::value;
-      constexpr int KS = decltype(ks_c)::value;
-      constexpr int FS = KS & 1;
-      constexpr int NWR = KS < 3 ? (NL - KS * WPK < WPK ? (NL - KS * WPK > 0 ? NL - KS * WPK : 0) : WPK) : 0;   // writes in this k-step
-      constexpr int NF = NFR + NWR;                 // memory "fillers" of this k-step: the fragment reads first, then the write + reload pairs
-      static_for<NMF>([&acc, &xf, &wf, &load_one, &write_one, &frag_read, cs_c, gs_c, ks_c](auto i_c) {
-        constexpr int CS = decltype(cs_c)::value, KS = decltype(ks_c)::value, FS = KS & 1;
-        constexpr int I = decltype(i_c)::value;
-        G4_MFMA(acc[I / FM][I % FM], wf[FS][I / FM], xf[FS][I % FM]);
-        static_for<NF>([&load_one, &write_one, &frag_read, cs_c, gs_c, ks_c, i_c](auto f_c) {
-          constexpr int CS = decltype(cs_c)::value, KS = decltype(ks_c)::value, FS = KS & 1, I = decltype(i_c)::value;
-          constexpr int Fi = decltype(f_c)::value;
-          constexpr int SLOT = NF <= NMF ? Fi : Fi * NMF / NF;      // one per MFMA shadow while they fit, else spread evenly
-          if constexpr (SLOT == I) {
-            if constexpr (Fi < NFR) {
-              // fragments of the next k-step: same stage for k-steps 1..3, the other stage (tile t+1, k-step 0) in k-step 3
-              if constexpr (KS < 3) frag_read(std::integral_constant<int, FS ^ 1>{}, cs_c, std::integral_constant<int, KS + 1>{}, f_c);
-              else frag_read(std::integral_constant<int, FS ^ 1>{}, std::integral_constant<int, CS ^ 1>{}, c0{}, f_c);
-            } else {
-              constexpr int J = KS * WPK + (Fi - NFR);
-              G4_WAIT_VM(2 * NL - 1);             // the oldest load in flight (vector J of tile t+1) has landed
-              write_one(gs_c, std::integral_constant<int, CS ^ 1>{}, std::integral_constant<int, J>{});
-              load_one(gs_c, std::integral_constant<int, J>{});
-            }
-          }
-        });
-      });
-      if constexpr (KS == 2) {
-        advance();                              // (all NL reloads of tile t+3 are issued by now)
-        G4_WAIT_LGKM(0);
-        G4_BARRIER();
-      } else if constexpr (KS == 3) {
-        G4_WAIT_LGKM(0);
-      } else {
-        G4_WAIT_LGKM(NWR);                      // the NFR fragment reads are older than this k-step's NWR writes
+    for (int i = 0; i < NA; ++i) {
+      const int m = tm * BM + srow + 32 * i;
+      unsigned v = 0xC0000000u, d01 = 0u, d12 = 0u;              // rows past M: far past num_records, and they stay there
+      if (m < p.M) {
+        const int f = (m / p.hw) % p.frames;
+        const int r0 = m - f * p.hw, r1 = f > 0 ? m - p.hw : m;
+        const int o[3] = {r0 * p.lda, r1 * p.lda, m * p.lda};
+        v = (unsigned)(o[seg0 < 3 ? seg0 : 2] + col0 + sch * 8) * 2u;
+        d01 = (unsigned)(o[1] - o[0] - p.cseg) * 2u;
+        d12 = (unsigned)(o[2] - o[1] - p.cseg) * 2u;
       }
-    });
-  };
-
-  int t = 0;
-  for (; t + 1 < nk; t += 2) {
-    tile(c0{}, c1{});
-    tile(c1{}, c0{});
+      tbl[i] = v; tbl[NA + i] = d01; tbl[2 * NA + i] = d12;
+    }
+    const unsigned tbl_addr = (unsigned)(STAGE + tid * (3 * NA) * 4);
+    if (nk > 0) {
+      if constexpr (FM == 4 && FN == 2) g4_loop_4x2_s2_tmix(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, (unsigned)kt0, sw, (unsigned)nk, (unsigned)tps, 2u * tps);
+      else if constexpr (FM == 2 && FN == 4) g4_loop_2x4_s2_tmix(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, (unsigned)kt0, sw, (unsigned)nk, (unsigned)tps, 2u * tps);
+      else if constexpr (FM == 2 && FN == 2) g4_loop_2x2_s2_tmix(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, (unsigned)kt0, sw, (unsigned)nk, (unsigned)tps, 2u * tps);
+      else if constexpr (FM == 2 && FN == 1) g4_loop_2x1_s2_tmix(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, (unsigned)kt0, sw, (unsigned)nk, (unsigned)tps, 2u * tps);
+      else if constexpr (FM == 1 && FN == 2) g4_loop_1x2_s2_tmix(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, (unsigned)kt0, sw, (unsigned)nk, (unsigned)tps, 2u * tps);
+      else if constexpr (FM == 1 && FN == 1) g4_loop_1x1_s2_tmix(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, (unsigned)kt0, sw, (unsigned)nk, (unsigned)tps, 2u * tps);
+    }
+  } else
+  if (nk > 0) {
+    if constexpr (FM == 4 && FN == 4) g4_loop_4x4_s2(acc, va0, vw0, wr0, rda0, rdw0, rsA, rsW, sa, sw, (unsigned)nk);
+    else if constexpr (FM == 4 && FN == 2) g4_loop_4x2_s2(acc, va0, vw0, wr0, rda0, rdw0, rsA, rsW, sa, sw, (unsigned)nk);
+    else if constexpr (FM == 2 && FN == 4) g4_loop_2x4_s2(acc, va0, vw0, wr0, rda0, rdw0, rsA, rsW, sa, sw, (unsigned)nk);
+    else if constexpr (FM == 2 && FN == 2) g4_loop_2x2_s2(acc, va0, vw0, wr0, rda0, rdw0, rsA, rsW, sa, sw, (unsigned)nk);
+    else if constexpr (FM == 2 && FN == 1) g4_loop_2x1_s2(acc, va0, vw0, wr0, rda0, rdw0, rsA, rsW, sa, sw, (unsigned)nk);
+    else if constexpr (FM == 1 && FN == 2) g4_loop_1x2_s2(acc, va0, vw0, wr0, rda0, rdw0, rsA, rsW, sa, sw, (unsigned)nk);
+    else g4_loop_1x1_s2(acc, va0, vw0, wr0, rda0, rdw0, rsA, rsW, sa, sw, (unsigned)nk);
   }
-  if (t < nk) tile(c0{}, c1{});
-  G4_WAIT_VM(0);
+  if (nk <= 0) {
+#pragma unroll
+    for (int a = 0; a < FN; ++a)
+#pragma unroll
+      for (int b = 0; b < FM; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   }
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // MFMA results -> any other reader
 
   const int m_base = tm * BM + wm * 32 * FM, n_base = tn * BN + wn * 32 * FN;
   if (p.split_k > 1) {
@@ -258,8 +176,16 @@ __global__ __launch_bounds__(256, 1) void gemm4_kernel(const avsd_gemm_desc p) {
     }
     return;
   }
-  const float pre_ln[2 * FM] = {};
-  epilogue<FN, FM>(p, acc, m_base, n_base, lane, 0, pre_ln, false);
+  // the shared epilogue, one 32-row fragment band at a time (a 16-fragment instantiation does not unroll: the accumulators would
+  // go through scratch memory); a band of FN <= 4 fragments takes the term-at-a-time form with batched operand loads
+  static_for<FM>([&p, &acc, m_base, n_base, lane](auto b_c) {
+    constexpr int B = decltype(b_c)::value;
+    f32x16 band[FN][1];
+#pragma unroll
+    for (int a = 0; a < FN; ++a) band[a][0] = acc[a][B];
+    const float pre_ln[2] = {};
+    epilogue<FN, 1>(p, band, m_base + 32 * B, n_base, lane, 0, pre_ln, false);
+  });
 }
 
 template <int FM, int FN, int MODE>
@@ -288,15 +214,31 @@ int launch4(const avsd_gemm_desc& d, hipStream_t s) {
 }  // namespace
 
 int avsd_gemm_dispatch_asm(const avsd_gemm_desc& d, hipStream_t s) {
-  AVSD_REQUIRE(d.mode == AVSD_GEMM_PLAIN && !d.A2 && d.batch == 1 && !(d.flags & AVSD_GEMM_X2) && d.K % 64 == 0,
-               "gemm/asm tiles: PLAIN single-source 16-bit operands with K %% 64 == 0 (got mode %d, K %d)", d.mode, d.K);
-  AVSD_REQUIRE((double)d.M * d.lda * 2.0 < 2147483648.0 && (double)d.N * d.ldw * 2.0 < 2147483648.0, "gemm/asm tiles: operands must be < 2 GiB");
+  AVSD_REQUIRE((d.mode == AVSD_GEMM_PLAIN || d.mode == AVSD_GEMM_TMIX) && !d.A2 && d.batch == 1 && !(d.flags & AVSD_GEMM_X2) && d.K % 64 == 0,
+               "gemm/asm tiles: PLAIN single-source or TMIX 16-bit operands with K %% 64 == 0 (got mode %d, K %d)", d.mode, d.K);
+  AVSD_REQUIRE((double)d.M * d.lda * 2.0 < 1073741824.0 && (double)d.N * d.ldw * 2.0 < 1073741824.0, "gemm/asm tiles: operands must be < 1 GiB");
   AVSD_REQUIRE(d.split_k <= 1 || (d.splitk_ws && d.split_k <= d.K / 64 && !(d.flags & AVSD_GEMM_GEGLU)), "gemm/asm tiles: bad split_k %d", d.split_k);
-  switch (d.tile - AVSD_GEMM_TILE_ASM_FIRST) {
+  const int k = d.tile - AVSD_GEMM_TILE_ASM_FIRST;
+  if (d.mode == AVSD_GEMM_TMIX) {
+    AVSD_REQUIRE(d.cseg % 64 == 0 && !(d.flags & AVSD_GEMM_LNFUSE), "gemm/asm tiles: TMIX needs cseg %% 64 == 0 (got %d)", d.cseg);
+    switch (k) {
+      case 1: return launch4<4, 2, AVSD_GEMM_TMIX>(d, s);
+      case 2: return launch4<2, 4, AVSD_GEMM_TMIX>(d, s);
+      case 3: return launch4<2, 2, AVSD_GEMM_TMIX>(d, s);
+      case 4: return launch4<2, 1, AVSD_GEMM_TMIX>(d, s);
+      case 5: return launch4<1, 2, AVSD_GEMM_TMIX>(d, s);
+      case 6: return launch4<1, 1, AVSD_GEMM_TMIX>(d, s);
+      default: AVSD_REQUIRE(false, "gemm/asm tiles: tile %d has no TMIX form (61..66 do)", d.tile);
+    }
+  }
+  switch (k) {
     case 0: return launch4<4, 4, AVSD_GEMM_PLAIN>(d, s);     // 256 x 256, 128 x 128 per wave, 144 KB
     case 1: return launch4<4, 2, AVSD_GEMM_PLAIN>(d, s);     // 256 x 128, 108 KB
     case 2: return launch4<2, 4, AVSD_GEMM_PLAIN>(d, s);     // 128 x 256
     case 3: return launch4<2, 2, AVSD_GEMM_PLAIN>(d, s);     // 128 x 128, 72 KB: two workgroups per CU
+    case 4: return launch4<2, 1, AVSD_GEMM_PLAIN>(d, s);     // 128 x 64, 54 KB
+    case 5: return launch4<1, 2, AVSD_GEMM_PLAIN>(d, s);     // 64 x 128
+    case 6: return launch4<1, 1, AVSD_GEMM_PLAIN>(d, s);     // 64 x 64, 36 KB: four workgroups per CU
     default: AVSD_REQUIRE(false, "gemm/asm tiles: unknown tile %d", d.tile);
   }
 }

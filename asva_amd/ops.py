@@ -111,6 +111,12 @@ X2_TILE_CANDIDATES = ((7, 1), (11, 1), (13, 1), (24, 1), (25, 1), (34, 1), (35, 
 X2_SPLITK_CANDIDATES = ((34, 2), (34, 4), (35, 2), (35, 4), (36, 2), (36, 4), (7, 2), (7, 4), (7, 8), (11, 2), (11, 4), (24, 2), (24, 4), (24, 8), (25, 2), (25, 4), (25, 8))
 # 3x3 stride-1 convolutions with the input tile resident in LDS (csrc/conv3r.hip): tile ids 40-49, geometry-dependent
 # (avsd_gemm_conv3r_supported); split_k cuts the cin / 64 channel chunks
+# 4-wave tiles with a hand-scheduled main loop (csrc/gemm4.hip): 60 = 256x256, 61 = 256x128, 62 = 128x256, 63 = 128x128; PLAIN, K % 64 == 0
+# 64 = 128x64, 65 = 64x128, 66 = 64x64; TMIX (cseg % 64 == 0): 61..66
+ASM_CANDIDATES = ((60, 1), (61, 1), (62, 1), (63, 1), (64, 1), (65, 1), (66, 1))
+ASM_SPLITK_CANDIDATES = ((63, 2), (63, 4), (63, 8), (61, 2), (62, 2), (62, 4), (64, 2), (64, 4), (65, 2), (65, 4), (66, 2), (66, 4))
+ASM_TILES = tuple(range(60, 67))
+_ASM_TILES = os.environ.get("AVSD_ASM_TILES", "1") != "0"
 CONV3R_TILES = (40, 42, 43, 44, 48)
 CONV3R2D_TILES = (51, 52, 53, 54)   # rectangular resident tiles (TH rows x 32 pixels) for images wider than 32 pixels: the VAE decoder, cfg 4
 _CONV3R2D_BN = {51: 128, 52: 160, 53: 128, 54: 128}
@@ -295,16 +301,42 @@ def _time_cold(launch, cand, warm, reps=7):
     return sorted(ms)[len(ms) // 2]
 
 
-def _pick_tile(key, launch, candidates=TILE_CANDIDATES, warm=None):
+_CHALLENGE = os.environ.get("AVSD_TUNE_CHALLENGE", "0") == "1"     # tools/tune_tiles.py --challenge: re-time table entries against new tiles
+_CHALLENGED: set = set()
+CHALLENGE_LOG: list = []
+
+
+def _challenge(key, launch, challengers, warm):
+    """the table's entry for `key` against `challengers` (new tile ids): replaced when one of them is >= 3 % faster hot (two
+    interleaved rounds, best-of) and not slower against cold weights"""
+    inc = _TILE_CACHE[key]
+    _CHALLENGED.add(key)
+    times = {}
+    for rnd in range(2):
+        for cand in (inc,) + tuple(c for c in challengers if c != inc):
+            if rnd == 0:
+                launch(*cand)
+            times[cand] = min(_time_hot(launch, cand), times.get(cand, float("inf")))
+    best = min(times, key=times.get)
+    if best != inc and times[best] < 0.97 * times[inc] and (warm is None or _time_cold(launch, best, warm) < _time_cold(launch, inc, warm)):
+        CHALLENGE_LOG.append((key, inc, best, times[inc] * 1e3, times[best] * 1e3))
+        _TILE_CACHE[key] = best
+
+
+def _pick_tile(key, launch, candidates=TILE_CANDIDATES, warm=None, challengers=()):
     """-> (tile, split_k).  Two passes: every candidate is timed back to back on a hot L2 (two interleaved rounds,
     best-of: robust to clock ramp / noise); the four fastest are then re-timed launch by launch against cold weights
     and warm activations (`warm`: the activation tensors; median of 7) — the state a launch meets inside a denoising
     step — and the winner of that pass is cached.  AVSD_TUNE_COLD=0 keeps the first pass only."""
     t = _TILE_CACHE.get(key)
     if t is not None:
+        if _CHALLENGE and challengers and key not in _CHALLENGED and _AUTOTUNE and _TIMER is None and not torch.cuda.is_current_stream_capturing():
+            _challenge(key, launch, challengers, warm)
+            return _TILE_CACHE[key]
         return t
     if not _AUTOTUNE or _TIMER is not None or torch.cuda.is_current_stream_capturing():
         return None
+    candidates = tuple(candidates) + tuple(challengers)
     times = {}
     for rnd in range(2):
         for cand in candidates:
@@ -553,7 +585,15 @@ def gemm(
             key = key + (d.hs, d.ws)
         if two_src_conv:
             key = key + ("a2", d.k_split)                         # a table entry of the one-source shape may name a tile that never reads A2
-        picked = _pick_tile(key, _launch, cands, warm=(a, a2, res1, res2))
+        asm = ()
+        if (_ASM_TILES and a2 is None and not P.SPLIT and K % 64 == 0 and M * lda < (1 << 29) and N * _ld(w) < (1 << 29) and
+                (mode == PLAIN or (mode == TMIX and d.cseg % 64 == 0 and ln is None))):
+            asm = tuple(c for c in ASM_CANDIDATES if mode == PLAIN or c[0] != 60)
+            if splitk_ok and ((M + 127) // 128) * ((N + 127) // 128) < 256 and nk >= 8:
+                asm = asm + tuple(c for c in ASM_SPLITK_CANDIDATES if nk // c[1] >= 4)
+        picked = _pick_tile(key, _launch, cands, warm=(a, a2, res1, res2), challengers=asm)
+        if picked is not None and picked[0] in ASM_TILES and not asm:        # (a two-source call shares the key of the one-source shape)
+            picked = None
         if picked is not None and picked[0] in CONV3R_TILES and not ((_CONV3R or two_src_conv) and _lib.lib().avsd_gemm_conv3r_supported(picked[0], d.hs, d.ws, d.cin)):
             picked = None
         if picked is not None and picked[0] in CONV3R2D_TILES and not ((_CONV3R or two_src_conv) and _lib.lib().avsd_gemm_conv3r2d_supported(picked[0], d.hs, d.ws, d.cin)):

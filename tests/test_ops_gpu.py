@@ -256,7 +256,7 @@ def test_gemm_conv3_resident_refuses_other_convolutions(ops):
         ops.gemm(x, wp, mode=ops.CONV3, conv=(2, 16, 16, 1, 0), tile=44, split_k=2)
 
 
-@pytest.mark.parametrize("tile,split", [(0, 1), (3, 1), (6, 1), (13, 1), (17, 1), (20, 1), (25, 1), (7, 2), (26, 4)])
+@pytest.mark.parametrize("tile,split", [(0, 1), (3, 1), (6, 1), (13, 1), (17, 1), (20, 1), (25, 1), (7, 2), (24, 4), (63, 1), (65, 2)])
 def test_gemm_layernorm_fusion(ops, tile, split):
     """LayerNorm folded into the GEMMs around it (AVSD_GEMM_ROWSTATS / AVSD_GEMM_LNFUSE): the producer's per-32-column
     (sum, sumsq) pairs are exact for its rounded output, and consumer(raw h) == Linear(LayerNorm(h))."""
@@ -298,7 +298,7 @@ def test_gemm_layernorm_fusion(ops, tile, split):
         assert rel_l2(yb, refb) < TOL_BF16
 
 
-@pytest.mark.parametrize("tile,split", [(4, 2), (6, 4), (7, 3), (9, 2), (8, 5), (20, 4), (22, 2), (25, 3), (18, 2), (26, 8), (24, 3), (29, 4), (30, 3), (31, 2), (32, 3), (33, 2)])
+@pytest.mark.parametrize("tile,split", [(4, 2), (6, 4), (7, 3), (9, 2), (8, 5), (20, 4), (22, 2), (25, 3), (19, 2), (24, 3), (30, 3), (31, 2), (32, 3), (38, 2)])
 def test_gemm_split_k(ops, tile, split):
     from asva_amd.weights import pack_conv3x3
 
@@ -747,3 +747,69 @@ def test_xattn_pack_kv_matches_indexing(ops, gather):
         kv3 = kv3[:, idx.long()].reshape(nb, lk, 2 * C)
     assert torch.equal(k[:, :lk], kv3[..., :C]) and torch.equal(vt[:, :, :lk], kv3[..., C:].transpose(1, 2))
     assert not k[:, lk:].any() and not vt[:, :, lk:].any()          # padding zero-filled by the launch
+
+
+# ---- hand-scheduled 4-wave tiles (csrc/gemm4.hip, ids 60-66) ---------------------------------------------------------------
+ASM_TILES = [60, 61, 62, 63, 64, 65, 66]
+
+
+@pytest.mark.parametrize("tile", ASM_TILES)
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 384, 320), (1000, 640, 1280), (77, 132, 192), (3000, 320, 640)])
+def test_gemm_asm_tiles_plain(ops, tile, M, N, K):
+    """csrc/gemm4.hip: same products in the same K order as the LDS-direct tiles -> bit-identical to tile 9 (odd and even numbers of K
+    tiles, M / N tails, K = one tile), against torch in f32, run to run; split-K slabs; every epilogue term"""
+    a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    bias, res, res2 = rndf(N, seed=3), rnd(M, N, seed=4), rnd(M, N, seed=5)
+    out = ops.gemm(a, w, bias=bias, res1=res, res2=res2, alpha=0.5, tile=tile)
+    assert rel_l2(out, 0.5 * (a.float() @ w.float().T) + bias + res.float() + res2.float()) < TOL_BF16
+    assert torch.equal(out, ops.gemm(a, w, bias=bias, res1=res, res2=res2, alpha=0.5, tile=9))
+    o32 = ops.gemm(a, w, bias=bias, out_f32=True, tile=tile)
+    assert rel_l2(o32, a.float() @ w.float().T + bias) < TOL_F32 and torch.equal(o32, ops.gemm(a, w, bias=bias, out_f32=True, tile=9))
+    assert all(torch.equal(ops.gemm(a, w, bias=bias, out_f32=True, tile=tile), o32) for _ in range(3))
+    if K >= 256:
+        for sk in (2, 3):
+            assert torch.equal(ops.gemm(a, w, bias=bias, out_f32=True, tile=tile, split_k=sk), ops.gemm(a, w, bias=bias, out_f32=True, tile=9, split_k=sk))
+    if N % 32 == 0:         # LayerNorm producer / consumer flags and GEGLU through the shared epilogue
+        st, st9 = torch.empty(M, N // 32, 2, device=dev()), torch.empty(M, N // 32, 2, device=dev())
+        h = ops.gemm(a, w, bias=bias, res1=res, rowstats=st, tile=tile)
+        assert torch.equal(h, ops.gemm(a, w, bias=bias, res1=res, rowstats=st9, tile=9)) and torch.equal(st, st9)
+        if N % 64 == 0:
+            w2 = rnd(64, N, seed=7, scale=N ** -0.5)
+            cs = w2.float().sum(1)
+            y = ops.gemm(h, w2, ln=(st, cs, 1e-5), tile=tile)
+            assert torch.equal(y, ops.gemm(h, w2, ln=(st, cs, 1e-5), tile=9))
+            assert torch.equal(ops.gemm(h, w2, geglu=True, ln=(ops.ln_fold(st), cs, 1e-5), tile=tile),
+                               ops.gemm(h, w2, geglu=True, ln=(ops.ln_fold(st), cs, 1e-5), tile=9))
+
+
+@pytest.mark.parametrize("tile", [61, 62, 63, 64, 65, 66])
+@pytest.mark.parametrize("B,hw,C,N", [(2, 64, 320, 320), (1, 32, 128, 132), (3, 96, 64, 64), (1, 16, 1280, 1280)])
+def test_gemm_asm_tiles_tmix(ops, tile, B, hw, C, N):
+    """the temporal-mix A operand in the hand-scheduled loop: per-vector jumps at the two K-segment boundaries (frame 0 -> previous
+    frame -> current frame), also for K slices that start inside a segment; full epilogue; against the f32 statement and tile 9"""
+    Fr = 12
+    M = B * Fr * hw
+    y = rnd(M, C, seed=1)
+    w = rnd(N, 3 * C, seed=2, scale=(3 * C) ** -0.5)
+    b, temb, res2 = rndf(N, seed=3), rndf(B, N, seed=5), rnd(M, N, seed=4)
+    y5 = y.float().reshape(B, Fr, hw, C)
+    prev = torch.cat([y5[:, :1], y5[:, :-1]], 1)
+    cat = torch.cat([y5[:, :1].expand_as(y5), prev, y5], -1).reshape(M, 3 * C)
+    ref = cat @ w.float().T + b + temb.repeat_interleave(Fr * hw, 0) + res2.float()
+    kw = dict(bias=b, rowvec=temb, rows_per_vec=Fr * hw, res2=res2, mode=ops.TMIX, tmix=(hw, Fr))
+    assert rel_l2(ops.gemm(y, w, tile=tile, **kw), ref) < TOL_BF16
+    o32 = ops.gemm(y, w, out_f32=True, tile=tile, **kw)
+    assert rel_l2(o32, ref) < TOL_F32 and torch.equal(o32, ops.gemm(y, w, out_f32=True, tile=9, **kw))
+    for sk in (2, 3):
+        if (3 * C // 64) // sk >= 2:
+            assert torch.equal(ops.gemm(y, w, out_f32=True, tile=tile, split_k=sk, **kw), ops.gemm(y, w, out_f32=True, tile=9, split_k=sk, **kw))
+
+
+def test_gemm_asm_tiles_refuse(ops):
+    a, w = rnd(512, 1280, seed=1), rnd(256, 1280, seed=2)
+    with pytest.raises(RuntimeError, match="asm tiles"):
+        ops.gemm(a[:, :640], w, a2=a[:, 640:], tile=63)                    # two-source operand
+    with pytest.raises(RuntimeError, match="asm tiles"):
+        ops.gemm(rnd(128, 200, seed=1), rnd(64, 200, seed=2), tile=63)     # K % 64 != 0
+    with pytest.raises(RuntimeError, match="asm tiles"):
+        ops.gemm(rnd(2 * 12 * 32, 64, seed=1), rnd(64, 192, seed=2), mode=ops.TMIX, tmix=(32, 12), tile=60)    # no TMIX form of the 256 x 256 tile

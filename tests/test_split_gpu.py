@@ -58,7 +58,7 @@ def test_split_roundtrip_carries_16_bits(ops):
         ops._lo(torch.zeros(8, 8, dtype=torch.bfloat16, device=dev()))      # not a twin allocation
 
 
-@pytest.mark.parametrize("tile", [4, 7, 11, 12, 13, 24, 25, 34, 35, 36, 0])
+@pytest.mark.parametrize("tile", [7, 11, 13, 24, 25, 34, 35, 36, 0])
 @pytest.mark.parametrize("M,N,K", [(384, 320, 320), (1000, 640, 1280), (128, 64, 64), (77, 132, 200), (2048, 1280, 768)])
 def test_gemm_plain(ops, tile, M, N, K):
     a, av = act(ops, M, K, seed=1)
@@ -79,7 +79,7 @@ def test_gemm_asymmetric_transpose_detect(ops):
     a = ops.to_act(torch.eye(M, device=dev()))
     wf = (torch.arange(N * K, device=dev()).reshape(N, K) % 6553).float() / 16.0       # needs both planes
     w = ops.to_act(wf)
-    for tile in (4, 7, 11, 12, 13, 24, 25, 34, 35, 36):
+    for tile in (7, 11, 13, 24, 25, 34, 35, 36):
         out = ops.gemm(a, w, out_f32=True, tile=tile)
         assert torch.equal(out, ops.from_act(w).T.contiguous())
 

@@ -14,7 +14,9 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-if "--extend" not in sys.argv:
+if "--challenge" in sys.argv:
+    os.environ["AVSD_TUNE_CHALLENGE"] = "1"     # keep the shipped table; re-time its entries against the newer tile ids only
+elif "--extend" not in sys.argv:
     os.environ.setdefault("AVSD_TILE_CACHE", "/nonexistent")    # start from an empty table (--extend: keep the shipped one, add what is missing)
 import torch  # noqa: E402
 
@@ -28,6 +30,9 @@ def main():
     ap.add_argument("--out", default="gpurun_out/tiles_gfx950.json")
     ap.add_argument("--skip-cfg4", action="store_true")
     ap.add_argument("--extend", action="store_true", help="keep the shipped table's entries; tune only the shapes it lacks")
+    ap.add_argument("--challenge", action="store_true", help="keep the shipped table; re-time every entry met against the tile ids added since "
+                                                            "(ops.ASM_CANDIDATES) and replace it when one of them is >= 3 %% faster")
+    ap.add_argument("--only-cfg2", action="store_true")
     ap.add_argument("--split", action="store_true", help="tune the split-precision (AVSD_GEMM_X2) shapes of cfg 2 and the VAE "
                                                         "(their table keys carry the X2 flag, so they live beside the 16-bit ones)")
     a = ap.parse_args()
@@ -57,6 +62,12 @@ def main():
         print(f"tuned ({branches * n_clips}, 4, {frames}, {hw}, {hw}): {len(ops.tile_cache())} shapes, {time.time() - t0:.0f} s", flush=True)
 
     fwd(1, 12, 32)              # cfg 2
+    if a.only_cfg2:
+        for row in ops.CHALLENGE_LOG:
+            print("replaced", row)
+        ops.save_tile_cache(a.out)
+        print(f"wrote {a.out}: {len(ops.tile_cache())} shapes in {time.time() - t0:.0f} s")
+        return
     if not a.split:
         fwd(4, 12, 32)              # cfg 3 per-GPU forward
         fwd(1, 12, 32, branches=3)  # dual guidance
@@ -79,6 +90,8 @@ def main():
         torch.cuda.synchronize()
         print(f"tuned cfg4: {len(ops.tile_cache())} shapes, {time.time() - t0:.0f} s", flush=True)
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+    for row in ops.CHALLENGE_LOG:
+        print("replaced", row)
     ops.save_tile_cache(a.out)
     print(f"wrote {a.out}: {len(ops.tile_cache())} shapes in {time.time() - t0:.0f} s")
 

@@ -91,9 +91,8 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void conv3r_kernel(const avsd_
     wg = c / nsplit;
     ksplit = c - wg * nsplit;
   }
-  const bool nmaj = (p.flags & AVSD_GEMM_XCD_N) != 0;
-  const int tn = nmaj ? wg / ntm : wg % ntn;
-  const int tm = nmaj ? wg % ntm : wg / ntn;
+  int tm, tn;
+  tile_of_item(wg, ntm, ntn, (p.flags & AVSD_GEMM_XCD_N) != 0, p.reserved0, tm, tn);
   const int m0 = tm * BM;
   const int ws = p.ws;
   const int ar = BM + 2 * ws;                 // staged rows
@@ -352,9 +351,8 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void conv3r2d_kernel(const avs
     wg = c / nsplit;
     ksplit = c - wg * nsplit;
   }
-  const bool nmaj = (p.flags & AVSD_GEMM_XCD_N) != 0;
-  const int tn = nmaj ? wg / ntm : wg % ntn;
-  const int tm = nmaj ? wg % ntm : wg / ntn;
+  int tm, tn;
+  tile_of_item(wg, ntm, ntn, (p.flags & AVSD_GEMM_XCD_N) != 0, p.reserved0, tm, tn);
   const int img = tm / tpi;
   const int trem = tm - img * tpi;
   const int ty0 = (trem / tpr) * TH, tx0 = (trem % tpr) * 32;

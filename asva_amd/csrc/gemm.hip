@@ -343,9 +343,8 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm2_kernel(const avsd_g
   // Each XCD owns a contiguous range of `wg`.  Default: row-major tiles, so an XCD covers a band of M and its L2
   // fetches that band of A once while EVERY XCD streams all of W.  AVSD_GEMM_XCD_N: column-major, an XCD covers a
   // band of N — W is fetched once chip-wide and A by every XCD (the host picks whichever operand is larger).
-  const bool nmaj = (p.flags & AVSD_GEMM_XCD_N) != 0;
-  const int tn = nmaj ? wg / ntm : wg % ntn;
-  const int tm = nmaj ? wg % ntm : wg / ntn;
+  int tm, tn;
+  tile_of_item(wg, ntm, ntn, (p.flags & AVSD_GEMM_XCD_N) != 0, p.reserved0, tm, tn);
   const int64_t bz = blockIdx.z;
   // split-K: this workgroup owns K tiles [kt0, kt1)
   const int nk_all = (p.K + BK - 1) / BK;
@@ -957,8 +956,9 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
     if (d.split_k > 1) AVSD_REQUIRE(d.splitk_ws != nullptr, "gemm: split_k needs a workspace");
     return avsd_gemm_dispatch_conv3r(d, reinterpret_cast<hipStream_t>(stream));
   }
-  if (d.tile >= AVSD_GEMM_TILE_ASM_FIRST && d.tile <= AVSD_GEMM_TILE_ASM_LAST) return avsd_gemm_dispatch_asm(d, reinterpret_cast<hipStream_t>(stream));
-  if (d.split_k > 1) {
+  const bool asm_tile = d.tile >= AVSD_GEMM_TILE_ASM_FIRST && d.tile <= AVSD_GEMM_TILE_ASM_LAST;
+  if (asm_tile && !(d.flags & AVSD_GEMM_X2)) return avsd_gemm_dispatch_asm(d, reinterpret_cast<hipStream_t>(stream));
+  if (d.split_k > 1 && !asm_tile) {
     AVSD_REQUIRE(d.splitk_ws != nullptr, "gemm: split_k needs a workspace");
     AVSD_REQUIRE(!(d.flags & AVSD_GEMM_GEGLU) && d.batch == 1, "gemm: split_k cannot be combined with GEGLU or batching");
     AVSD_REQUIRE((d.tile >= 4 && d.tile <= ((d.flags & AVSD_GEMM_X2) ? AVSD_GEMM_MAX_TILE_X2 : AVSD_GEMM_MAX_TILE)) ||
@@ -977,6 +977,7 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
     const double a_rows = d.mode == AVSD_GEMM_CONV3 ? (double)(d.M / (d.ho * d.wo)) * d.hs * d.ws : (double)d.M;
     AVSD_REQUIRE(a_rows * d.lda * 2.0 < 2147483648.0 && (double)d.N * d.ldw * 2.0 < 2147483648.0, "gemm/x2: operands must be < 2 GiB per plane");
     hipStream_t sx = reinterpret_cast<hipStream_t>(stream);
+    if (asm_tile) return avsd_gemm_dispatch_asm(d, sx);
     switch (d.mode) {
       case AVSD_GEMM_PLAIN: return avsd_gemm_dispatch_x2_plain(d, d.tile, sx);
       case AVSD_GEMM_TMIX: return avsd_gemm_dispatch_x2_tmix(d, d.tile, sx);

@@ -53,14 +53,16 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-template <int FM, int FN, int MODE>
+// X2 (AVSD_GEMM_X2, split precision): every operand a (main, rest) pair of planes — an LDS stage holds [A | W | A rest | W rest], the rest
+// planes come through second buffer descriptors with the same offsets, every fragment pair takes three MFMAs (Wr.A, W.Ar, W.A).
+template <int FM, int FN, int MODE, bool X2 = false>
 __global__ __launch_bounds__(256, 1) void gemm4_kernel(const avsd_gemm_desc p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem4[];
   constexpr int BM = 64 * FM, BN = 64 * FN;
   constexpr int A_BYTES = BM * ROWB;
   static_assert(MODE == AVSD_GEMM_PLAIN || MODE == AVSD_GEMM_TMIX, "gemm4: PLAIN or TMIX operands");
   constexpr int NA = BM / 32;
-  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int STAGE = (BM + BN) * ROWB * (X2 ? 2 : 1);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -81,9 +83,8 @@ __global__ __launch_bounds__(256, 1) void gemm4_kernel(const avsd_gemm_desc p) {
     wg = c / nsplit;
     ksplit = c - wg * nsplit;
   }
-  const bool nmaj = (p.flags & AVSD_GEMM_XCD_N) != 0;
-  const int tn = nmaj ? wg / ntm : wg % ntn;
-  const int tm = nmaj ? wg % ntm : wg / ntn;
+  int tm, tn;
+  tile_of_item(wg, ntm, ntn, (p.flags & AVSD_GEMM_XCD_N) != 0, p.reserved0, tm, tn);
   const int nk_all = p.K / BK;
   const int per_split = (nk_all + nsplit - 1) / nsplit;
   const int kt0 = ksplit * per_split;
@@ -94,6 +95,10 @@ __global__ __launch_bounds__(256, 1) void gemm4_kernel(const avsd_gemm_desc p) {
   const unsigned long long pa = (unsigned long long)p.A, pw = (unsigned long long)p.W;
   const u32x4 rsA = {(unsigned)pa, (unsigned)(pa >> 32) & 0xffffu, (unsigned)p.M * (unsigned)p.lda * 2u, 0x00020000u};
   const u32x4 rsW = {(unsigned)pw, (unsigned)(pw >> 32) & 0xffffu, (unsigned)p.N * (unsigned)p.ldw * 2u, 0x00020000u};
+  const unsigned long long par = pa + (X2 ? (unsigned long long)p.a_lo * 2ull : 0ull), pwr = pw + (X2 ? (unsigned long long)p.w_lo * 2ull : 0ull);
+  const u32x4 rsAr = {(unsigned)par, (unsigned)(par >> 32) & 0xffffu, rsA[2], 0x00020000u};
+  const u32x4 rsWr = {(unsigned)pwr, (unsigned)(pwr >> 32) & 0xffffu, rsW[2], 0x00020000u};
+  (void)rsAr; (void)rsWr;
 
   // staging: thread t moves the 16-byte vector (row (t >> 3) + 32 i, k-chunk t & 7) of each operand tile; fragment row
   // wm/wn * (32 F) + 32 b + (lane & 31), 16-byte chunk 2 ks + (lane >> 5)
@@ -104,6 +109,17 @@ __global__ __launch_bounds__(256, 1) void gemm4_kernel(const avsd_gemm_desc p) {
   const unsigned rda0 = (unsigned)((wm * 32 * FM + (lane & 31)) * ROWB + (lane >> 5) * 16);
   const unsigned rdw0 = (unsigned)(A_BYTES + (wn * 32 * FN + (lane & 31)) * ROWB + (lane >> 5) * 16);
   const unsigned sa = 32u * (unsigned)p.lda * 2u, sw = 32u * (unsigned)p.ldw * 2u;
+
+  // LayerNorm fold with pre-folded statistics (one (sum, sumsq) pair per row, avsd_ln_fold): the pairs of this lane's FM rows are
+  // requested BEFORE the main loop (older than every load the loop issues, so its counted waits stay valid) and folded after it
+  const bool ln_pre = (p.flags & AVSD_GEMM_LNFUSE) != 0 && p.ln_nblk == 1;
+  float2 ln_raw[FM];
+#pragma unroll
+  for (int b = 0; b < FM; ++b) {
+    ln_raw[b] = make_float2(0.f, 0.f);
+    const int m = tm * BM + wm * 32 * FM + b * 32 + (lane & 31);
+    if (ln_pre && m < p.M) ln_raw[b] = reinterpret_cast<const float2*>(p.ln_stats)[m];
+  }
 
   f32x16 acc[FN][FM];
   if constexpr (MODE == AVSD_GEMM_TMIX) {
@@ -130,15 +146,29 @@ __global__ __launch_bounds__(256, 1) void gemm4_kernel(const avsd_gemm_desc p) {
     }
     const unsigned tbl_addr = (unsigned)(STAGE + tid * (3 * NA) * 4);
     if (nk > 0) {
-      if constexpr (FM == 4 && FN == 2) g4_loop_4x2_s2_tmix(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, (unsigned)kt0, sw, (unsigned)nk, (unsigned)tps, 2u * tps);
-      else if constexpr (FM == 2 && FN == 4) g4_loop_2x4_s2_tmix(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, (unsigned)kt0, sw, (unsigned)nk, (unsigned)tps, 2u * tps);
-      else if constexpr (FM == 2 && FN == 2) g4_loop_2x2_s2_tmix(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, (unsigned)kt0, sw, (unsigned)nk, (unsigned)tps, 2u * tps);
-      else if constexpr (FM == 2 && FN == 1) g4_loop_2x1_s2_tmix(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, (unsigned)kt0, sw, (unsigned)nk, (unsigned)tps, 2u * tps);
-      else if constexpr (FM == 1 && FN == 2) g4_loop_1x2_s2_tmix(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, (unsigned)kt0, sw, (unsigned)nk, (unsigned)tps, 2u * tps);
-      else if constexpr (FM == 1 && FN == 1) g4_loop_1x1_s2_tmix(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, (unsigned)kt0, sw, (unsigned)nk, (unsigned)tps, 2u * tps);
+      const unsigned tp = (unsigned)tps;
+      if constexpr (X2) {
+        if constexpr (FM == 2 && FN == 2) g4_loop_2x2_s2_tmix_x2(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, rsAr, rsWr, (unsigned)kt0, sw, (unsigned)nk, tp, 2u * tp);
+        else if constexpr (FM == 2 && FN == 1) g4_loop_2x1_s2_tmix_x2(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, rsAr, rsWr, (unsigned)kt0, sw, (unsigned)nk, tp, 2u * tp);
+        else if constexpr (FM == 1 && FN == 2) g4_loop_1x2_s2_tmix_x2(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, rsAr, rsWr, (unsigned)kt0, sw, (unsigned)nk, tp, 2u * tp);
+        else g4_loop_1x1_s2_tmix_x2(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, rsAr, rsWr, (unsigned)kt0, sw, (unsigned)nk, tp, 2u * tp);
+      } else {
+        if constexpr (FM == 4 && FN == 2) g4_loop_4x2_s2_tmix(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, (unsigned)kt0, sw, (unsigned)nk, tp, 2u * tp);
+        else if constexpr (FM == 2 && FN == 4) g4_loop_2x4_s2_tmix(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, (unsigned)kt0, sw, (unsigned)nk, tp, 2u * tp);
+        else if constexpr (FM == 2 && FN == 2) g4_loop_2x2_s2_tmix(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, (unsigned)kt0, sw, (unsigned)nk, tp, 2u * tp);
+        else if constexpr (FM == 2 && FN == 1) g4_loop_2x1_s2_tmix(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, (unsigned)kt0, sw, (unsigned)nk, tp, 2u * tp);
+        else if constexpr (FM == 1 && FN == 2) g4_loop_1x2_s2_tmix(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, (unsigned)kt0, sw, (unsigned)nk, tp, 2u * tp);
+        else if constexpr (FM == 1 && FN == 1) g4_loop_1x1_s2_tmix(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, (unsigned)kt0, sw, (unsigned)nk, tp, 2u * tp);
+      }
     }
   } else
   if (nk > 0) {
+    if constexpr (X2) {
+      if constexpr (FM == 2 && FN == 2) g4_loop_2x2_s2_x2(acc, va0, vw0, wr0, rda0, rdw0, rsA, rsW, rsAr, rsWr, sa, sw, (unsigned)nk);
+      else if constexpr (FM == 2 && FN == 1) g4_loop_2x1_s2_x2(acc, va0, vw0, wr0, rda0, rdw0, rsA, rsW, rsAr, rsWr, sa, sw, (unsigned)nk);
+      else if constexpr (FM == 1 && FN == 2) g4_loop_1x2_s2_x2(acc, va0, vw0, wr0, rda0, rdw0, rsA, rsW, rsAr, rsWr, sa, sw, (unsigned)nk);
+      else g4_loop_1x1_s2_x2(acc, va0, vw0, wr0, rda0, rdw0, rsA, rsW, rsAr, rsWr, sa, sw, (unsigned)nk);
+    } else
     if constexpr (FM == 4 && FN == 4) g4_loop_4x4_s2(acc, va0, vw0, wr0, rda0, rdw0, rsA, rsW, sa, sw, (unsigned)nk);
     else if constexpr (FM == 4 && FN == 2) g4_loop_4x2_s2(acc, va0, vw0, wr0, rda0, rdw0, rsA, rsW, sa, sw, (unsigned)nk);
     else if constexpr (FM == 2 && FN == 4) g4_loop_2x4_s2(acc, va0, vw0, wr0, rda0, rdw0, rsA, rsW, sa, sw, (unsigned)nk);
@@ -178,24 +208,34 @@ __global__ __launch_bounds__(256, 1) void gemm4_kernel(const avsd_gemm_desc p) {
   }
   // the shared epilogue, one 32-row fragment band at a time (a 16-fragment instantiation does not unroll: the accumulators would
   // go through scratch memory); a band of FN <= 4 fragments takes the term-at-a-time form with batched operand loads
-  static_for<FM>([&p, &acc, m_base, n_base, lane](auto b_c) {
+  static_for<FM>([&p, &acc, &ln_raw, ln_pre, m_base, n_base, lane](auto b_c) {
     constexpr int B = decltype(b_c)::value;
     f32x16 band[FN][1];
 #pragma unroll
     for (int a = 0; a < FN; ++a) band[a][0] = acc[a][B];
-    const float pre_ln[2] = {};
-    epilogue<FN, 1>(p, band, m_base + 32 * B, n_base, lane, 0, pre_ln, false);
+    float pre_ln[2] = {1.f, 0.f};
+    if (ln_pre) {          // same arithmetic as ln_row_stats (gemm_common.h) on one pair
+      float sm = ln_raw[B].x, sq = ln_raw[B].y;
+      asm volatile("" : "+v"(sm), "+v"(sq));      // the fold (and the wait for the pair) stays behind the main loop
+      const float inv_k = 1.0f / (float)p.K;
+      const float mean = sm * inv_k;
+      const float var = fmaxf(sq * inv_k - mean * mean, 0.f);
+      pre_ln[0] = rsqrtf(var + p.ln_eps);
+      pre_ln[1] = mean * pre_ln[0];
+    }
+    if constexpr (X2) epilogue_x2<FN, 1>(p, band, m_base + 32 * B, n_base, lane, 0, pre_ln, ln_pre);
+    else epilogue<FN, 1>(p, band, m_base + 32 * B, n_base, lane, 0, pre_ln, ln_pre);
   });
 }
 
-template <int FM, int FN, int MODE>
+template <int FM, int FN, int MODE, bool X2 = false>
 int launch4(const avsd_gemm_desc& d, hipStream_t s) {
   constexpr int BM = 64 * FM, BN = 64 * FN;
-  constexpr size_t lds = (size_t)2 * (BM + BN) * ROWB;
+  constexpr size_t lds = (size_t)2 * (BM + BN) * ROWB * (X2 ? 2 : 1);
   static_assert(lds <= 160 * 1024, "tile does not fit the 160 KB of LDS");
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<FM, FN, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<FM, FN, MODE, X2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       avsd_set_error("gemm4: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
       return AVSD_ELAUNCH;
@@ -205,7 +245,7 @@ int launch4(const avsd_gemm_desc& d, hipStream_t s) {
   const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
   const int nsplit = d.split_k > 1 ? d.split_k : 1;
   dim3 grid((unsigned)(ntm * ntn), (unsigned)nsplit, 1);
-  hipLaunchKernelGGL((gemm4_kernel<FM, FN, MODE>), grid, dim3(256), lds, s, d);
+  hipLaunchKernelGGL((gemm4_kernel<FM, FN, MODE, X2>), grid, dim3(256), lds, s, d);
   AVSD_CHECK_LAUNCH("gemm4 launch");
   if (nsplit > 1) return avsd_gemm_splitk_reduce(d, s);
   return AVSD_OK;
@@ -214,13 +254,24 @@ int launch4(const avsd_gemm_desc& d, hipStream_t s) {
 }  // namespace
 
 int avsd_gemm_dispatch_asm(const avsd_gemm_desc& d, hipStream_t s) {
-  AVSD_REQUIRE((d.mode == AVSD_GEMM_PLAIN || d.mode == AVSD_GEMM_TMIX) && !d.A2 && d.batch == 1 && !(d.flags & AVSD_GEMM_X2) && d.K % 64 == 0,
-               "gemm/asm tiles: PLAIN single-source or TMIX 16-bit operands with K %% 64 == 0 (got mode %d, K %d)", d.mode, d.K);
+  AVSD_REQUIRE((d.mode == AVSD_GEMM_PLAIN || d.mode == AVSD_GEMM_TMIX) && !d.A2 && d.batch == 1 && d.K % 64 == 0,
+               "gemm/asm tiles: PLAIN single-source or TMIX operands with K %% 64 == 0 (got mode %d, K %d)", d.mode, d.K);
   AVSD_REQUIRE((double)d.M * d.lda * 2.0 < 1073741824.0 && (double)d.N * d.ldw * 2.0 < 1073741824.0, "gemm/asm tiles: operands must be < 1 GiB");
   AVSD_REQUIRE(d.split_k <= 1 || (d.splitk_ws && d.split_k <= d.K / 64 && !(d.flags & AVSD_GEMM_GEGLU)), "gemm/asm tiles: bad split_k %d", d.split_k);
   const int k = d.tile - AVSD_GEMM_TILE_ASM_FIRST;
-  if (d.mode == AVSD_GEMM_TMIX) {
-    AVSD_REQUIRE(d.cseg % 64 == 0 && !(d.flags & AVSD_GEMM_LNFUSE), "gemm/asm tiles: TMIX needs cseg %% 64 == 0 (got %d)", d.cseg);
+  const bool tmix = d.mode == AVSD_GEMM_TMIX;
+  if (tmix) AVSD_REQUIRE(d.cseg % 64 == 0 && !(d.flags & AVSD_GEMM_LNFUSE), "gemm/asm tiles: TMIX needs cseg %% 64 == 0 (got %d)", d.cseg);
+  if (d.flags & AVSD_GEMM_X2) {
+    // (plane offsets, out_lo / res*_lo: checked by avsd_gemm_bf16 before it dispatches here)
+    switch (k) {
+      case 3: return tmix ? launch4<2, 2, AVSD_GEMM_TMIX, true>(d, s) : launch4<2, 2, AVSD_GEMM_PLAIN, true>(d, s);     // 128 x 128, 144 KB
+      case 4: return tmix ? launch4<2, 1, AVSD_GEMM_TMIX, true>(d, s) : launch4<2, 1, AVSD_GEMM_PLAIN, true>(d, s);     // 128 x 64, 108 KB
+      case 5: return tmix ? launch4<1, 2, AVSD_GEMM_TMIX, true>(d, s) : launch4<1, 2, AVSD_GEMM_PLAIN, true>(d, s);     // 64 x 128
+      case 6: return tmix ? launch4<1, 1, AVSD_GEMM_TMIX, true>(d, s) : launch4<1, 1, AVSD_GEMM_PLAIN, true>(d, s);     // 64 x 64, 72 KB
+      default: AVSD_REQUIRE(false, "gemm/asm tiles: tile %d has no split-precision form (63..66 do)", d.tile);
+    }
+  }
+  if (tmix) {
     switch (k) {
       case 1: return launch4<4, 2, AVSD_GEMM_TMIX>(d, s);
       case 2: return launch4<2, 4, AVSD_GEMM_TMIX>(d, s);

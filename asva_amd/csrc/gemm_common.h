@@ -658,6 +658,28 @@ __device__ __forceinline__ void wait_tiles_ahead(int ahead) {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// Work item `wg` (XCD-contiguous: each of the 8 XCDs owns one contiguous range) -> output tile (tm, tn).  Bands of the major
+// dimension (M by default, N under AVSD_GEMM_XCD_N: the operand of the band is what the XCD's L2 fetches once); on big grids the
+// ~32 workgroups an XCD runs at a time cover a G x (32 / G) BLOCK of tiles instead of one row of 32, so the L2 fetches
+// G + 32 / G operand panels per K tile instead of 33 (measured on the asm tiles: 8192^3 1090 -> 850 us, 6144 x 5120 x 640
+// 64 -> 54 us; G = 4 .. 8 equal, profiles/r4_raster_probe.txt).  `g_override` > 0 replaces G (probe knob, avsd_gemm_desc.reserved0).
+__device__ __forceinline__ void tile_of_item(int wg, int ntm, int ntn, bool nmaj, int g_override, int& tm, int& tn) {
+  const int nmajor = nmaj ? ntn : ntm, nminor = nmaj ? ntm : ntn;      // wg = major * nminor + minor
+  int tmaj, tmin;
+  if (nminor >= 16 && nmajor >= 8) {
+    const int G = g_override > 0 ? g_override : 8;
+    const int gsize = G * nminor, grp = wg / gsize, first = grp * G, in = wg - grp * gsize;
+    const int gm = min(nmajor - first, G);
+    tmaj = first + in % gm;
+    tmin = in / gm;
+  } else {
+    tmaj = wg / nminor;
+    tmin = wg - tmaj * nminor;
+  }
+  tn = nmaj ? tmaj : tmin;
+  tm = nmaj ? tmin : tmaj;
+}
+
 
 // ---- LDS-direct K tiles (gemm2_kernel and the fused kernels) ----------------------------------------------------------
 // Tile image: rows of 64 16-bit values = 128 B, two rows = one 256-B line L; the 16-byte slot index inside a line is

@@ -116,7 +116,10 @@ X2_SPLITK_CANDIDATES = ((34, 2), (34, 4), (35, 2), (35, 4), (36, 2), (36, 4), (7
 ASM_CANDIDATES = ((60, 1), (61, 1), (62, 1), (63, 1), (64, 1), (65, 1), (66, 1))
 ASM_SPLITK_CANDIDATES = ((63, 2), (63, 4), (63, 8), (61, 2), (62, 2), (62, 4), (64, 2), (64, 4), (65, 2), (65, 4), (66, 2), (66, 4))
 ASM_TILES = tuple(range(60, 67))
+ASM_X2_CANDIDATES = ((63, 1), (64, 1), (65, 1), (66, 1))        # split precision: 128x128 ... 64x64
+ASM_X2_SPLITK_CANDIDATES = ((63, 2), (63, 4), (64, 2), (64, 4), (65, 2), (65, 4), (66, 2), (66, 4), (66, 8))
 _ASM_TILES = os.environ.get("AVSD_ASM_TILES", "1") != "0"
+_RASTER_G = int(os.environ.get("AVSD_RASTER_G", "0"))       # probe knob: rows of the tile blocks an XCD walks (0 = the kernel's default)
 CONV3R_TILES = (40, 42, 43, 44, 48)
 CONV3R2D_TILES = (51, 52, 53, 54)   # rectangular resident tiles (TH rows x 32 pixels) for images wider than 32 pixels: the VAE decoder, cfg 4
 _CONV3R2D_BN = {51: 128, 52: 160, 53: 128, 54: 128}
@@ -543,6 +546,7 @@ def gemm(
     if _XCD_MODE == "n" or (_XCD_MODE == "auto" and N * K > a_bytes):
         d.flags |= XCD_N
     d.batch = 1
+    d.reserved0 = _RASTER_G
     ws = None
     if P.SPLIT:
         if master is not None:
@@ -586,11 +590,11 @@ def gemm(
         if two_src_conv:
             key = key + ("a2", d.k_split)                         # a table entry of the one-source shape may name a tile that never reads A2
         asm = ()
-        if (_ASM_TILES and a2 is None and not P.SPLIT and K % 64 == 0 and M * lda < (1 << 29) and N * _ld(w) < (1 << 29) and
+        if (_ASM_TILES and a2 is None and K % 64 == 0 and M * lda < (1 << 29) and N * _ld(w) < (1 << 29) and
                 (mode == PLAIN or (mode == TMIX and d.cseg % 64 == 0 and ln is None))):
-            asm = tuple(c for c in ASM_CANDIDATES if mode == PLAIN or c[0] != 60)
+            asm = ASM_X2_CANDIDATES if P.SPLIT else tuple(c for c in ASM_CANDIDATES if mode == PLAIN or c[0] != 60)
             if splitk_ok and ((M + 127) // 128) * ((N + 127) // 128) < 256 and nk >= 8:
-                asm = asm + tuple(c for c in ASM_SPLITK_CANDIDATES if nk // c[1] >= 4)
+                asm = asm + tuple(c for c in (ASM_X2_SPLITK_CANDIDATES if P.SPLIT else ASM_SPLITK_CANDIDATES) if nk // c[1] >= 4)
         picked = _pick_tile(key, _launch, cands, warm=(a, a2, res1, res2), challengers=asm)
         if picked is not None and picked[0] in ASM_TILES and not asm:        # (a two-source call shares the key of the one-source shape)
             picked = None

@@ -14,6 +14,80 @@ def rnd(*s, scale=1.0):
     return (torch.randn(*s, generator=g) * scale).to(torch.bfloat16).to(dev)
 
 
+if "--x2" in sys.argv:
+    # split precision: the asm tiles (63-66) against the LDS-direct X2 tile 11 (same three passes in the same order -> bit-identical)
+    from asva_amd import precision as P
+    P.set_split(True)
+    bad = 0
+    for M, N, K in [(256, 256, 64), (512, 384, 320), (1000, 640, 1280), (77, 132, 192), (3000, 320, 640)]:
+        a, w = ops.to_act(torch.randn(M, K, generator=g).to(dev)), ops.to_act((torch.randn(N, K, generator=g) * K ** -0.5).to(dev))
+        bias, res = torch.randn(N, generator=g).to(dev), ops.to_act(torch.randn(M, N, generator=g).to(dev))
+        ref = ops.gemm(a, w, bias=bias, res1=res, tile=11)
+        ref32 = ops.gemm(a, w, bias=bias, out_f32=True, tile=11)
+        exact = ops.from_act(a).double() @ ops.from_act(w).double().T + bias.double()
+        for t in (63, 64, 65, 66):
+            out = ops.gemm(a, w, bias=bias, res1=res, tile=t)
+            o32 = ops.gemm(a, w, bias=bias, out_f32=True, tile=t)
+            same = torch.equal(ops.from_act(out), ops.from_act(ref)) and torch.equal(o32, ref32)
+            e64 = ((o32.double() - exact).norm() / exact.norm()).item()
+            bad += 0 if same else 1
+            print(f"x2 parity {M}x{N}x{K} tile {t}: {'bit-identical to X2 tile 11' if same else 'DIFFERS'}  rel vs f64 {e64:.2e}", flush=True)
+            if K >= 256:
+                sk, rk = ops.gemm(a, w, bias=bias, out_f32=True, tile=t, split_k=2), ops.gemm(a, w, bias=bias, out_f32=True, tile=11, split_k=2)
+                if not torch.equal(sk, rk):
+                    bad += 1
+                    print("   split_k=2 DIFFERS")
+    for B, hw, C, N in [(2, 64, 320, 320), (1, 32, 128, 132), (1, 16, 1280, 1280)]:
+        Fr = 12
+        M = B * Fr * hw
+        y, w = ops.to_act(torch.randn(M, C, generator=g).to(dev)), ops.to_act((torch.randn(N, 3 * C, generator=g) * (3 * C) ** -0.5).to(dev))
+        b, res2 = torch.randn(N, generator=g).to(dev), ops.to_act(torch.randn(M, N, generator=g).to(dev))
+        kw = dict(bias=b, res2=res2, mode=ops.TMIX, tmix=(hw, Fr))
+        ref = ops.gemm(y, w, out_f32=True, tile=11, **kw)
+        for t in (63, 64, 65, 66):
+            for sk in (1, 2):
+                o = ops.gemm(y, w, out_f32=True, tile=t, split_k=sk, **kw)
+                r = ref if sk == 1 else ops.gemm(y, w, out_f32=True, tile=11, split_k=sk, **kw)
+                if not torch.equal(o, r):
+                    bad += 1
+                    print(f"x2 tmix parity B={B} hw={hw} C={C} N={N} tile {t} split {sk}: DIFFERS rel {((o - r).norm() / r.norm()).item():.3e}", flush=True)
+    print("X2 PARITY", "OK" if bad == 0 else f"FAILED ({bad})", flush=True)
+    for M, N, K in [(24576, 320, 320), (24576, 320, 1280), (6144, 640, 640), (6144, 640, 2560), (1536, 1280, 1280), (1536, 1280, 5120), (24576, 2560, 320), (6144, 5120, 640), (384, 1280, 1280)]:
+        a, w = ops.to_act(torch.randn(M, K, generator=g).to(dev)), ops.to_act((torch.randn(N, K, generator=g) * K ** -0.5).to(dev))
+        b = torch.randn(N, generator=g).to(dev)
+        out = ops.alloc16((M, N), dev)
+        fl = 6.0 * M * N * K
+        row = [f"x2 {M:6d}x{N:5d}x{K:5d}"]
+        us = ops._time_hot(lambda tt, sk: ops.gemm(a, w, bias=b, out=out), (0, 1), reps=4) * 1e3
+        row.append(f"table {us:7.1f} us {fl / us / 1e6:5.0f} TF(3p)")
+        for t, sk in [(11, 1), (35, 1), (63, 1), (64, 1), (65, 1), (66, 1), (64, 2), (66, 2)]:
+            if (K // 64) // sk < 4 and sk > 1:
+                continue
+            try:
+                us = ops._time_hot(lambda tt, s_: ops.gemm(a, w, bias=b, out=out, tile=tt, split_k=s_), (t, sk), reps=4) * 1e3
+                row.append(f"t{t}/{sk} {us:6.1f}")
+            except Exception as e:  # noqa: BLE001
+                row.append(f"t{t}/{sk} n/a")
+        print("  ".join(row), flush=True)
+    for B, hw, C, N in [(2, 64, 1280, 1280), (2, 16, 1280, 1280), (2, 256, 640, 640), (2, 1024, 320, 320)]:
+        Fr = 12
+        M = B * Fr * hw
+        y, w = ops.to_act(torch.randn(M, C, generator=g).to(dev)), ops.to_act((torch.randn(N, 3 * C, generator=g) * (3 * C) ** -0.5).to(dev))
+        b = torch.randn(N, generator=g).to(dev)
+        out = ops.alloc16((M, N), dev)
+        kw = dict(bias=b, res1=y, mode=ops.TMIX, tmix=(hw, Fr), out=out)
+        row = [f"x2 tmix {M:6d}x{N:5d}x{3 * C:5d}"]
+        us = ops._time_hot(lambda tt, sk: ops.gemm(y, w, **kw), (0, 1), reps=4) * 1e3
+        row.append(f"table {us:7.1f} us")
+        for t, sk in [(63, 1), (64, 1), (65, 1), (66, 1), (64, 2), (66, 2), (66, 4)]:
+            try:
+                us = ops._time_hot(lambda tt, s_: ops.gemm(y, w, tile=tt, split_k=s_, **kw), (t, sk), reps=4) * 1e3
+                row.append(f"t{t}/{sk} {us:6.1f}")
+            except Exception as e:  # noqa: BLE001
+                row.append(f"t{t}/{sk} n/a")
+        print("  ".join(row), flush=True)
+    sys.exit(0)
+
 # ---- parity: same products, same K order -> bit-identical to the LDS-direct tile 9
 bad = 0
 for M, N, K in [(256, 256, 64), (256, 256, 128), (512, 384, 320), (1000, 640, 1280), (77, 132, 192), (2048, 1280, 768), (3000, 320, 640)]:

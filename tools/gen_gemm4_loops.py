@@ -5,27 +5,33 @@ without the wait states an MFMA result needs — so each loop is ONE statement: 
 
     python tools/gen_gemm4_loops.py > asva_amd/csrc/gemm4_loops.inc
 
-Register map (per lane): v0-v31 stay the compiler's; from v32: 16-byte-vector offsets VA[NA] VW[NW], LDS addresses (write A/W x 2
-stages, read A/W x 2 stages), fragment sets XF[2][FM] WF[2][FN] (4 registers each), staging G[NSTG][NA + NW] (4 registers each).
+Variants: (FM, FN) = 32-row / 32-column fragments per wave (4 waves as 2 x 2); planes = 1 (16-bit operands) or 2 (split precision,
+AVSD_GEMM_X2: every operand a (main, rest) pair, three MFMAs per fragment pair); tmix = the temporal-mix A operand.
+Register map (per lane): v0-v31 stay the compiler's; from v32: vector offsets VA[NA] VW[NW], LDS addresses (write / read x A / W x
+stage x plane), fragment sets XF[sets][planes][FM] WF[sets][planes][FN] (4 registers each), staging G[NSTG][planes][NA + NW]
+(4 registers each), and for tmix the per-vector segment jumps D01[NA] D12[NA].
 """
 import sys
 
 ROWB = 144
 
 
-def gen(FM, FN, NSTG, mfma_op, ablate="", deep=None, tmix=False):
+def gen(FM, FN, NSTG, mfma_op, ablate="", deep=None, tmix=False, planes=1, base=32):
+    P = planes
     NA, NW = 2 * FM, 2 * FN
     NL = NA + NW
     BM, BN = 64 * FM, 64 * FN
     A_BYTES, W_BYTES = BM * ROWB, BN * ROWB
-    STAGE = A_BYTES + W_BYTES
+    PLANE = A_BYTES + W_BYTES
+    STAGE = P * PLANE
     NMF, NFR = FM * FN, FM + FN
+    NPASS = 3 if P == 2 else 1
     if deep is None:
-        deep = NMF <= 8          # small wave tiles: a k-step is <= 256 cycles of MFMA — fragments are read TWO k-steps ahead (4 sets)
+        deep = NMF * NPASS <= 8  # small wave tiles: a k-step is <= 256 cycles of MFMA — fragments are read TWO k-steps ahead (4 sets)
     NSETS = 4 if deep else 2
     NWK = 2 if deep else 3       # k-steps that carry the write + reload pairs (the barrier follows the last of them)
     WPK = (NL + NWK - 1) // NWK
-    r = 32
+    r = base                     # first register of the loop (the compiler keeps v0 .. base - 1)
 
     def take(n):
         nonlocal r
@@ -35,35 +41,38 @@ def gen(FM, FN, NSTG, mfma_op, ablate="", deep=None, tmix=False):
 
     VA = [take(1) for _ in range(NA)]
     VW = [take(1) for _ in range(NW)]
-    WRA = [take(1) for _ in range(2)]
-    WRW = [take(1) for _ in range(2)]
-    RDA = [take(1) for _ in range(2)]
-    RDW = [take(1) for _ in range(2)]
-    if r % 2:
-        r += 1                                   # 64-bit-aligned tuples from here on (ds_read_b128 / MFMA sources want even bases)
-    XF = [[take(4) for _ in range(FM)] for _ in range(NSETS)]
-    WF = [[take(4) for _ in range(FN)] for _ in range(NSETS)]
-    G = [[take(4) for _ in range(NL)] for _ in range(NSTG)]
+    WRA = [[take(1) for _ in range(P)] for _ in range(2)]
+    WRW = [[take(1) for _ in range(P)] for _ in range(2)]
+    RDA = [[take(1) for _ in range(P)] for _ in range(2)]
+    RDW = [[take(1) for _ in range(P)] for _ in range(2)]
     if tmix:       # temporal-mix A operand: per-vector jumps at the two K-segment boundaries (frame 0 -> previous frame -> current frame)
         D01 = [take(1) for _ in range(NA)]
         D12 = [take(1) for _ in range(NA)]
         TMP = take(1)
+    if r % 2:
+        r += 1                                   # 64-bit-aligned tuples from here on
+    XF = [[[take(4) for _ in range(FM)] for _ in range(P)] for _ in range(NSETS)]
+    WF = [[[take(4) for _ in range(FN)] for _ in range(P)] for _ in range(NSETS)]
+    G = [[[take(4) for _ in range(NL)] for _ in range(P)] for _ in range(NSTG)]
     last = r - 1
-    assert last <= 255, last
+    assert last <= 255, (FM, FN, P, last)
+    assert NSTG * NL * P - P < 64 and (NFR + WPK) * P < 16, "vmcnt is a 6-bit, lgkmcnt a 4-bit counter"
 
     def v4(b):
         return f"v[{b}:{b + 3}]"
 
     out = []
     emit = out.append
+    RS = {(0, 0): "%[rsA]", (1, 0): "%[rsW]", (0, 1): "%[rsAr]", (1, 1): "%[rsWr]"}
 
     def load(s, j):
         if "g" in ablate:
             return
-        if j < NA:
-            emit(f"buffer_load_dwordx4 {v4(G[s][j])}, v{VA[j]}, %[rsA], 0 offen")
-        else:
-            emit(f"buffer_load_dwordx4 {v4(G[s][j])}, v{VW[j - NA]}, %[rsW], 0 offen")
+        for pl in range(P):
+            if j < NA:
+                emit(f"buffer_load_dwordx4 {v4(G[s][pl][j])}, v{VA[j]}, {RS[(0, pl)]}, 0 offen")
+            else:
+                emit(f"buffer_load_dwordx4 {v4(G[s][pl][j])}, v{VW[j - NA]}, {RS[(1, pl)]}, 0 offen")
 
     def bump(j, inc):
         if "g" in ablate:
@@ -79,18 +88,21 @@ def gen(FM, FN, NSTG, mfma_op, ablate="", deep=None, tmix=False):
     def write(s, st, j):
         if "w" in ablate:
             return
-        if j < NA:
-            emit(f"ds_write_b128 v{WRA[st]}, {v4(G[s][j])} offset:{j * 32 * ROWB}")
-        else:
-            emit(f"ds_write_b128 v{WRW[st]}, {v4(G[s][j])} offset:{(j - NA) * 32 * ROWB}")
+        for pl in range(P):
+            if j < NA:
+                emit(f"ds_write_b128 v{WRA[st][pl]}, {v4(G[s][pl][j])} offset:{j * 32 * ROWB}")
+            else:
+                emit(f"ds_write_b128 v{WRW[st][pl]}, {v4(G[s][pl][j])} offset:{(j - NA) * 32 * ROWB}")
 
     def fread(fs, st, ks, rr):
+        # fragment read rr of 0 .. P * NFR - 1: plane-major (all main-plane fragments, then the rest planes)
         if "r" in ablate:
             return
-        if rr < FM:
-            emit(f"ds_read_b128 {v4(XF[fs][rr])}, v{RDA[st]} offset:{rr * 32 * ROWB + ks * 32}")
+        pl, q = rr // NFR, rr % NFR
+        if q < FM:
+            emit(f"ds_read_b128 {v4(XF[fs][pl][q])}, v{RDA[st][pl]} offset:{q * 32 * ROWB + ks * 32}")
         else:
-            emit(f"ds_read_b128 {v4(WF[fs][rr - FM])}, v{RDW[st]} offset:{(rr - FM) * 32 * ROWB + ks * 32}")
+            emit(f"ds_read_b128 {v4(WF[fs][pl][q - FM])}, v{RDW[st][pl]} offset:{(q - FM) * 32 * ROWB + ks * 32}")
 
     def set_inc(ahead):
         # %[inc] = (t + ahead < nk) ? 128 : 0   — the offsets of a tile past the end of K stay on the last tile
@@ -124,14 +136,13 @@ def gen(FM, FN, NSTG, mfma_op, ablate="", deep=None, tmix=False):
     emit(f"v_mov_b32 v{VW[0]}, %[vw0]")
     for i in range(1, NW):
         emit(f"v_add_u32 v{VW[i]}, %[sw], v{VW[i - 1]}")
-    emit(f"v_mov_b32 v{WRA[0]}, %[wr0]")
-    emit(f"v_add_u32 v{WRW[0]}, {A_BYTES}, v{WRA[0]}")
-    emit(f"v_add_u32 v{WRA[1]}, {STAGE}, v{WRA[0]}")
-    emit(f"v_add_u32 v{WRW[1]}, {STAGE + A_BYTES}, v{WRA[0]}")
-    emit(f"v_mov_b32 v{RDA[0]}, %[rda0]")
-    emit(f"v_add_u32 v{RDA[1]}, {STAGE}, v{RDA[0]}")
-    emit(f"v_mov_b32 v{RDW[0]}, %[rdw0]")
-    emit(f"v_add_u32 v{RDW[1]}, {STAGE}, v{RDW[0]}")
+    for st in range(2):
+        for pl in range(P):
+            off = st * STAGE + pl * PLANE
+            emit(f"v_add_u32 v{WRA[st][pl]}, {off}, %[wr0]" if off else f"v_mov_b32 v{WRA[st][pl]}, %[wr0]")
+            emit(f"v_add_u32 v{WRW[st][pl]}, {off + A_BYTES}, %[wr0]")
+            emit(f"v_add_u32 v{RDA[st][pl]}, {off}, %[rda0]" if off else f"v_mov_b32 v{RDA[st][pl]}, %[rda0]")
+            emit(f"v_add_u32 v{RDW[st][pl]}, {off}, %[rdw0]" if off else f"v_mov_b32 v{RDW[st][pl]}, %[rdw0]")
     emit("s_mov_b32 %[t], 0")
     # tiles 0 .. NSTG - 1 in flight; offsets advance to tile (index of the load + 1) when that tile exists
     for s in range(NSTG):
@@ -139,7 +150,7 @@ def gen(FM, FN, NSTG, mfma_op, ablate="", deep=None, tmix=False):
         for j in range(NL):
             load(s, j)
             bump(j, "%[inc]")
-    emit(f"s_waitcnt vmcnt({(NSTG - 1) * NL})")
+    emit(f"s_waitcnt vmcnt({(NSTG - 1) * NL * P})")
     for j in range(NL):
         write(0, 0, j)
     set_inc(NSTG + 1)
@@ -149,7 +160,7 @@ def gen(FM, FN, NSTG, mfma_op, ablate="", deep=None, tmix=False):
     emit("s_waitcnt lgkmcnt(0)")
     emit("s_barrier")
     for ks0 in range(2 if deep else 1):
-        for rr in range(NFR):
+        for rr in range(NFR * P):
             fread(ks0, 0, ks0, rr)
     emit("s_waitcnt lgkmcnt(0)")
 
@@ -160,15 +171,27 @@ def gen(FM, FN, NSTG, mfma_op, ablate="", deep=None, tmix=False):
         for ks in range(4):
             fs = ks if deep else ks & 1
             nwr = max(0, min(WPK, NL - ks * WPK)) if ks < NWK else 0
-            fillers = [("r", f) for f in range(NFR)] + [("w", ks * WPK + f) for f in range(nwr)]
+            fillers = [("r", f) for f in range(NFR * P)] + [("w", ks * WPK + f) for f in range(nwr)]
             nf = len(fillers)
             dist = 2 if deep else 1                     # fragment prefetch distance in k-steps
-            for i in range(NMF):
-                a, b = i // FM, i % FM
-                c = "0" if (zero_c and ks == 0) else f"%[acc{a * FM + b}]"
-                emit(f"{mfma_op} %[acc{a * FM + b}], {v4(WF[fs][a])}, {v4(XF[fs][b])}, {c}")
+            # MFMAs of the k-step.  Split precision: three passes in the order of gemm2_kernel<X2> (Wr.A, W.Ar, W.A) — pass-major, so the
+            # three MFMAs of one accumulator are NMF instructions apart while every element still sums its products in that order
+            mf = []
+            for ps in range(NPASS):
+                for i in range(NMF):
+                    a, b = i // FM, i % FM
+                    if P == 1:
+                        wsrc, xsrc = WF[fs][0][a], XF[fs][0][b]
+                    else:
+                        wsrc = WF[fs][1][a] if ps == 0 else WF[fs][0][a]
+                        xsrc = XF[fs][1][b] if ps == 1 else XF[fs][0][b]
+                    c = "0" if (zero_c and ks == 0 and ps == 0) else f"%[acc{a * FM + b}]"
+                    mf.append(f"{mfma_op} %[acc{a * FM + b}], {v4(wsrc)}, {v4(xsrc)}, {c}")
+            nslots = len(mf)
+            for i in range(nslots):
+                emit(mf[i])
                 for fi, (kind, x) in enumerate(fillers):
-                    slot = fi if nf <= NMF else fi * NMF // nf
+                    slot = fi if nf <= nslots else fi * nslots // nf
                     if slot != i:
                         continue
                     if kind == "r":
@@ -179,7 +202,7 @@ def gen(FM, FN, NSTG, mfma_op, ablate="", deep=None, tmix=False):
                         else:
                             fread(fset, cs ^ 1, kt - 4, x)
                     else:
-                        emit(f"s_waitcnt vmcnt({NSTG * NL - 1})")
+                        emit(f"s_waitcnt vmcnt({NSTG * NL * P - P})")
                         write(gs, cs ^ 1, x)
                         load(gs, x)
                         bump(x, "%[inc]")
@@ -190,11 +213,11 @@ def gen(FM, FN, NSTG, mfma_op, ablate="", deep=None, tmix=False):
                 if "b" not in ablate:
                     emit("s_barrier")
             elif deep:
-                emit(f"s_waitcnt lgkmcnt({NFR + nwr})")       # the reads issued ONE k-step earlier (older than this k-step's) are in
+                emit(f"s_waitcnt lgkmcnt({(NFR + nwr) * P})")   # the reads issued ONE k-step earlier (older than this k-step's) are in
             elif ks == 3:
                 emit("s_waitcnt lgkmcnt(0)")
             else:
-                emit(f"s_waitcnt lgkmcnt({nwr})")
+                emit(f"s_waitcnt lgkmcnt({nwr * P})")
 
     gs_even = NSTG - 1          # staging set that holds tile t + 1 when t is even
     tile(0, gs_even, True)                        # t = 0
@@ -215,16 +238,17 @@ def gen(FM, FN, NSTG, mfma_op, ablate="", deep=None, tmix=False):
     emit("s_nop 15")
     emit("s_nop 15")
 
-    name = f"g4_loop_{FM}x{FN}_s{NSTG}" + (f"_ab_{ablate}" if ablate else "") + ("_tmix" if tmix else "")
+    name = f"g4_loop_{FM}x{FN}_s{NSTG}" + (f"_ab_{ablate}" if ablate else "") + ("_tmix" if tmix else "") + ("_x2" if P == 2 else "")
     nacc = FM * FN
     lines = []
-    lines.append(f"// {BM} x {BN} tile, {32 * FM} x {32 * FN} per wave, {NSTG} K tile(s) of global loads in flight; registers v32 .. v{last}")
+    lines.append(f"// {BM} x {BN} tile, {32 * FM} x {32 * FN} per wave, {NSTG} K tile(s) of global loads in flight, {P} plane(s); registers v{base} .. v{last}")
     lines.append(f"__device__ __forceinline__ void {name}(f32x16 (&acc)[{FN}][{FM}], unsigned va0, unsigned vw0, unsigned wr0, unsigned rda0, unsigned rdw0,")
+    x2args = " u32x4 rsAr, u32x4 rsWr," if P == 2 else ""
     if tmix:
-        lines.append("                                           u32x4 rsA, u32x4 rsW, unsigned kt0, unsigned sw, unsigned nk, unsigned tps, unsigned tps2) {")
+        lines.append(f"                                           u32x4 rsA, u32x4 rsW,{x2args} unsigned kt0, unsigned sw, unsigned nk, unsigned tps, unsigned tps2) {{")
         lines.append("  unsigned long long m1, m2, mv;")
     else:
-        lines.append("                                           u32x4 rsA, u32x4 rsW, unsigned sa, unsigned sw, unsigned nk) {")
+        lines.append(f"                                           u32x4 rsA, u32x4 rsW,{x2args} unsigned sa, unsigned sw, unsigned nk) {{")
     lines.append("  unsigned t, tmp, inc;")
     lines.append("  asm volatile(")
     for ln in out:
@@ -233,32 +257,40 @@ def gen(FM, FN, NSTG, mfma_op, ablate="", deep=None, tmix=False):
     lines.append(f"      : {outs},")
     lines.append('        [t] "=&s"(t), [tmp] "=&s"(tmp), [inc] "=&s"(inc)' + (', [m1] "=&s"(m1), [m2] "=&s"(m2), [mv] "=&s"(mv)' if tmix else ""))
     lines.append('      : [va0] "v"(va0), [vw0] "v"(vw0), [wr0] "v"(wr0), [rda0] "v"(rda0), [rdw0] "v"(rdw0), [rsA] "s"(rsA), [rsW] "s"(rsW),')
+    if P == 2:
+        lines.append('        [rsAr] "s"(rsAr), [rsWr] "s"(rsWr),')
     if tmix:
         lines.append('        [kt0] "s"(kt0), [sw] "s"(sw), [nk] "s"(nk), [tps] "s"(tps), [tps2] "s"(tps2)')
     else:
         lines.append('        [sa] "s"(sa), [sw] "s"(sw), [nk] "s"(nk)')
-    clob = ", ".join(f'"v{i}"' for i in range(32, last + 1))
+    clob = ", ".join(f'"v{i}"' for i in range(base, last + 1))
     lines.append(f'      : "memory", "scc", {clob});')
     lines.append("}")
     lines.append("")
-    assert nacc + 3 + 10 + (5 if tmix else 0) <= 30
+    assert nacc + 3 + 10 + (5 if tmix else 0) + (2 if P == 2 else 0) <= 30
     return "\n".join(lines), name
 
 
 def main():
     print("// GENERATED by tools/gen_gemm4_loops.py — do not edit; see csrc/gemm4.hip for the schedule.")
     print("// clang-format off")
-    for FM, FN, NSTG in ((4, 4, 2), (4, 2, 2), (2, 4, 2), (2, 2, 2), (2, 1, 2), (1, 2, 2), (1, 1, 2)):
-        txt, _ = gen(FM, FN, NSTG, "AVSD_MFMA_OP_PLACEHOLDER")
+
+    def put(*a, **k):
+        txt, _ = gen(*a, "AVSD_MFMA_OP_PLACEHOLDER", **k)
         print(txt.replace('"AVSD_MFMA_OP_PLACEHOLDER ', 'AVSD_MFMA_OP " '))
+
+    for FM, FN in ((4, 4), (4, 2), (2, 4), (2, 2), (2, 1), (1, 2), (1, 1)):
+        put(FM, FN, 2)
     for FM, FN in ((4, 2), (2, 4), (2, 2), (2, 1), (1, 2), (1, 1)):
-        txt, _ = gen(FM, FN, 2, "AVSD_MFMA_OP_PLACEHOLDER", tmix=True, deep=(FM * FN <= 4))
-        print(txt.replace('"AVSD_MFMA_OP_PLACEHOLDER ', 'AVSD_MFMA_OP " '))
+        put(FM, FN, 2, tmix=True, deep=(FM * FN <= 4))
+    # split precision (two planes per operand, three MFMA passes)
+    for FM, FN in ((2, 2), (2, 1), (1, 2), (1, 1)):
+        put(FM, FN, 2, planes=2)
+        put(FM, FN, 2, planes=2, tmix=True, base=(28 if (FM, FN) == (2, 2) else 32))
     if "--ablate" in sys.argv:
         print("#define AVSD_G4_ABLATE 1")
         for ab in ("g", "w", "r", "gw", "gwr", "b", "gwrb"):
-            txt, _ = gen(4, 4, 2, "AVSD_MFMA_OP_PLACEHOLDER", ab)
-            print(txt.replace('"AVSD_MFMA_OP_PLACEHOLDER ', 'AVSD_MFMA_OP " '))
+            put(4, 4, 2, ablate=ab)
 
 
 if __name__ == "__main__":

@@ -55,7 +55,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // X2 (AVSD_GEMM_X2, split precision): every operand a (main, rest) pair of planes — an LDS stage holds [A | W | A rest | W rest], the rest
 // planes come through second buffer descriptors with the same offsets, every fragment pair takes three MFMAs (Wr.A, W.Ar, W.A).
-template <int FM, int FN, int MODE, bool X2 = false>
+// NS = K tiles of global loads in flight per workgroup (staging register sets): 2, or 4 for the small tiles of the weight-streaming layers
+template <int FM, int FN, int MODE, bool X2 = false, int NS = 2>
 __global__ __launch_bounds__(256, 1) void gemm4_kernel(const avsd_gemm_desc p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem4[];
   constexpr int BM = 64 * FM, BN = 64 * FN;
@@ -98,17 +99,29 @@ __global__ __launch_bounds__(256, 1) void gemm4_kernel(const avsd_gemm_desc p) {
   const unsigned long long par = pa + (X2 ? (unsigned long long)p.a_lo * 2ull : 0ull), pwr = pw + (X2 ? (unsigned long long)p.w_lo * 2ull : 0ull);
   const u32x4 rsAr = {(unsigned)par, (unsigned)(par >> 32) & 0xffffu, rsA[2], 0x00020000u};
   const u32x4 rsWr = {(unsigned)pwr, (unsigned)(pwr >> 32) & 0xffffu, rsW[2], 0x00020000u};
-  (void)rsAr; (void)rsWr;
 
+  // Rotated K walk (AVSD_GEMM_KROT): workgroups that share a column band of W (same tn, different tm) start at different K tiles of the
+  // slice and wrap around.  Walking K in lockstep, all of them wait for the SAME weight tile at the same time — inside a denoising
+  // step the weights come from HBM (2.3 GB stream through the caches between two uses), so the launch runs as one chain of HBM round
+  // trips with only (column bands x prefetch depth) distinct tiles in flight; rotated, every tile a workgroup needs was fetched by
+  // its neighbour a few tiles earlier and all of W is requested in the first few tile times.  The f32 summation order of a row band
+  // then starts at its kst (deterministic; results differ from the unrotated walk in the last bits).
+  using Loop = G4Loop<FM, FN, NS, MODE == AVSD_GEMM_TMIX, X2>;
+  const int kst = (Loop::rot && (p.flags & AVSD_GEMM_KROT) && nk > 1 && ntm > 1) ? (int)(((long long)tm * nk) / ntm) : 0;
+  const int kfirst = kt0 + kst;
   // staging: thread t moves the 16-byte vector (row (t >> 3) + 32 i, k-chunk t & 7) of each operand tile; fragment row
   // wm/wn * (32 F) + 32 b + (lane & 31), 16-byte chunk 2 ks + (lane >> 5)
   const int srow = tid >> 3, sch = tid & 7;
-  const unsigned va0 = (unsigned)((tm * BM + srow) * p.lda + kt0 * BK + sch * 8) * 2u;
-  const unsigned vw0 = (unsigned)((tn * BN + srow) * p.ldw + kt0 * BK + sch * 8) * 2u;
-  const unsigned wr0 = (unsigned)(srow * ROWB + sch * 16);
-  const unsigned rda0 = (unsigned)((wm * 32 * FM + (lane & 31)) * ROWB + (lane >> 5) * 16);
-  const unsigned rdw0 = (unsigned)(A_BYTES + (wn * 32 * FN + (lane & 31)) * ROWB + (lane >> 5) * 16);
-  const unsigned sa = 32u * (unsigned)p.lda * 2u, sw = 32u * (unsigned)p.ldw * 2u;
+  G4Args ga;
+  ga.va0 = (unsigned)((tm * BM + srow) * p.lda + kfirst * BK + sch * 8) * 2u;
+  ga.vw0 = (unsigned)((tn * BN + srow) * p.ldw + kfirst * BK + sch * 8) * 2u;
+  ga.wr0 = (unsigned)(srow * ROWB + sch * 16);
+  ga.rda0 = (unsigned)((wm * 32 * FM + (lane & 31)) * ROWB + (lane >> 5) * 16);
+  ga.rdw0 = (unsigned)(A_BYTES + (wn * 32 * FN + (lane & 31)) * ROWB + (lane >> 5) * 16);
+  ga.rsA = rsA; ga.rsW = rsW; ga.rsAr = rsAr; ga.rsWr = rsWr;
+  ga.kst = (unsigned)kst; ga.winc = 128u - 128u * (unsigned)nk;
+  ga.sa = 32u * (unsigned)p.lda * 2u; ga.sw = 32u * (unsigned)p.ldw * 2u;
+  ga.nk = (unsigned)nk; ga.kt0 = (unsigned)kt0; ga.tps = 0u; ga.tps2 = 0u;
 
   // LayerNorm fold with pre-folded statistics (one (sum, sumsq) pair per row, avsd_ln_fold): the pairs of this lane's FM rows are
   // requested BEFORE the main loop (older than every load the loop issues, so its counted waits stay valid) and folded after it
@@ -124,59 +137,35 @@ __global__ __launch_bounds__(256, 1) void gemm4_kernel(const avsd_gemm_desc p) {
   f32x16 acc[FN][FM];
   if constexpr (MODE == AVSD_GEMM_TMIX) {
     // temporal-mix A operand (utils.py:43-53): K segment s of output row (b, f, p) reads row (b, {0, max(f - 1, 0), f}[s], p).  Per 16-byte
-    // vector of this thread: its byte offset in the first tile of this K slice and the two jumps it takes, on top of the regular
-    // +128 bytes per K tile, when the tile index crosses a segment boundary.  The asm loop fetches them from the second LDS stage
-    // (unused until its first write, which follows these reads in the same wave's in-order LDS queue).
+    // vector of this thread: its byte offset in the first tile it loads and the jumps it takes, on top of the regular +128 bytes per
+    // K tile, when the tile index crosses a segment boundary (d01, d12) or wraps from the last tile of the slice to its first (dw).
+    // The asm loop fetches them from the second LDS stage (unused until its first write, which follows these reads in the same
+    // wave's in-order LDS queue).
     const int tps = p.cseg / BK;                                   // K tiles per segment
-    const int seg0 = kt0 / tps, col0 = (kt0 - seg0 * tps) * BK;
-    unsigned* tbl = reinterpret_cast<unsigned*>(smem4 + STAGE) + tid * (3 * NA);
+    const int seg0 = min(kfirst / tps, 2), col0 = (kfirst - seg0 * tps) * BK;
+    const int ke = kt0 + nk - 1;                                   // last / first tile of the slice: the wrap jump
+    const int seg_e = min(max(ke, 0) / tps, 2), col_e = (ke - seg_e * tps) * BK;
+    const int seg_s = min(kt0 / tps, 2), col_s = (kt0 - seg_s * tps) * BK;
+    unsigned* tbl = reinterpret_cast<unsigned*>(smem4 + STAGE) + tid * (4 * NA);
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int m = tm * BM + srow + 32 * i;
-      unsigned v = 0xC0000000u, d01 = 0u, d12 = 0u;              // rows past M: far past num_records, and they stay there
+      unsigned v = 0xC0000000u, d01 = 0u, d12 = 0u, dw = 0u;       // rows past M: far past num_records, and they stay there
       if (m < p.M) {
         const int f = (m / p.hw) % p.frames;
         const int r0 = m - f * p.hw, r1 = f > 0 ? m - p.hw : m;
         const int o[3] = {r0 * p.lda, r1 * p.lda, m * p.lda};
-        v = (unsigned)(o[seg0 < 3 ? seg0 : 2] + col0 + sch * 8) * 2u;
+        v = (unsigned)(o[seg0] + col0 + sch * 8) * 2u;
         d01 = (unsigned)(o[1] - o[0] - p.cseg) * 2u;
         d12 = (unsigned)(o[2] - o[1] - p.cseg) * 2u;
+        dw = (unsigned)(o[seg_s] + col_s - o[seg_e] - col_e - BK) * 2u;
       }
-      tbl[i] = v; tbl[NA + i] = d01; tbl[2 * NA + i] = d12;
+      tbl[i] = v; tbl[NA + i] = d01; tbl[2 * NA + i] = d12; tbl[3 * NA + i] = dw;
     }
-    const unsigned tbl_addr = (unsigned)(STAGE + tid * (3 * NA) * 4);
-    if (nk > 0) {
-      const unsigned tp = (unsigned)tps;
-      if constexpr (X2) {
-        if constexpr (FM == 2 && FN == 2) g4_loop_2x2_s2_tmix_x2(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, rsAr, rsWr, (unsigned)kt0, sw, (unsigned)nk, tp, 2u * tp);
-        else if constexpr (FM == 2 && FN == 1) g4_loop_2x1_s2_tmix_x2(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, rsAr, rsWr, (unsigned)kt0, sw, (unsigned)nk, tp, 2u * tp);
-        else if constexpr (FM == 1 && FN == 2) g4_loop_1x2_s2_tmix_x2(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, rsAr, rsWr, (unsigned)kt0, sw, (unsigned)nk, tp, 2u * tp);
-        else g4_loop_1x1_s2_tmix_x2(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, rsAr, rsWr, (unsigned)kt0, sw, (unsigned)nk, tp, 2u * tp);
-      } else {
-        if constexpr (FM == 4 && FN == 2) g4_loop_4x2_s2_tmix(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, (unsigned)kt0, sw, (unsigned)nk, tp, 2u * tp);
-        else if constexpr (FM == 2 && FN == 4) g4_loop_2x4_s2_tmix(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, (unsigned)kt0, sw, (unsigned)nk, tp, 2u * tp);
-        else if constexpr (FM == 2 && FN == 2) g4_loop_2x2_s2_tmix(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, (unsigned)kt0, sw, (unsigned)nk, tp, 2u * tp);
-        else if constexpr (FM == 2 && FN == 1) g4_loop_2x1_s2_tmix(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, (unsigned)kt0, sw, (unsigned)nk, tp, 2u * tp);
-        else if constexpr (FM == 1 && FN == 2) g4_loop_1x2_s2_tmix(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, (unsigned)kt0, sw, (unsigned)nk, tp, 2u * tp);
-        else if constexpr (FM == 1 && FN == 1) g4_loop_1x1_s2_tmix(acc, tbl_addr, vw0, wr0, rda0, rdw0, rsA, rsW, (unsigned)kt0, sw, (unsigned)nk, tp, 2u * tp);
-      }
-    }
-  } else
-  if (nk > 0) {
-    if constexpr (X2) {
-      if constexpr (FM == 2 && FN == 2) g4_loop_2x2_s2_x2(acc, va0, vw0, wr0, rda0, rdw0, rsA, rsW, rsAr, rsWr, sa, sw, (unsigned)nk);
-      else if constexpr (FM == 2 && FN == 1) g4_loop_2x1_s2_x2(acc, va0, vw0, wr0, rda0, rdw0, rsA, rsW, rsAr, rsWr, sa, sw, (unsigned)nk);
-      else if constexpr (FM == 1 && FN == 2) g4_loop_1x2_s2_x2(acc, va0, vw0, wr0, rda0, rdw0, rsA, rsW, rsAr, rsWr, sa, sw, (unsigned)nk);
-      else g4_loop_1x1_s2_x2(acc, va0, vw0, wr0, rda0, rdw0, rsA, rsW, rsAr, rsWr, sa, sw, (unsigned)nk);
-    } else
-    if constexpr (FM == 4 && FN == 4) g4_loop_4x4_s2(acc, va0, vw0, wr0, rda0, rdw0, rsA, rsW, sa, sw, (unsigned)nk);
-    else if constexpr (FM == 4 && FN == 2) g4_loop_4x2_s2(acc, va0, vw0, wr0, rda0, rdw0, rsA, rsW, sa, sw, (unsigned)nk);
-    else if constexpr (FM == 2 && FN == 4) g4_loop_2x4_s2(acc, va0, vw0, wr0, rda0, rdw0, rsA, rsW, sa, sw, (unsigned)nk);
-    else if constexpr (FM == 2 && FN == 2) g4_loop_2x2_s2(acc, va0, vw0, wr0, rda0, rdw0, rsA, rsW, sa, sw, (unsigned)nk);
-    else if constexpr (FM == 2 && FN == 1) g4_loop_2x1_s2(acc, va0, vw0, wr0, rda0, rdw0, rsA, rsW, sa, sw, (unsigned)nk);
-    else if constexpr (FM == 1 && FN == 2) g4_loop_1x2_s2(acc, va0, vw0, wr0, rda0, rdw0, rsA, rsW, sa, sw, (unsigned)nk);
-    else g4_loop_1x1_s2(acc, va0, vw0, wr0, rda0, rdw0, rsA, rsW, sa, sw, (unsigned)nk);
+    ga.va0 = (unsigned)(STAGE + tid * (4 * NA) * 4);
+    ga.tps = (unsigned)tps; ga.tps2 = 2u * (unsigned)tps;
   }
+  if (nk > 0) Loop::run(acc, ga);
   if (nk <= 0) {
 #pragma unroll
     for (int a = 0; a < FN; ++a)
@@ -228,14 +217,14 @@ __global__ __launch_bounds__(256, 1) void gemm4_kernel(const avsd_gemm_desc p) {
   });
 }
 
-template <int FM, int FN, int MODE, bool X2 = false>
+template <int FM, int FN, int MODE, bool X2 = false, int NS = 2>
 int launch4(const avsd_gemm_desc& d, hipStream_t s) {
   constexpr int BM = 64 * FM, BN = 64 * FN;
   constexpr size_t lds = (size_t)2 * (BM + BN) * ROWB * (X2 ? 2 : 1);
   static_assert(lds <= 160 * 1024, "tile does not fit the 160 KB of LDS");
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<FM, FN, MODE, X2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<FM, FN, MODE, X2, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       avsd_set_error("gemm4: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
       return AVSD_ELAUNCH;
@@ -245,7 +234,7 @@ int launch4(const avsd_gemm_desc& d, hipStream_t s) {
   const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
   const int nsplit = d.split_k > 1 ? d.split_k : 1;
   dim3 grid((unsigned)(ntm * ntn), (unsigned)nsplit, 1);
-  hipLaunchKernelGGL((gemm4_kernel<FM, FN, MODE, X2>), grid, dim3(256), lds, s, d);
+  hipLaunchKernelGGL((gemm4_kernel<FM, FN, MODE, X2, NS>), grid, dim3(256), lds, s, d);
   AVSD_CHECK_LAUNCH("gemm4 launch");
   if (nsplit > 1) return avsd_gemm_splitk_reduce(d, s);
   return AVSD_OK;
@@ -279,7 +268,10 @@ int avsd_gemm_dispatch_asm(const avsd_gemm_desc& d, hipStream_t s) {
       case 4: return launch4<2, 1, AVSD_GEMM_TMIX>(d, s);
       case 5: return launch4<1, 2, AVSD_GEMM_TMIX>(d, s);
       case 6: return launch4<1, 1, AVSD_GEMM_TMIX>(d, s);
-      default: AVSD_REQUIRE(false, "gemm/asm tiles: tile %d has no TMIX form (61..66 do)", d.tile);
+      case 7: return launch4<2, 1, AVSD_GEMM_TMIX, false, 4>(d, s);
+      case 8: return launch4<1, 2, AVSD_GEMM_TMIX, false, 4>(d, s);
+      case 9: return launch4<1, 1, AVSD_GEMM_TMIX, false, 4>(d, s);
+      default: AVSD_REQUIRE(false, "gemm/asm tiles: tile %d has no TMIX form (61..69 do)", d.tile);
     }
   }
   switch (k) {
@@ -290,6 +282,9 @@ int avsd_gemm_dispatch_asm(const avsd_gemm_desc& d, hipStream_t s) {
     case 4: return launch4<2, 1, AVSD_GEMM_PLAIN>(d, s);     // 128 x 64, 54 KB
     case 5: return launch4<1, 2, AVSD_GEMM_PLAIN>(d, s);     // 64 x 128
     case 6: return launch4<1, 1, AVSD_GEMM_PLAIN>(d, s);     // 64 x 64, 36 KB: four workgroups per CU
+    case 7: return launch4<2, 1, AVSD_GEMM_PLAIN, false, 4>(d, s);     // the three small tiles with FOUR K tiles in flight
+    case 8: return launch4<1, 2, AVSD_GEMM_PLAIN, false, 4>(d, s);
+    case 9: return launch4<1, 1, AVSD_GEMM_PLAIN, false, 4>(d, s);
     default: AVSD_REQUIRE(false, "gemm/asm tiles: unknown tile %d", d.tile);
   }
 }

@@ -17,7 +17,7 @@ from . import precision as P
 from ._lib import GemmDesc, XAttnDesc, check
 
 PLAIN, TMIX, CONV3 = 0, 1, 2
-GEGLU, OUT_F32, GELU, XCD_N, ROWSTATS, LNFUSE, RES1_F32, RES2_F32, X2 = 1, 2, 4, 8, 16, 32, 64, 128, 256
+GEGLU, OUT_F32, GELU, XCD_N, ROWSTATS, LNFUSE, RES1_F32, RES2_F32, X2, KROT = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 _XCD_MODE = os.environ.get("AVSD_XCD_MODE", "auto")     # auto | m | n  (which operand each XCD's L2 fetches once)
 F32 = torch.float32      # (16-bit storage dtype: P.ACT, asva_amd/precision.py)
 
@@ -113,12 +113,23 @@ X2_SPLITK_CANDIDATES = ((34, 2), (34, 4), (35, 2), (35, 4), (36, 2), (36, 4), (7
 # (avsd_gemm_conv3r_supported); split_k cuts the cin / 64 channel chunks
 # 4-wave tiles with a hand-scheduled main loop (csrc/gemm4.hip): 60 = 256x256, 61 = 256x128, 62 = 128x256, 63 = 128x128; PLAIN, K % 64 == 0
 # 64 = 128x64, 65 = 64x128, 66 = 64x64; TMIX (cseg % 64 == 0): 61..66
-ASM_CANDIDATES = ((60, 1), (61, 1), (62, 1), (63, 1), (64, 1), (65, 1), (66, 1))
-ASM_SPLITK_CANDIDATES = ((63, 2), (63, 4), (63, 8), (61, 2), (62, 2), (62, 4), (64, 2), (64, 4), (65, 2), (65, 4), (66, 2), (66, 4))
-ASM_TILES = tuple(range(60, 67))
+ASM_CANDIDATES = ((60, 1), (61, 1), (62, 1), (63, 1), (64, 1), (65, 1), (66, 1), (67, 1), (68, 1), (69, 1))
+ASM_SPLITK_CANDIDATES = ((63, 2), (63, 4), (63, 8), (61, 2), (62, 2), (62, 4), (64, 2), (64, 4), (65, 2), (65, 4), (66, 2), (66, 4), (67, 2), (68, 2), (69, 2), (69, 4))
+ASM_TILES = tuple(range(60, 70))
 ASM_X2_CANDIDATES = ((63, 1), (64, 1), (65, 1), (66, 1))        # split precision: 128x128 ... 64x64
 ASM_X2_SPLITK_CANDIDATES = ((63, 2), (63, 4), (64, 2), (64, 4), (65, 2), (65, 4), (66, 2), (66, 4), (66, 8))
 _ASM_TILES = os.environ.get("AVSD_ASM_TILES", "1") != "0"
+# asm tiles: row bands start their K walk at different tiles (AVSD_GEMM_KROT, include/avsd.h) — the weights of the low-resolution layers
+# come from HBM inside a step, and a lockstep walk is one chain of round trips.  AVSD_KROT=0 / set_krot(False): the unrotated walk
+# (bit-identical to the LDS-direct tiles).
+_KROT = os.environ.get("AVSD_KROT", "1") != "0"
+
+
+def set_krot(on: bool) -> None:
+    global _KROT
+    _KROT = bool(on)
+
+
 _RASTER_G = int(os.environ.get("AVSD_RASTER_G", "0"))       # probe knob: rows of the tile blocks an XCD walks (0 = the kernel's default)
 CONV3R_TILES = (40, 42, 43, 44, 48)
 CONV3R2D_TILES = (51, 52, 53, 54)   # rectangular resident tiles (TH rows x 32 pixels) for images wider than 32 pixels: the VAE decoder, cfg 4
@@ -560,6 +571,7 @@ def gemm(
     def _set(t, sk):
         nonlocal ws
         d.tile, d.split_k = t, sk
+        d.flags = (d.flags | KROT) if (_KROT and t in ASM_TILES) else (d.flags & ~KROT)       # (after the table key was formed: not part of it)
         if sk > 1:
             if ws is None or ws.numel() < sk * M * N:
                 ws = torch.empty((sk * M * N,), dtype=F32, device=a.device)

@@ -75,13 +75,16 @@ int avsd_device_info(char* name_host, int len, int* num_cu_host);
  *                    in f32 while the 16-bit copy in `out` feeds the next matrix multiply.
  * "16-bit" = bfloat16 in libavsd_hip.so, IEEE half in libavsd_hip_f16.so (the same sources built with -DAVSD_F16=1;
  *   avsd_precision() tells which); accumulation and the epilogue are f32 in both.
+ *   AVSD_GEMM_KROT:  scheduling hint for the asm tiles (gemm4.hip): row bands start their K walk at different tiles and wrap (the weights of
+ *                    the low-resolution layers stream from HBM: a lockstep walk is one chain of round trips).  Deterministic; the f32
+ *                    summation order of a band then starts mid-K, so results differ from the unrotated walk in the last bits.
  *   AVSD_GEMM_XCD_N: scheduling hint, no effect on the result — tiles are dealt to the 8 XCDs in bands of N instead of
  *                    bands of M, so the weights (not the activations) are the operand each L2 fetches only once.
  * blockIdx.z batches: pointers advance by batch_stride_* elements (0 = shared).
  */
 enum { AVSD_GEMM_PLAIN = 0, AVSD_GEMM_TMIX = 1, AVSD_GEMM_CONV3 = 2 };
 enum { AVSD_GEMM_GEGLU = 1, AVSD_GEMM_OUT_F32 = 2, AVSD_GEMM_GELU = 4, AVSD_GEMM_XCD_N = 8, AVSD_GEMM_ROWSTATS = 16,
-       AVSD_GEMM_LNFUSE = 32, AVSD_GEMM_RES1_F32 = 64, AVSD_GEMM_RES2_F32 = 128, AVSD_GEMM_X2 = 256 };
+       AVSD_GEMM_LNFUSE = 32, AVSD_GEMM_RES1_F32 = 64, AVSD_GEMM_RES2_F32 = 128, AVSD_GEMM_X2 = 256, AVSD_GEMM_KROT = 512 };
 #define AVSD_GEMM_MAX_TILE 33
 #define AVSD_GEMM_MAX_TILE_X2 36   /* AVSD_GEMM_X2 also has tiles 34..36 (gemm.hip dispatch_tile_x2) */
 /* 256 x 160 LDS-direct tile, 8 MFMA + 4 loader waves (gemm.hip dispatch_tile; not with AVSD_GEMM_X2) */
@@ -92,9 +95,9 @@ enum { AVSD_GEMM_GEGLU = 1, AVSD_GEMM_OUT_F32 = 2, AVSD_GEMM_GELU = 4, AVSD_GEMM
  * cin % 64 == 0, image width <= 32 and a tile of whole image rows / whole images (avsd_gemm_conv3r_supported); split_k cuts
  * the channel chunks (split_k <= cin / 64).  No AVSD_GEMM_X2 / GEGLU / LNFUSE.  Other descriptors are refused with these ids. */
 /* 4-wave tiles with a hand-scheduled (inline-asm) main loop, register-staged operands (gemm4.hip): 60 = 256 x 256, 61 = 256 x 128,
- * 62 = 128 x 256, 63 = 128 x 128, 64 = 128 x 64, 65 = 64 x 128, 66 = 64 x 64.  PLAIN single-source descriptors with K % 64 == 0, no AVSD_GEMM_X2; every epilogue flag; split_k. */
+ * 62 = 128 x 256, 63 = 128 x 128, 64 = 128 x 64, 65 = 64 x 128, 66 = 64 x 64, 67..69 = the last three with four K tiles in flight.  PLAIN single-source descriptors with K % 64 == 0, no AVSD_GEMM_X2; every epilogue flag; split_k. */
 #define AVSD_GEMM_TILE_ASM_FIRST 60
-#define AVSD_GEMM_TILE_ASM_LAST 66
+#define AVSD_GEMM_TILE_ASM_LAST 69
 #define AVSD_GEMM_TILE_CONV3R_FIRST 40
 #define AVSD_GEMM_TILE_CONV3R_LAST 49
 /* the same convolution with RECTANGULAR resident tiles (TH image rows x 32 pixels + a one-pixel halo, positions outside the image

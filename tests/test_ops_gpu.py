@@ -749,13 +749,21 @@ def test_xattn_pack_kv_matches_indexing(ops, gather):
     assert not k[:, lk:].any() and not vt[:, :, lk:].any()          # padding zero-filled by the launch
 
 
-# ---- hand-scheduled 4-wave tiles (csrc/gemm4.hip, ids 60-66) ---------------------------------------------------------------
-ASM_TILES = [60, 61, 62, 63, 64, 65, 66]
+# ---- hand-scheduled 4-wave tiles (csrc/gemm4.hip, ids 60-69) ---------------------------------------------------------------
+@pytest.fixture
+def krot_off(ops):
+    """the unrotated K walk: same f32 order as the LDS-direct tiles"""
+    ops.set_krot(False)
+    yield
+    ops.set_krot(True)
+
+
+ASM_TILES = [60, 61, 62, 63, 64, 65, 66, 67, 68, 69]
 
 
 @pytest.mark.parametrize("tile", ASM_TILES)
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 384, 320), (1000, 640, 1280), (77, 132, 192), (3000, 320, 640)])
-def test_gemm_asm_tiles_plain(ops, tile, M, N, K):
+def test_gemm_asm_tiles_plain(ops, tile, M, N, K, krot_off):
     """csrc/gemm4.hip: same products in the same K order as the LDS-direct tiles -> bit-identical to tile 9 (odd and even numbers of K
     tiles, M / N tails, K = one tile), against torch in f32, run to run; split-K slabs; every epilogue term"""
     a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
@@ -782,9 +790,9 @@ def test_gemm_asm_tiles_plain(ops, tile, M, N, K):
                                ops.gemm(h, w2, geglu=True, ln=(ops.ln_fold(st), cs, 1e-5), tile=9))
 
 
-@pytest.mark.parametrize("tile", [61, 62, 63, 64, 65, 66])
+@pytest.mark.parametrize("tile", [61, 62, 63, 64, 65, 66, 67, 68, 69])
 @pytest.mark.parametrize("B,hw,C,N", [(2, 64, 320, 320), (1, 32, 128, 132), (3, 96, 64, 64), (1, 16, 1280, 1280)])
-def test_gemm_asm_tiles_tmix(ops, tile, B, hw, C, N):
+def test_gemm_asm_tiles_tmix(ops, tile, B, hw, C, N, krot_off):
     """the temporal-mix A operand in the hand-scheduled loop: per-vector jumps at the two K-segment boundaries (frame 0 -> previous
     frame -> current frame), also for K slices that start inside a segment; full epilogue; against the f32 statement and tile 9"""
     Fr = 12
@@ -803,6 +811,39 @@ def test_gemm_asm_tiles_tmix(ops, tile, B, hw, C, N):
     for sk in (2, 3):
         if (3 * C // 64) // sk >= 2:
             assert torch.equal(ops.gemm(y, w, out_f32=True, tile=tile, split_k=sk, **kw), ops.gemm(y, w, out_f32=True, tile=9, split_k=sk, **kw))
+
+
+@pytest.mark.parametrize("tile", [61, 63, 64, 65, 66, 67, 68, 69])
+def test_gemm_asm_tiles_rotated_k_walk(ops, tile):
+    """AVSD_GEMM_KROT (the default of the asm tiles): every row band starts its K walk at another tile and wraps — also inside split-K
+    slices and across the temporal-mix segment boundaries.  Same products, another f32 order: f32-output tolerance against torch,
+    bit-identical run to run, and different bits from the unrotated walk somewhere (the flag really rotates)."""
+    ops.set_krot(True)
+    for M, N, K in [(1000, 640, 1280), (3000, 320, 640), (1536, 1280, 1920)]:
+        a, w, bias = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rndf(N, seed=3)
+        ref = a.float() @ w.float().T + bias
+        for sk in (1, 2, 3):
+            o = ops.gemm(a, w, bias=bias, out_f32=True, tile=tile, split_k=sk)
+            assert rel_l2(o, ref) < TOL_F32
+            assert all(torch.equal(ops.gemm(a, w, bias=bias, out_f32=True, tile=tile, split_k=sk), o) for _ in range(3))
+        ops.set_krot(False)
+        plain = ops.gemm(a, w, bias=bias, out_f32=True, tile=tile)
+        ops.set_krot(True)
+        if tile != 61 or M > 256:
+            assert not torch.equal(ops.gemm(a, w, bias=bias, out_f32=True, tile=tile), plain)
+    if tile != 61:
+        for B, hw, C, N in [(2, 64, 320, 320), (1, 32, 128, 132), (1, 16, 1280, 1280), (2, 64, 192, 64)]:
+            Fr = 12
+            M = B * Fr * hw
+            y, w, b = rnd(M, C, seed=1), rnd(N, 3 * C, seed=2, scale=(3 * C) ** -0.5), rndf(N, seed=3)
+            y5 = y.float().reshape(B, Fr, hw, C)
+            prev = torch.cat([y5[:, :1], y5[:, :-1]], 1)
+            ref = torch.cat([y5[:, :1].expand_as(y5), prev, y5], -1).reshape(M, 3 * C) @ w.float().T + b
+            for sk in (1, 2, 3, 4):
+                if (3 * C // 64) // sk < 2:
+                    continue
+                o = ops.gemm(y, w, bias=b, out_f32=True, mode=ops.TMIX, tmix=(hw, Fr), tile=tile, split_k=sk)
+                assert rel_l2(o, ref) < TOL_F32, (B, hw, C, N, sk)
 
 
 def test_gemm_asm_tiles_refuse(ops):

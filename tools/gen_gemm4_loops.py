@@ -16,7 +16,7 @@ import sys
 ROWB = 144
 
 
-def gen(FM, FN, NSTG, mfma_op, ablate="", deep=None, tmix=False, planes=1, base=32):
+def gen(FM, FN, NSTG, mfma_op, ablate="", deep=None, tmix=False, planes=1, base=32, rot=True):
     P = planes
     NA, NW = 2 * FM, 2 * FN
     NL = NA + NW
@@ -48,6 +48,7 @@ def gen(FM, FN, NSTG, mfma_op, ablate="", deep=None, tmix=False, planes=1, base=
     if tmix:       # temporal-mix A operand: per-vector jumps at the two K-segment boundaries (frame 0 -> previous frame -> current frame)
         D01 = [take(1) for _ in range(NA)]
         D12 = [take(1) for _ in range(NA)]
+        DW = [take(1) for _ in range(NA)] if rot else None      # ... and from the last K tile of the slice back to its first (rotated K walk)
         TMP = take(1)
     if r % 2:
         r += 1                                   # 64-bit-aligned tuples from here on
@@ -81,7 +82,11 @@ def gen(FM, FN, NSTG, mfma_op, ablate="", deep=None, tmix=False, planes=1, base=
         if tmix and j < NA:
             emit(f"v_cndmask_b32_e64 v{TMP}, 0, v{D01[j]}, %[m1]")
             emit(f"v_cndmask_b32_e64 v{TMP}, v{TMP}, v{D12[j]}, %[m2]")
-            emit(f"v_add3_u32 v{reg}, v{reg}, v{TMP}, {inc}")
+            if rot:
+                emit(f"v_cndmask_b32_e64 v{TMP}, v{TMP}, v{DW[j]}, %[m3]")
+                emit(f"v_add3_u32 v{reg}, v{reg}, v{TMP}, %[inca]")
+            else:
+                emit(f"v_add3_u32 v{reg}, v{reg}, v{TMP}, {inc}")
         else:
             emit(f"v_add_u32 v{reg}, {inc}, v{reg}")
 
@@ -105,13 +110,31 @@ def gen(FM, FN, NSTG, mfma_op, ablate="", deep=None, tmix=False, planes=1, base=
             emit(f"ds_read_b128 {v4(WF[fs][pl][q - FM])}, v{RDW[st][pl]} offset:{(q - FM) * 32 * ROWB + ks * 32}")
 
     def set_inc(ahead):
-        # %[inc] = (t + ahead < nk) ? 128 : 0   — the offsets of a tile past the end of K stay on the last tile
+        # Offsets advance from sequence index t + ahead - 1 to t + ahead.  The K walk starts at tile %[kst] of the slice and wraps:
+        # position = (kst + index) mod nk.  %[inc] = 0 past the end (the last tile is re-read, never consumed), 128 - 128 nk at the
+        # wrap, else 128.
         emit(f"s_add_u32 %[tmp], %[t], {ahead}")
+        if rot:
+            emit("s_add_u32 %[tmp2], %[tmp], %[kst]")
+            emit("s_cmp_eq_u32 %[tmp2], %[nk]")
+            emit("s_cselect_b32 %[inc], %[winc], 128")
+            if tmix:
+                emit("s_cselect_b64 %[m3], -1, 0")
         emit("s_cmp_lt_u32 %[tmp], %[nk]")
-        emit("s_cselect_b32 %[inc], 128, 0")
+        if rot:
+            emit("s_cselect_b32 %[inc], %[inc], 0")
+        else:
+            emit("s_cselect_b32 %[inc], 128, 0")
         if tmix:
-            # m1 / m2 = all ones when the offsets advance INTO segment 1 / 2 (global tile index kt0 + t + ahead == tps / 2 tps) and that tile exists
+            # m1 / m2 = all ones when the offsets advance INTO segment 1 / 2 (global tile index == tps / 2 tps), m3 at the wrap; only when
+            # that tile exists.  Global index of the next tile: kt0 + ((kst + index) mod nk)
             emit("s_cselect_b64 %[mv], -1, 0")
+            if rot:
+                emit("s_cselect_b32 %[inca], 128, 0")
+                emit("s_and_b64 %[m3], %[m3], %[mv]")
+                emit("s_cmp_ge_u32 %[tmp2], %[nk]")
+                emit("s_cselect_b32 %[tmp], %[nk], 0")
+                emit("s_sub_u32 %[tmp], %[tmp2], %[tmp]")
             emit("s_add_u32 %[tmp], %[tmp], %[kt0]")
             emit("s_cmp_eq_u32 %[tmp], %[tps]")
             emit("s_cselect_b64 %[m1], -1, 0")
@@ -119,6 +142,9 @@ def gen(FM, FN, NSTG, mfma_op, ablate="", deep=None, tmix=False, planes=1, base=
             emit("s_cmp_eq_u32 %[tmp], %[tps2]")
             emit("s_cselect_b64 %[m2], -1, 0")
             emit("s_and_b64 %[m2], %[m2], %[mv]")
+            if rot:          # a wrap that lands exactly on a segment boundary takes the wrap jump only
+                emit("s_andn2_b64 %[m1], %[m1], %[m3]")
+                emit("s_andn2_b64 %[m2], %[m2], %[m3]")
 
     # ---- prologue -----------------------------------------------------------------------------------------------------------------
     emit("s_nop 4")
@@ -128,6 +154,8 @@ def gen(FM, FN, NSTG, mfma_op, ablate="", deep=None, tmix=False, planes=1, base=
             emit(f"ds_read_b32 v{VA[i]}, %[va0] offset:{4 * i}")
             emit(f"ds_read_b32 v{D01[i]}, %[va0] offset:{4 * (NA + i)}")
             emit(f"ds_read_b32 v{D12[i]}, %[va0] offset:{4 * (2 * NA + i)}")
+            if rot:
+                emit(f"ds_read_b32 v{DW[i]}, %[va0] offset:{4 * (3 * NA + i)}")
         emit("s_waitcnt lgkmcnt(0)")
     else:
         emit(f"v_mov_b32 v{VA[0]}, %[va0]")
@@ -219,20 +247,23 @@ def gen(FM, FN, NSTG, mfma_op, ablate="", deep=None, tmix=False, planes=1, base=
             else:
                 emit(f"s_waitcnt lgkmcnt({nwr * P})")
 
-    gs_even = NSTG - 1          # staging set that holds tile t + 1 when t is even
-    tile(0, gs_even, True)                        # t = 0
+    # K tile t multiplies LDS stage t & 1 and refills staging set (t + 1) % NSTG: the loop body repeats every L = lcm(2, NSTG) tiles
+    import math
+    L = 2 * NSTG // math.gcd(2, NSTG)
+    tile(0, 1 % NSTG, True)                       # t = 0 (first MFMA of every accumulator takes C = 0)
     emit("s_add_u32 %[t], %[t], 1")
     emit("s_cmp_ge_u32 %[t], %[nk]")
     emit("s_cbranch_scc1 L_end_%=")
     emit("L_loop_%=:")
-    tile(1, 0, False)                             # odd t
-    emit("s_add_u32 %[t], %[t], 1")
-    emit("s_cmp_ge_u32 %[t], %[nk]")
-    emit("s_cbranch_scc1 L_end_%=")
-    tile(0, gs_even, False)                       # even t
-    emit("s_add_u32 %[t], %[t], 1")
-    emit("s_cmp_lt_u32 %[t], %[nk]")
-    emit("s_cbranch_scc1 L_loop_%=")
+    for u in range(1, L + 1):                     # t = u (mod L)
+        tile(u & 1, (u + 1) % NSTG, False)
+        emit("s_add_u32 %[t], %[t], 1")
+        if u < L:
+            emit("s_cmp_ge_u32 %[t], %[nk]")
+            emit("s_cbranch_scc1 L_end_%=")
+        else:
+            emit("s_cmp_lt_u32 %[t], %[nk]")
+            emit("s_cbranch_scc1 L_loop_%=")
     emit("L_end_%=:")
     emit("s_waitcnt vmcnt(0)")
     emit("s_nop 15")
@@ -241,52 +272,74 @@ def gen(FM, FN, NSTG, mfma_op, ablate="", deep=None, tmix=False, planes=1, base=
     name = f"g4_loop_{FM}x{FN}_s{NSTG}" + (f"_ab_{ablate}" if ablate else "") + ("_tmix" if tmix else "") + ("_x2" if P == 2 else "")
     nacc = FM * FN
     lines = []
-    lines.append(f"// {BM} x {BN} tile, {32 * FM} x {32 * FN} per wave, {NSTG} K tile(s) of global loads in flight, {P} plane(s); registers v{base} .. v{last}")
-    lines.append(f"__device__ __forceinline__ void {name}(f32x16 (&acc)[{FN}][{FM}], unsigned va0, unsigned vw0, unsigned wr0, unsigned rda0, unsigned rdw0,")
-    x2args = " u32x4 rsAr, u32x4 rsWr," if P == 2 else ""
+    lines.append(f"// {BM} x {BN} tile, {32 * FM} x {32 * FN} per wave, {NSTG} K tile(s) of global loads in flight, {P} plane(s)"
+                 f"{', temporal-mix A' if tmix else ''}{', rotated K walk' if rot else ''}; registers v{base} .. v{last}")
+    lines.append(f"__device__ __forceinline__ void {name}(f32x16 (&acc)[{FN}][{FM}], const G4Args& a) {{")
     if tmix:
-        lines.append(f"                                           u32x4 rsA, u32x4 rsW,{x2args} unsigned kt0, unsigned sw, unsigned nk, unsigned tps, unsigned tps2) {{")
-        lines.append("  unsigned long long m1, m2, mv;")
-    else:
-        lines.append(f"                                           u32x4 rsA, u32x4 rsW,{x2args} unsigned sa, unsigned sw, unsigned nk) {{")
-    lines.append("  unsigned t, tmp, inc;")
+        lines.append("  unsigned long long m1, m2, mv" + (", m3;" if rot else ";"))
+    lines.append("  unsigned t, tmp, inc" + (", tmp2" if rot else "") + (", inca;" if (rot and tmix) else ";"))
     lines.append("  asm volatile(")
     for ln in out:
         lines.append(f'      "{ln}\\n\\t"')
-    outs = ", ".join(f'[acc{a * FM + b}] "=&a"(acc[{a}][{b}])' for a in range(FN) for b in range(FM))
+    outs = ", ".join(f'[acc{x * FM + b}] "=&a"(acc[{x}][{b}])' for x in range(FN) for b in range(FM))
     lines.append(f"      : {outs},")
-    lines.append('        [t] "=&s"(t), [tmp] "=&s"(tmp), [inc] "=&s"(inc)' + (', [m1] "=&s"(m1), [m2] "=&s"(m2), [mv] "=&s"(mv)' if tmix else ""))
-    lines.append('      : [va0] "v"(va0), [vw0] "v"(vw0), [wr0] "v"(wr0), [rda0] "v"(rda0), [rdw0] "v"(rdw0), [rsA] "s"(rsA), [rsW] "s"(rsW),')
+    lines.append('        [t] "=&s"(t), [tmp] "=&s"(tmp), [inc] "=&s"(inc)' + (', [tmp2] "=&s"(tmp2)' if rot else "") + (', [inca] "=&s"(inca), [m3] "=&s"(m3)' if (rot and tmix) else "") +
+                 (', [m1] "=&s"(m1), [m2] "=&s"(m2), [mv] "=&s"(mv)' if tmix else ""))
+    lines.append('      : [va0] "v"(a.va0), [vw0] "v"(a.vw0), [wr0] "v"(a.wr0), [rda0] "v"(a.rda0), [rdw0] "v"(a.rdw0), [rsA] "s"(a.rsA), [rsW] "s"(a.rsW),')
     if P == 2:
-        lines.append('        [rsAr] "s"(rsAr), [rsWr] "s"(rsWr),')
+        lines.append('        [rsAr] "s"(a.rsAr), [rsWr] "s"(a.rsWr),')
+    if rot:
+        lines.append('        [kst] "s"(a.kst), [winc] "s"(a.winc),')
     if tmix:
-        lines.append('        [kt0] "s"(kt0), [sw] "s"(sw), [nk] "s"(nk), [tps] "s"(tps), [tps2] "s"(tps2)')
+        lines.append('        [kt0] "s"(a.kt0), [sw] "s"(a.sw), [nk] "s"(a.nk), [tps] "s"(a.tps), [tps2] "s"(a.tps2)')
     else:
-        lines.append('        [sa] "s"(sa), [sw] "s"(sw), [nk] "s"(nk)')
+        lines.append('        [sa] "s"(a.sa), [sw] "s"(a.sw), [nk] "s"(a.nk)')
     clob = ", ".join(f'"v{i}"' for i in range(base, last + 1))
     lines.append(f'      : "memory", "scc", {clob});')
     lines.append("}")
+    if not ablate:
+        lines.append(f"template <> struct G4Loop<{FM}, {FN}, {NSTG}, {'true' if tmix else 'false'}, {'true' if P == 2 else 'false'}> {{")
+        lines.append(f"  static constexpr bool rot = {'true' if rot else 'false'};      // takes a rotated K walk (G4Args::kst != 0)")
+        lines.append(f"  static __device__ __forceinline__ void run(f32x16 (&acc)[{FN}][{FM}], const G4Args& a) {{ {name}(acc, a); }}")
+        lines.append("};")
     lines.append("")
-    assert nacc + 3 + 10 + (5 if tmix else 0) + (2 if P == 2 else 0) <= 30
+    nops = nacc + 3 + 10 + (5 if tmix else 0) + (2 if P == 2 else 0) + ((3 + (2 if tmix else 0)) if rot else 0)
+    assert nops <= 30, (FM, FN, P, tmix, nops)
     return "\n".join(lines), name
 
 
 def main():
     print("// GENERATED by tools/gen_gemm4_loops.py — do not edit; see csrc/gemm4.hip for the schedule.")
     print("// clang-format off")
+    print("""// Arguments of a loop (all wave-uniform except the five per-lane addresses): byte offsets of this thread's first A / W vector in the
+// first K tile it loads (tmix: LDS address of its per-vector table instead of va0), LDS addresses of its vector slot / fragment rows,
+// buffer descriptors (rsAr / rsWr: the rest planes, split precision), kst = first K tile of the walk inside the slice and
+// winc = 128 - 128 nk (the wrap), sa / sw = byte distance between this thread's consecutive vectors (32 rows), nk = K tiles of the slice,
+// tmix: kt0 = first K tile of the slice, tps / tps2 = K tiles per segment / twice that.
+struct G4Args {
+  unsigned va0, vw0, wr0, rda0, rdw0;
+  u32x4 rsA, rsW, rsAr, rsWr;
+  unsigned kst, winc, sa, sw, nk, kt0, tps, tps2;
+};
+template <int FM, int FN, int NS, bool TMIX, bool X2> struct G4Loop;
+""")
 
     def put(*a, **k):
         txt, _ = gen(*a, "AVSD_MFMA_OP_PLACEHOLDER", **k)
         print(txt.replace('"AVSD_MFMA_OP_PLACEHOLDER ', 'AVSD_MFMA_OP " '))
 
     for FM, FN in ((4, 4), (4, 2), (2, 4), (2, 2), (2, 1), (1, 2), (1, 1)):
-        put(FM, FN, 2)
+        put(FM, FN, 2, rot=(FM * FN < 16))
     for FM, FN in ((4, 2), (2, 4), (2, 2), (2, 1), (1, 2), (1, 1)):
-        put(FM, FN, 2, tmix=True, deep=(FM * FN <= 4))
+        put(FM, FN, 2, tmix=True, deep=(FM * FN <= 4), rot=(FM * FN <= 4))
+    # four K tiles in flight for the small tiles: the low-resolution layers stream their weights from HBM (cold inside a denoising step)
+    for FM, FN in ((2, 1), (1, 2), (1, 1)):
+        put(FM, FN, 4)
+        put(FM, FN, 4, tmix=True)
     # split precision (two planes per operand, three MFMA passes)
     for FM, FN in ((2, 2), (2, 1), (1, 2), (1, 1)):
         put(FM, FN, 2, planes=2)
-        put(FM, FN, 2, planes=2, tmix=True, base=(28 if (FM, FN) == (2, 2) else 32))
+        put(FM, FN, 2, planes=2, tmix=True, base=(28 if (FM, FN) == (2, 2) else 32), rot=((FM, FN) == (1, 1)))
     if "--ablate" in sys.argv:
         print("#define AVSD_G4_ABLATE 1")
         for ab in ("g", "w", "r", "gw", "gwr", "b", "gwrb"):

@@ -102,7 +102,13 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void conv3r_kernel(const avsd_
   const int per_split = (nchunks + nsplit - 1) / nsplit;
   const int c0 = ksplit * per_split;
   const int c1 = min(nchunks, c0 + per_split);
-  const int nk = max(c1 - c0, 0) * 9;
+  const int nch = max(c1 - c0, 0);
+  const int nk = nch * 9;
+  // Rotated chunk walk (AVSD_GEMM_KROT, see gemm4.hip): row bands that share a column band of W start at different channel chunks of
+  // the slice and wrap, so the cold weight stream is requested in parallel instead of as one chain of HBM round trips.  The walk is
+  // indexed by q = 0 .. nch - 1 (the A double buffer alternates on q), the chunk it stands for is chunk_of(q).
+  const int crot = ((p.flags & AVSD_GEMM_KROT) && nch > 1 && ntm > 1) ? (int)(((long long)tm * nch) / ntm) : 0;
+  auto chunk_of = [&](int q) { const int c = q + crot; return c0 + (c >= nch ? c - nch : c); };
 
   const h16_t* Ab = reinterpret_cast<const h16_t*>(p.A);
   const h16_t* Wb = reinterpret_cast<const h16_t*>(p.W);
@@ -133,8 +139,9 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void conv3r_kernel(const avsd_
     wv[j] = n < p.N;
     wo[j] = n * p.ldw + (x & 7) * 8;
   }
-  auto issue_a = [&](int chunk) {
-    unsigned char* ab = smemr + (chunk & 1) * A_BYTES;
+  auto issue_a = [&](int q) {
+    unsigned char* ab = smemr + (q & 1) * A_BYTES;
+    const int chunk = chunk_of(q);
     const bool first = chunk < csplit;
     const int ld = first ? p.lda : p.lda2;
     const int coff = a_ch8 + (first ? chunk : chunk - csplit) * 64;
@@ -148,17 +155,17 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void conv3r_kernel(const avsd_
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, dst, 16, (int)vo, 0, 0, 0);
     }
   };
-  int i_t = 0, i_chunk = c0, i_tap = 0;       // next W tile to issue
+  int i_t = 0, i_q = 0, i_tap = 0;            // next W tile to issue
   auto issue_w = [&]() {
     unsigned char* sb = smemr + 2 * A_BYTES + (i_t % STAGES) * W_BYTES;
-    const int kbase = i_tap * p.cin + i_chunk * 64;
+    const int kbase = i_tap * p.cin + chunk_of(i_q) * 64;
 #pragma unroll
     for (int j = 0; j < PW; ++j) {
       const unsigned vo = wv[j] ? (unsigned)(wo[j] + kbase) * 2u : OOBR;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(sb + (wave + j * NWAVES) * 1024), 16, (int)vo, 0, 0, 0);
     }
     ++i_t;
-    if (++i_tap == 9) { i_tap = 0; ++i_chunk; }
+    if (++i_tap == 9) { i_tap = 0; ++i_q; }
   };
   // loads that may stay in flight behind W tile kt: the W tiles of iterations kt-STAGES+2 .. kt-1 and the A chunk one of
   // them issued (an iteration j >= 0 with tap(j) == 0 and a chunk after its own)
@@ -168,25 +175,25 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void conv3r_kernel(const avsd_
 #pragma unroll
     for (int d = 1; d <= STAGES - 2; ++d) {
       const int j = kt - d;
-      if (j >= 0 && j % 9 == 0 && c0 + j / 9 + 1 < c1) a = true;
+      if (j >= 0 && j % 9 == 0 && j / 9 + 1 < nch) a = true;
     }
     wait_ring<STAGES - 2, PW, PAC>(nw, a);
   };
 
   if (is_loader && nk > 0) {
-    issue_a(c0);
+    issue_a(0);
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
       if (s < nk) issue_w();
   }
   if (LW > 0 && is_loader) {
-    int tap = 0, chunk = c0;
+    int tap = 0, q = 0;
     for (int kt = 0; kt < nk; ++kt) {
       wait_tile(kt);
       __builtin_amdgcn_s_barrier();
-      if (tap == 0 && chunk + 1 < c1) issue_a(chunk + 1);
+      if (tap == 0 && q + 1 < nch) issue_a(q + 1);
       if (kt + STAGES - 1 < nk) issue_w();
-      if (++tap == 9) { tap = 0; ++chunk; }
+      if (++tap == 9) { tap = 0; ++q; }
     }
     return;
   }
@@ -233,17 +240,17 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void conv3r_kernel(const avsd_
   }
   const int chalf = lane >> 5;
 
-  int tap = 0, kh = 0, kw = 0, chunk = c0;
+  int tap = 0, kh = 0, kw = 0, q = 0;
   for (int kt = 0; kt < nk; ++kt) {
     if (LW == 0) wait_tile(kt);
     __builtin_amdgcn_s_barrier();
     if (LW == 0) {
-      if (tap == 0 && chunk + 1 < c1) issue_a(chunk + 1);
+      if (tap == 0 && q + 1 < nch) issue_a(q + 1);
       if (kt + STAGES - 1 < nk) issue_w();
     }
     // this tap's fragment rows: staged row i = r + kh * ws + kw - 1
     const int shift = kh * ws + kw - 1;
-    const int abuf = (chunk & 1) * A_BYTES;
+    const int abuf = (q & 1) * A_BYTES;
     int xa_base[FM], xa_sw[FM];
 #pragma unroll
     for (int b = 0; b < FM; ++b) {
@@ -273,7 +280,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void conv3r_kernel(const avsd_
     }
     ++tap;
     if (++kw == 3) { kw = 0; ++kh; }
-    if (tap == 9) { tap = 0; kh = 0; kw = 0; ++chunk; }
+    if (tap == 9) { tap = 0; kh = 0; kw = 0; ++q; }
   }
 
   if (p.split_k > 1) {

@@ -394,22 +394,31 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm2_kernel(const avsd_g
   // Fast path needs every K tile inside one tap / segment (cin % 64 == 0, cseg % 64 == 0).
   const bool fast = (MODE == AVSD_GEMM_PLAIN) || (MODE == AVSD_GEMM_TMIX && p.cseg % BK == 0) ||
                     (MODE == AVSD_GEMM_CONV3 && p.cin % BK == 0);
-  int i_kbase = kt0 * BK;   // first k of the tile
+  // Rotated K walk (AVSD_GEMM_KROT, see gemm4.hip): row bands (tm) that share a column band of W start at different K tiles of
+  // the slice and wrap — the weights of the low-resolution layers stream from HBM inside a step, and a lockstep walk is one chain
+  // of round trips.  Deterministic; only the f32 summation order of a band rotates.
+  const int nk_slice = max(kt1 - kt0, 0);
+  const int krot = ((p.flags & AVSD_GEMM_KROT) && nk_slice > 1 && ntm > 1) ? (int)(((long long)tm * nk_slice) / ntm) : 0;
+  int i_kbase = 0;          // first k of the tile
   int i_c0 = 0;             // PLAIN: = kbase; CONV3: channel offset inside the tap; TMIX: offset inside the segment
   int i_kh = 0, i_kw = 0, i_seg = 0;
   bool i_second = false;
-  if (MODE == AVSD_GEMM_PLAIN) {
-    i_c0 = i_kbase;
-    i_second = p.A2 != nullptr && i_kbase >= p.k_split;
-  } else if (MODE == AVSD_GEMM_TMIX) {
-    i_seg = i_kbase / p.cseg;
-    i_c0 = i_kbase - i_seg * p.cseg;
-  } else {
-    const int tap = i_kbase / p.cin;
-    i_c0 = i_kbase - tap * p.cin;
-    i_kh = tap / 3;
-    i_kw = tap - i_kh * 3;
-  }
+  auto seek = [&](int kbase) {            // decode state of the tile that starts at element `kbase` of K
+    i_kbase = kbase;
+    if (MODE == AVSD_GEMM_PLAIN) {
+      i_c0 = i_kbase;
+      i_second = p.A2 != nullptr && i_kbase >= p.k_split;
+    } else if (MODE == AVSD_GEMM_TMIX) {
+      i_seg = i_kbase / p.cseg;
+      i_c0 = i_kbase - i_seg * p.cseg;
+    } else {
+      const int tap = i_kbase / p.cin;
+      i_c0 = i_kbase - tap * p.cin;
+      i_kh = tap / 3;
+      i_kw = tap - i_kh * 3;
+    }
+  };
+  seek((kt0 + krot) * BK);
   const int hin = p.hs << p.ups, win = p.ws << p.ups;
   int abase[PA];
   bool aok[PA];
@@ -467,8 +476,12 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm2_kernel(const avsd_g
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsWr, dr, 16, (int)vo, 0, 0, 0);
       }
     }
-    // advance the decode state to the next K tile
+    // advance the decode state to the next K tile (rotated walk: from the last tile of the slice back to its first)
     i_kbase += BK;
+    if (krot != 0 && i_kbase >= kt1 * BK) {
+      seek(kt0 * BK);
+      rebase();
+    } else
     if (MODE == AVSD_GEMM_PLAIN) {
       i_c0 = i_kbase;
       if (!i_second && i_kbase >= p.k_split && i_kbase < p.K) { i_second = true; rebase(); }

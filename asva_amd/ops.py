@@ -119,10 +119,15 @@ ASM_TILES = tuple(range(60, 70))
 ASM_X2_CANDIDATES = ((63, 1), (64, 1), (65, 1), (66, 1))        # split precision: 128x128 ... 64x64
 ASM_X2_SPLITK_CANDIDATES = ((63, 2), (63, 4), (64, 2), (64, 4), (65, 2), (65, 4), (66, 2), (66, 4), (66, 8))
 _ASM_TILES = os.environ.get("AVSD_ASM_TILES", "1") != "0"
-# asm tiles: row bands start their K walk at different tiles (AVSD_GEMM_KROT, include/avsd.h) — the weights of the low-resolution layers
-# come from HBM inside a step, and a lockstep walk is one chain of round trips.  AVSD_KROT=0 / set_krot(False): the unrotated walk
-# (bit-identical to the LDS-direct tiles).
+# Row bands start their K walk at different tiles (AVSD_GEMM_KROT, include/avsd.h; LDS-direct, resident-convolution and asm tiles) — the
+# weights of the low-resolution layers come from HBM inside a step, and a lockstep walk is one chain of round trips.
+# AVSD_KROT=0 / set_krot(False): the unrotated walk (every tile of a family then sums K in the same order).
 _KROT = os.environ.get("AVSD_KROT", "1") != "0"
+_KROT_ASM_ONLY = os.environ.get("AVSD_KROT", "1") == "2"          # probe: rotate the asm tiles only
+# ... and only where the weights one XCD walks (its share of W under the column banding) stay in its 4-MB L2 for a whole rotation: bands
+# that stand at different K positions re-read W a rotation apart, so a larger W (the 3x3 convolutions at 8 x 8: 29 MB) would come from
+# the Infinity Cache once per band instead of once (measured: rotating everything 80.9 steps/s, this rule 81.8, nothing 80.0)
+_KROT_MAX_W = int(os.environ.get("AVSD_KROT_MAXW", str(16 << 20)))
 
 
 def set_krot(on: bool) -> None:
@@ -317,6 +322,7 @@ def _time_cold(launch, cand, warm, reps=7):
 
 _CHALLENGE = os.environ.get("AVSD_TUNE_CHALLENGE", "0") == "1"     # tools/tune_tiles.py --challenge: re-time table entries against new tiles
 _CHALLENGED: set = set()
+RECORD_KEYS = None
 CHALLENGE_LOG: list = []
 
 
@@ -571,7 +577,8 @@ def gemm(
     def _set(t, sk):
         nonlocal ws
         d.tile, d.split_k = t, sk
-        d.flags = (d.flags | KROT) if (_KROT and t in ASM_TILES) else (d.flags & ~KROT)       # (after the table key was formed: not part of it)
+        krot = _KROT and (t in ASM_TILES or not _KROT_ASM_ONLY) and 2 * N * K <= _KROT_MAX_W
+        d.flags = (d.flags | KROT) if krot else (d.flags & ~KROT)          # (set after the table key was formed: not part of it)
         if sk > 1:
             if ws is None or ws.numel() < sk * M * N:
                 ws = torch.empty((sk * M * N,), dtype=F32, device=a.device)
@@ -607,6 +614,9 @@ def gemm(
             asm = ASM_X2_CANDIDATES if P.SPLIT else tuple(c for c in ASM_CANDIDATES if mode == PLAIN or c[0] != 60)
             if splitk_ok and ((M + 127) // 128) * ((N + 127) // 128) < 256 and nk >= 8:
                 asm = asm + tuple(c for c in (ASM_X2_SPLITK_CANDIDATES if P.SPLIT else ASM_SPLITK_CANDIDATES) if nk // c[1] >= 4)
+        if RECORD_KEYS is not None:          # tools/tune_in_step.py: which table keys a forward uses, how often, and what could run them
+            rec = RECORD_KEYS.setdefault(key, {"n": 0, "cands": tuple(dict.fromkeys(tuple(cands) + tuple(asm))), "flops": 2.0 * M * N * K})
+            rec["n"] += 1
         picked = _pick_tile(key, _launch, cands, warm=(a, a2, res1, res2), challengers=asm)
         if picked is not None and picked[0] in ASM_TILES and not asm:        # (a two-source call shares the key of the one-source shape)
             picked = None

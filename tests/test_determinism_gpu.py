@@ -34,16 +34,21 @@ print("HASH", h(out), h(frames))
 """
 
 
-def _run():
+def _spawn():
     env = dict(os.environ)
     env.pop("AVSD_AUTOTUNE", None)
-    r = subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT)], capture_output=True, text=True, env=env, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][-1]
+    return subprocess.Popen([sys.executable, "-c", CHILD.format(root=ROOT)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+
+
+def _collect(proc):
+    out, err = proc.communicate(timeout=900)
+    assert proc.returncode == 0, err[-2000:]
+    line = [ln for ln in out.splitlines() if ln.startswith("HASH")][-1]
     return line.split()[1:]
 
 
 def test_two_processes_give_bit_identical_outputs():
-    a, b = _run(), _run()
+    pa, pb = _spawn(), _spawn()          # side by side (each spends most of its time filling 1.17 B parameters on the host)
+    a, b = _collect(pa), _collect(pb)
     print("UNet output sha256", a[0][:16], "| VAE frames sha256", a[1][:16])
     assert a == b

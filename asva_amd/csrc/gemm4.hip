@@ -55,7 +55,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // X2 (AVSD_GEMM_X2, split precision): every operand a (main, rest) pair of planes — an LDS stage holds [A | W | A rest | W rest], the rest
 // planes come through second buffer descriptors with the same offsets, every fragment pair takes three MFMAs (Wr.A, W.Ar, W.A).
-// NS = K tiles of global loads in flight per workgroup (staging register sets): 2, or 4 for the small tiles of the weight-streaming layers
+// NS = K tiles of global loads in flight per workgroup (staging register sets of the generated loop): 2 in every shipped tile
 template <int FM, int FN, int MODE, bool X2 = false, int NS = 2>
 __global__ __launch_bounds__(256, 1) void gemm4_kernel(const avsd_gemm_desc p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem4[];
@@ -268,10 +268,7 @@ int avsd_gemm_dispatch_asm(const avsd_gemm_desc& d, hipStream_t s) {
       case 4: return launch4<2, 1, AVSD_GEMM_TMIX>(d, s);
       case 5: return launch4<1, 2, AVSD_GEMM_TMIX>(d, s);
       case 6: return launch4<1, 1, AVSD_GEMM_TMIX>(d, s);
-      case 7: return launch4<2, 1, AVSD_GEMM_TMIX, false, 4>(d, s);
-      case 8: return launch4<1, 2, AVSD_GEMM_TMIX, false, 4>(d, s);
-      case 9: return launch4<1, 1, AVSD_GEMM_TMIX, false, 4>(d, s);
-      default: AVSD_REQUIRE(false, "gemm/asm tiles: tile %d has no TMIX form (61..69 do)", d.tile);
+      default: AVSD_REQUIRE(false, "gemm/asm tiles: tile %d has no TMIX form (61..66 do)", d.tile);
     }
   }
   switch (k) {
@@ -282,9 +279,6 @@ int avsd_gemm_dispatch_asm(const avsd_gemm_desc& d, hipStream_t s) {
     case 4: return launch4<2, 1, AVSD_GEMM_PLAIN>(d, s);     // 128 x 64, 54 KB
     case 5: return launch4<1, 2, AVSD_GEMM_PLAIN>(d, s);     // 64 x 128
     case 6: return launch4<1, 1, AVSD_GEMM_PLAIN>(d, s);     // 64 x 64, 36 KB: four workgroups per CU
-    case 7: return launch4<2, 1, AVSD_GEMM_PLAIN, false, 4>(d, s);     // the three small tiles with FOUR K tiles in flight
-    case 8: return launch4<1, 2, AVSD_GEMM_PLAIN, false, 4>(d, s);
-    case 9: return launch4<1, 1, AVSD_GEMM_PLAIN, false, 4>(d, s);
     default: AVSD_REQUIRE(false, "gemm/asm tiles: unknown tile %d", d.tile);
   }
 }

@@ -113,9 +113,9 @@ X2_SPLITK_CANDIDATES = ((34, 2), (34, 4), (35, 2), (35, 4), (36, 2), (36, 4), (7
 # (avsd_gemm_conv3r_supported); split_k cuts the cin / 64 channel chunks
 # 4-wave tiles with a hand-scheduled main loop (csrc/gemm4.hip): 60 = 256x256, 61 = 256x128, 62 = 128x256, 63 = 128x128; PLAIN, K % 64 == 0
 # 64 = 128x64, 65 = 64x128, 66 = 64x64; TMIX (cseg % 64 == 0): 61..66
-ASM_CANDIDATES = ((60, 1), (61, 1), (62, 1), (63, 1), (64, 1), (65, 1), (66, 1), (67, 1), (68, 1), (69, 1))
-ASM_SPLITK_CANDIDATES = ((63, 2), (63, 4), (63, 8), (61, 2), (62, 2), (62, 4), (64, 2), (64, 4), (65, 2), (65, 4), (66, 2), (66, 4), (67, 2), (68, 2), (69, 2), (69, 4))
-ASM_TILES = tuple(range(60, 70))
+ASM_CANDIDATES = ((60, 1), (61, 1), (62, 1), (63, 1), (64, 1), (65, 1), (66, 1))
+ASM_SPLITK_CANDIDATES = ((63, 2), (63, 4), (63, 8), (61, 2), (62, 2), (62, 4), (64, 2), (64, 4), (65, 2), (65, 4), (66, 2), (66, 4))
+ASM_TILES = tuple(range(60, 67))
 ASM_X2_CANDIDATES = ((63, 1), (64, 1), (65, 1), (66, 1))        # split precision: 128x128 ... 64x64
 ASM_X2_SPLITK_CANDIDATES = ((63, 2), (63, 4), (64, 2), (64, 4), (65, 2), (65, 4), (66, 2), (66, 4), (66, 8))
 _ASM_TILES = os.environ.get("AVSD_ASM_TILES", "1") != "0"

@@ -332,10 +332,8 @@ template <int FM, int FN, int NS, bool TMIX, bool X2> struct G4Loop;
         put(FM, FN, 2, rot=(FM * FN < 16))
     for FM, FN in ((4, 2), (2, 4), (2, 2), (2, 1), (1, 2), (1, 1)):
         put(FM, FN, 2, tmix=True, deep=(FM * FN <= 4), rot=(FM * FN <= 4))
-    # four K tiles in flight for the small tiles: the low-resolution layers stream their weights from HBM (cold inside a denoising step)
-    for FM, FN in ((2, 1), (1, 2), (1, 1)):
-        put(FM, FN, 4)
-        put(FM, FN, 4, tmix=True)
+    # (NSTG = 4, four K tiles of global loads in flight, was built for the three small tiles as ids 67-69: no shape of the
+    #  tuned table chose it over NSTG = 2 once the K walk was rotated, so the variants are not emitted; gen() still takes NSTG)
     # split precision (two planes per operand, three MFMA passes)
     for FM, FN in ((2, 2), (2, 1), (1, 2), (1, 1)):
         put(FM, FN, 2, planes=2)

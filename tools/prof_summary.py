@@ -15,7 +15,7 @@ def short(name: str) -> str:
     if m:
         bm, bn, wm, wn, st, lw, gn = m.groups()
         return f"conv3r<{bm}x{bn},{wm}x{wn}w{'+' + lw + 'L' if lw != '0' else ''},{st}st{',gn' if gn in ('true', '1') else ''}>"
-    m = re.search(r"gemm4_kernel<(\d+), (\d+), (\d+)(?:, (\w+))?>", name)
+    m = re.search(r"gemm4_kernel<(\d+), (\d+), (\d+)(?:, (\w+))?(?:, \d+)?>", name)
     if m:
         fm, fn, mode, x2 = m.groups()
         return f"gemm4<{64 * int(fm)}x{64 * int(fn)},asm,{('plain','tmix','conv3')[int(mode)]}{',x2' if x2 in ('true', '1') else ''}>"

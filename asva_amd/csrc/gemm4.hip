@@ -53,6 +53,20 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
+// The loop leaves the accumulators in AGPRs ("=&a" outputs).  Read through the compiler, all of them are copied to VGPRs right behind
+// the loop (the value's register class is decided at its definition), which the 256 x 256 tile cannot hold: 100-132 registers went to
+// scratch, 25 us per tile.  Read through this instead, a fragment leaves the AGPRs where the epilogue consumes it.
+__device__ __forceinline__ f32x16 from_agpr(const f32x16& a) {
+  f32x16 v;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float f;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(f) : "a"(a[r]));
+    v[r] = f;
+  }
+  return v;
+}
+
 // X2 (AVSD_GEMM_X2, split precision): every operand a (main, rest) pair of planes — an LDS stage holds [A | W | A rest | W rest], the rest
 // planes come through second buffer descriptors with the same offsets, every fragment pair takes three MFMAs (Wr.A, W.Ar, W.A).
 // NS = K tiles of global loads in flight per workgroup (staging register sets of the generated loop): 2 in every shipped tile
@@ -165,15 +179,10 @@ __global__ __launch_bounds__(256, 1) void gemm4_kernel(const avsd_gemm_desc p) {
     ga.va0 = (unsigned)(STAGE + tid * (4 * NA) * 4);
     ga.tps = (unsigned)tps; ga.tps2 = 2u * (unsigned)tps;
   }
-  if (nk > 0) Loop::run(acc, ga);
-  if (nk <= 0) {
-#pragma unroll
-    for (int a = 0; a < FN; ++a)
-#pragma unroll
-      for (int b = 0; b < FM; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  }
+  // every K slice holds at least one tile (avsd_gemm_dispatch_asm refuses a split that leaves an empty slice): the accumulators
+  // are ONLY the loop's AGPR outputs — a zero-filled alternative merges with them in VGPRs, all FM * FN * 16 copied at the join
+  // (the 256 x 256 tile spilled 132 of them to scratch: 25 us per tile in front of its epilogue)
+  Loop::run(acc, ga);
 
   const int m_base = tm * BM + wm * 32 * FM, n_base = tn * BN + wn * 32 * FN;
   if (p.split_k > 1) {
@@ -184,14 +193,15 @@ __global__ __launch_bounds__(256, 1) void gemm4_kernel(const avsd_gemm_desc p) {
       const int m = m_base + b * 32 + (lane & 31);
       if (m >= p.M) continue;
 #pragma unroll
-      for (int a = 0; a < FN; ++a)
+      for (int a = 0; a < FN; ++a) {
+        const f32x16 v = from_agpr(acc[a][b]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int n = n_base + a * 32 + 8 * q + hsel;
           if (n < p.N)
-            *reinterpret_cast<float4*>(ws + (int64_t)m * p.N + n) =
-                make_float4(acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]);
+            *reinterpret_cast<float4*>(ws + (int64_t)m * p.N + n) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
         }
+      }
     }
     return;
   }
@@ -199,9 +209,12 @@ __global__ __launch_bounds__(256, 1) void gemm4_kernel(const avsd_gemm_desc p) {
   // go through scratch memory); a band of FN <= 4 fragments takes the term-at-a-time form with batched operand loads
   static_for<FM>([&p, &acc, &ln_raw, ln_pre, m_base, n_base, lane](auto b_c) {
     constexpr int B = decltype(b_c)::value;
+    // bands are independent, and with 512 registers per lane the scheduler would interleave them (all FM * FN * 16 accumulators
+    // copied out of the AGPRs up front: 132 spilled registers in the 256 x 256 tile); keep each band's instructions together
+    __builtin_amdgcn_sched_barrier(0);
     f32x16 band[FN][1];
 #pragma unroll
-    for (int a = 0; a < FN; ++a) band[a][0] = acc[a][B];
+    for (int a = 0; a < FN; ++a) band[a][0] = from_agpr(acc[a][B]);
     float pre_ln[2] = {1.f, 0.f};
     if (ln_pre) {          // same arithmetic as ln_row_stats (gemm_common.h) on one pair
       float sm = ln_raw[B].x, sq = ln_raw[B].y;
@@ -247,6 +260,10 @@ int avsd_gemm_dispatch_asm(const avsd_gemm_desc& d, hipStream_t s) {
                "gemm/asm tiles: PLAIN single-source or TMIX operands with K %% 64 == 0 (got mode %d, K %d)", d.mode, d.K);
   AVSD_REQUIRE((double)d.M * d.lda * 2.0 < 1073741824.0 && (double)d.N * d.ldw * 2.0 < 1073741824.0, "gemm/asm tiles: operands must be < 1 GiB");
   AVSD_REQUIRE(d.split_k <= 1 || (d.splitk_ws && d.split_k <= d.K / 64 && !(d.flags & AVSD_GEMM_GEGLU)), "gemm/asm tiles: bad split_k %d", d.split_k);
+  if (d.split_k > 1) {
+    const int nk_all = d.K / 64, per = (nk_all + d.split_k - 1) / d.split_k;
+    AVSD_REQUIRE((d.split_k - 1) * per < nk_all, "gemm/asm tiles: split_k %d leaves an empty slice of the %d K tiles", d.split_k, nk_all);
+  }
   const int k = d.tile - AVSD_GEMM_TILE_ASM_FIRST;
   const bool tmix = d.mode == AVSD_GEMM_TMIX;
   if (tmix) AVSD_REQUIRE(d.cseg % 64 == 0 && !(d.flags & AVSD_GEMM_LNFUSE), "gemm/asm tiles: TMIX needs cseg %% 64 == 0 (got %d)", d.cseg);

@@ -613,7 +613,8 @@ def gemm(
                 (mode == PLAIN or (mode == TMIX and d.cseg % 64 == 0 and ln is None))):
             asm = ASM_X2_CANDIDATES if P.SPLIT else tuple(c for c in ASM_CANDIDATES if mode == PLAIN or c[0] != 60)
             if splitk_ok and ((M + 127) // 128) * ((N + 127) // 128) < 256 and nk >= 8:
-                asm = asm + tuple(c for c in (ASM_X2_SPLITK_CANDIDATES if P.SPLIT else ASM_SPLITK_CANDIDATES) if nk // c[1] >= 4)
+                asm = asm + tuple(c for c in (ASM_X2_SPLITK_CANDIDATES if P.SPLIT else ASM_SPLITK_CANDIDATES)
+                                  if nk // c[1] >= 4 and (c[1] - 1) * -(-nk // c[1]) < nk)      # (no empty K slice: the asm tiles refuse it)
         if RECORD_KEYS is not None:          # tools/tune_in_step.py: which table keys a forward uses, how often, and what could run them
             rec = RECORD_KEYS.setdefault(key, {"n": 0, "cands": tuple(dict.fromkeys(tuple(cands) + tuple(asm))), "flops": 2.0 * M * N * K})
             rec["n"] += 1

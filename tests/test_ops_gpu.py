@@ -840,7 +840,12 @@ def test_gemm_asm_tiles_rotated_k_walk(ops, tile):
             prev = torch.cat([y5[:, :1], y5[:, :-1]], 1)
             ref = torch.cat([y5[:, :1].expand_as(y5), prev, y5], -1).reshape(M, 3 * C) @ w.float().T + b
             for sk in (1, 2, 3, 4):
-                if (3 * C // 64) // sk < 2:
+                nk = 3 * C // 64
+                if nk // sk < 2:
+                    continue
+                if (sk - 1) * -(-nk // sk) >= nk:        # a slice without K tiles: refused, not zero-filled
+                    with pytest.raises(RuntimeError, match="empty slice"):
+                        ops.gemm(y, w, bias=b, out_f32=True, mode=ops.TMIX, tmix=(hw, Fr), tile=tile, split_k=sk)
                     continue
                 o = ops.gemm(y, w, bias=b, out_f32=True, mode=ops.TMIX, tmix=(hw, Fr), tile=tile, split_k=sk)
                 assert rel_l2(o, ref) < TOL_F32, (B, hw, C, N, sk)

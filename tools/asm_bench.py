@@ -88,8 +88,9 @@ if "--x2" in sys.argv:
         print("  ".join(row), flush=True)
     sys.exit(0)
 
-# ---- parity: same products, same K order -> bit-identical to the LDS-direct tile 9
+# ---- parity: same products, same K order (rotated K walk off) -> bit-identical to the LDS-direct tile 9
 bad = 0
+ops.set_krot(False)
 for M, N, K in [(256, 256, 64), (256, 256, 128), (512, 384, 320), (1000, 640, 1280), (77, 132, 192), (2048, 1280, 768), (3000, 320, 640)]:
     a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
     bias, res = torch.randn(N, generator=g).to(dev), rnd(M, N)
@@ -132,6 +133,7 @@ for B, hw, C, N in [(2, 64, 320, 320), (1, 32, 128, 132), (3, 96, 64, 64), (2, 3
             if not ok:
                 print(f"tmix parity B={B} hw={hw} C={C} N={N} tile {t} split {sk}: DIFFERS rel {((o - r).norm() / r.norm()).item():.3e}", flush=True)
 print("PARITY", "OK" if bad == 0 else f"FAILED ({bad})", flush=True)
+ops.set_krot(True)
 if "--tmix" in sys.argv:
     for B, hw, C, N in [(2, 64, 1280, 1280), (2, 16, 1280, 1280), (2, 256, 640, 640), (2, 1024, 320, 320), (2, 1024, 640, 640), (2, 256, 1280, 1280)]:
         Fr = 12

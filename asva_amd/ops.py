@@ -18,7 +18,7 @@ from ._lib import GemmDesc, XAttnDesc, check
 
 PLAIN, TMIX, CONV3 = 0, 1, 2
 GEGLU, OUT_F32, GELU, XCD_N, ROWSTATS, LNFUSE, RES1_F32, RES2_F32, X2, KROT = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
-_XCD_MODE = os.environ.get("AVSD_XCD_MODE", "auto")     # auto | m | n  (which operand each XCD's L2 fetches once)
+_XCD_MODE = "auto"     # auto | m | n  (which operand each XCD's L2 fetches once)
 F32 = torch.float32      # (16-bit storage dtype: P.ACT, asva_amd/precision.py)
 
 
@@ -118,16 +118,16 @@ ASM_SPLITK_CANDIDATES = ((63, 2), (63, 4), (63, 8), (61, 2), (62, 2), (62, 4), (
 ASM_TILES = tuple(range(60, 67))
 ASM_X2_CANDIDATES = ((63, 1), (64, 1), (65, 1), (66, 1))        # split precision: 128x128 ... 64x64
 ASM_X2_SPLITK_CANDIDATES = ((63, 2), (63, 4), (64, 2), (64, 4), (65, 2), (65, 4), (66, 2), (66, 4), (66, 8))
-_ASM_TILES = os.environ.get("AVSD_ASM_TILES", "1") != "0"
+_ASM_TILES = True          # (module attribute: tools set it to False to time the LDS-direct tiles alone)
 # Row bands start their K walk at different tiles (AVSD_GEMM_KROT, include/avsd.h; LDS-direct, resident-convolution and asm tiles) — the
 # weights of the low-resolution layers come from HBM inside a step, and a lockstep walk is one chain of round trips.
 # AVSD_KROT=0 / set_krot(False): the unrotated walk (every tile of a family then sums K in the same order).
 _KROT = os.environ.get("AVSD_KROT", "1") != "0"
-_KROT_ASM_ONLY = os.environ.get("AVSD_KROT", "1") == "2"          # probe: rotate the asm tiles only
+_KROT_ASM_ONLY = False          # probe (profiles/r4_krot_ab.txt): rotate the asm tiles only
 # ... and only where the weights one XCD walks (its share of W under the column banding) stay in its 4-MB L2 for a whole rotation: bands
 # that stand at different K positions re-read W a rotation apart, so a larger W (the 3x3 convolutions at 8 x 8: 29 MB) would come from
 # the Infinity Cache once per band instead of once (measured: rotating everything 80.9 steps/s, this rule 81.8, nothing 80.0)
-_KROT_MAX_W = int(os.environ.get("AVSD_KROT_MAXW", str(16 << 20)))
+_KROT_MAX_W = 16 << 20
 
 
 def set_krot(on: bool) -> None:
@@ -135,12 +135,12 @@ def set_krot(on: bool) -> None:
     _KROT = bool(on)
 
 
-_RASTER_G = int(os.environ.get("AVSD_RASTER_G", "0"))       # probe knob: rows of the tile blocks an XCD walks (0 = the kernel's default)
+_RASTER_G = 0       # probe knob: rows of the tile blocks an XCD walks (0 = the kernel's default)
 CONV3R_TILES = (40, 42, 43, 44, 48)
 CONV3R2D_TILES = (51, 52, 53, 54)   # rectangular resident tiles (TH rows x 32 pixels) for images wider than 32 pixels: the VAE decoder, cfg 4
 _CONV3R2D_BN = {51: 128, 52: 160, 53: 128, 54: 128}
 CONV3R_SPLITS = (1, 2, 4, 5, 8, 10)
-_CONV3R = os.environ.get("AVSD_CONV3R", "1") != "0"
+_CONV3R = True
 
 
 _CONV3R_BN = (128, 128, 160, 160, 128, 128, 256, 320, 256, 64)
@@ -272,7 +272,7 @@ def _heuristic_tile_x2(M: int, N: int, K: int, geglu: bool, splitk_ok: bool):
     return 25, sk
 
 
-_TUNE_COLD = os.environ.get("AVSD_TUNE_COLD", "1") != "0"
+_TUNE_COLD = True
 _FLUSH = None
 
 
@@ -715,7 +715,7 @@ def linear_small_m(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
 
 
 # one-launch GroupNorm for small batches (csrc/groupnorm_fused.hip); AVSD_GN_FUSED=0: always the pair
-_GN_FUSED = os.environ.get("AVSD_GN_FUSED", "1") != "0"
+_GN_FUSED = True
 
 
 def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], nb: int, rows_per_batch: int, groups: int,

@@ -35,7 +35,7 @@ UP_TYPES = ("FFSpatioAudioTempCrossAttnUpBlock3D", "FFSpatioTempCrossAttnUpBlock
 MID_TYPES = ("FFSpatioAudioTempCrossAttnUNetMidBlock3D", "FFSpatioTempCrossAttnUNetMidBlock3D")
 
 
-_FUSE_LN = os.environ.get("AVSD_FUSE_LN", "1") != "0"    # fold LayerNorm 1 / audio / 2 / 3 into the GEMMs around them
+_FUSE_LN = True    # fold LayerNorm 1 / audio / 2 / 3 into the GEMMs around them
 # f32 residual stream: every tensor that is later ADDED to (ResBlock input/output, the transformer's h, skips) also keeps an
 # un-rounded f32 master written by the epilogue that produced it; matrix operands and norms still read the 16-bit copy.
 # Removes the ~100 chained roundings of the residual stream (the dominant error term of the 16-bit path) for one extra f32
@@ -44,16 +44,16 @@ _F32_RES = os.environ.get("AVSD_F32_RESIDUAL", "0") != "0"
 # BASELINE cfg 5: e4m3 Q / K / V in the first-frame and cross attentions (avsd_attention_fp8), f32 softmax / accumulation.
 # Per model: `unet.fp8_attention = True` (optionally `unet.fp8_scales = (q, k, v)` per-tensor scales, default 1.0).
 _ATTN_FP8 = os.environ.get("AVSD_ATTN_FP8", "0") != "0"
-_FUSE_XATTN = os.environ.get("AVSD_FUSE_XATTN", "1") != "0"
+_FUSE_XATTN = True
 # the GEGLU projection re-folds the K / 32 LayerNorm partials of its rows in each of its 20-80 column tiles (+8-10 us per launch): fold
 # them once in a tiny launch (avsd_ln_fold) and hand it one pair per row
-_LN_PREFOLD = os.environ.get("AVSD_LN_PREFOLD", "1") != "0"
+_LN_PREFOLD = True
 # Classifier-free-guidance branches that share latents, timestep AND text conditioning (audio-only guidance: text [t, t],
 # pipeline_audio_cond_animation.py:155) are identical until the first audio cross-attention: conv_in, the first ResBlock and the
 # first transformer's GroupNorm / proj_in / first-frame attention are computed once and replicated (the reference computes them
 # per branch on its torch.cat'ed batch).  14 launches run on half (a third) of the rows.
-_SHARE_PREFIX = os.environ.get("AVSD_SHARE_PREFIX", "1") != "0"
-_F32_CONV_Y = os.environ.get("AVSD_F32_CONV_Y", "1") != "0"      # with the f32 residual stream: also the conv output inside FFInflatedConv3d
+_SHARE_PREFIX = True
+_F32_CONV_Y = True      # with the f32 residual stream: also the conv output inside FFInflatedConv3d
 
 
 def _replicate(a: "_Act", r: int) -> "_Act":

@@ -42,6 +42,7 @@ class GemmDesc(C.Structure):
         ("out_master", c_void_p), ("ldm", C.c_int32), ("reserved0", C.c_int32),
         ("a_lo", C.c_int64), ("a2_lo", C.c_int64), ("w_lo", C.c_int64), ("out_lo", C.c_int64), ("res1_lo", C.c_int64),
         ("res2_lo", C.c_int64),
+        ("stats_pos", c_void_p), ("ln_rowvec", c_void_p), ("pos_hw", C.c_int32), ("pos_frames", C.c_int32),
     ]
 
 
@@ -61,6 +62,7 @@ class XAttnDesc(C.Structure):
         ("o_bias", c_void_p), ("out", c_void_p),
         ("out_master", c_void_p), ("ldm", C.c_int32), ("reserved0", C.c_int32),
         ("rowstats", c_void_p),
+        ("stats_pos", c_void_p), ("pos_hw", C.c_int32), ("pos_frames", C.c_int32),
     ]
 
 

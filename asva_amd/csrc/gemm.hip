@@ -682,6 +682,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const avsd_gemm_desc
       const float mean = sm * inv_k;
       const float rstd = rsqrtf(fmaxf(sq * inv_k - mean * mean, 0.f) + p.ln_eps);
       const float4 cs = *reinterpret_cast<const float4*>(p.ln_colsum + n);
+      if (p.ln_rowvec) {
+        const float4 pv = *reinterpret_cast<const float4*>(pos_row(p, p.ln_rowvec, m) + n);
+        v[0] += pv.x; v[1] += pv.y; v[2] += pv.z; v[3] += pv.w;
+      }
       v[0] = fmaf(v[0], rstd, -mean * rstd * cs.x); v[1] = fmaf(v[1], rstd, -mean * rstd * cs.y);
       v[2] = fmaf(v[2], rstd, -mean * rstd * cs.z); v[3] = fmaf(v[3], rstd, -mean * rstd * cs.w);
     }
@@ -725,8 +729,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const avsd_gemm_desc
       }
       if (p.flags & AVSD_GEMM_ROWSTATS) {
         // 8 consecutive threads hold one 32-column block of row m (N % 32 == 0, 256 % 8 == 0): fold in a fixed order
-        const float a0 = lo2f(st.x) + e0, a1 = hi2f(st.x) + e1;
-        const float a2 = lo2f(st.y) + e2, a3 = hi2f(st.y) + e3;
+        float a0 = lo2f(st.x) + e0, a1 = hi2f(st.x) + e1;
+        float a2 = lo2f(st.y) + e2, a3 = hi2f(st.y) + e3;
+        if (p.stats_pos) {
+          const float4 pv = *reinterpret_cast<const float4*>(pos_row(p, p.stats_pos, m) + n);
+          a0 += pv.x; a1 += pv.y; a2 += pv.z; a3 += pv.w;
+        }
         float sm = (a0 + a1) + (a2 + a3);
         float sq = fmaf(a0, a0, fmaf(a1, a1, fmaf(a2, a2, a3 * a3)));
 #pragma unroll
@@ -787,7 +795,6 @@ int dispatch_tile(const avsd_gemm_desc& d, int tile, hipStream_t s) {
     case 4: return launch2<128, 64, 2, 2, 3, MODE>(d, s);
     case 6: return launch2<128, 128, 2, 4, 3, MODE>(d, s);
     case 7: return launch2<64, 64, 2, 2, 4, MODE>(d, s);
-    case 8: return launch2<256, 64, 4, 2, 3, MODE>(d, s);
     case 9: return launch2<256, 128, 4, 2, 3, MODE>(d, s);
     case 11: return launch2<128, 128, 2, 2, 2, MODE>(d, s);   // 64 KB: two 4-wave blocks per CU, 64x64 wave tiles
     case 12: return launch2<128, 64, 2, 2, 2, MODE>(d, s);    // 48 KB: three blocks per CU
@@ -799,24 +806,19 @@ int dispatch_tile(const avsd_gemm_desc& d, int tile, hipStream_t s) {
     case 19: return launch2<256, 320, 4, 2, 2, MODE>(d, s);   // 144 KB, 8 waves, 64x160 wave tiles
     // the same tiles with 2 extra loader waves (LW): the MFMA waves issue no loads
     case 20: return launch2<256, 128, 4, 2, 3, MODE, 4>(d, s);
-    case 21: return launch2<256, 128, 4, 2, 2, MODE, 4>(d, s);
-    case 22: return launch2<128, 128, 2, 2, 3, MODE, 2>(d, s);
-    case 23: return launch2<128, 320, 4, 2, 2, MODE, 4>(d, s);
     case 24: return launch2<128, 64, 2, 2, 3, MODE, 2>(d, s);
     case 25: return launch2<64, 64, 2, 2, 4, MODE, 2>(d, s);
     // deep rings for the weight-streaming low-resolution layers (M = 384 / 1536, K up to 23040): what bounds them is the
     // bytes in flight per CU against the ~2 us HBM round trip, so the ring takes all of LDS
     case 30: return launch2<128, 128, 2, 4, 4, MODE>(d, s);     // 128 KB
     case 31: return launch2<128, 256, 2, 4, 3, MODE>(d, s);     // 144 KB, weight-heavy tile
-    // 96-row full-row tiles: the top-level layers (M = 24576 per clip, N = 320) are exactly ONE wave of 256 workgroups,
-    // each reads its activation rows once; 5 MFMA waves (96x64 each) + 2 loader waves
-    case 32: return launch2<96, 320, 1, 5, 3, MODE, 2>(d, s);   // 156 KB
     // 256 x 160: the geometry the resident convolution does best with on the N = 320 layers (conv3r.hip tile 43) — N = 320 /
     // 640 / 960 / 1280 in whole column tiles, 98 FLOP per staged byte (128 x 128: 64)
     case AVSD_GEMM_TILE_256x160_8W: return launch2<256, 160, 8, 1, 3, MODE, 4>(d, s);   // 156 KB, 32x160 wave tiles, 8 MFMA + 4 loader waves
     // (built, measured and dropped — never the tuner's pick on MI355X: 128x128 x 3 on 4 waves (5), 128x64 x 4 (10), the 128x320 / 64x320
     //  4-wave full-row tiles (15, 16), 256x256 (18), 128x128 / 256x64 / 64x320 with loader waves (26-28), the 5-deep 128x128 ring (29),
-    //  96x320 x 2 (33), 256x160 on 4 MFMA waves (39))
+    //  96x320 x 2 (33), 256x160 on 4 MFMA waves (39); round 4, <= 2 table entries each once the asm tiles existed: 256x64 (8), the
+    //  2-stage 256x128 / 3-stage 128x128 / 128x320 with loader waves (21-23), the 96x320 full-row tile (32))
     default:
       avsd_set_error("gemm: tile id %d is not built (gemm.hip dispatch_tile)", tile);
       return AVSD_EINVAL;
@@ -940,6 +942,12 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
                  "gemm: LNFUSE needs ln_stats, ln_colsum, ln_nblk and a single-source PLAIN operand");
     AVSD_REQUIRE(d.ln_nblk * 32 == d.K || d.ln_nblk == 1, "gemm: LNFUSE statistics are K / 32 pairs per row or one pre-folded pair (got %d for K = %d)", d.ln_nblk, d.K);
     AVSD_REQUIRE(d.batch == 1 || d.batch_stride_a % d.lda == 0, "gemm: LNFUSE batch stride must be whole rows");
+  }
+  if (d.stats_pos || d.ln_rowvec) {       // LayerNorm(x + pos[frame]) fold (include/avsd.h)
+    AVSD_REQUIRE(d.pos_hw > 0 && d.pos_frames > 0 && d.batch == 1 && !(d.flags & AVSD_GEMM_X2),
+                 "gemm: stats_pos / ln_rowvec need pos_hw > 0, pos_frames > 0, batch 1 and no AVSD_GEMM_X2 (got hw %d, frames %d)", d.pos_hw, d.pos_frames);
+    AVSD_REQUIRE(!d.stats_pos || (d.flags & AVSD_GEMM_ROWSTATS), "gemm: stats_pos without AVSD_GEMM_ROWSTATS");
+    AVSD_REQUIRE(!d.ln_rowvec || (d.flags & AVSD_GEMM_LNFUSE), "gemm: ln_rowvec without AVSD_GEMM_LNFUSE");
   }
   if (d.res1) AVSD_REQUIRE(d.ldr1 % 4 == 0, "gemm: ldr1 must be a multiple of 4");
   if (d.res2) AVSD_REQUIRE(d.ldr2 % 4 == 0, "gemm: ldr2 must be a multiple of 4");

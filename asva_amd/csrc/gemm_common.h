@@ -31,6 +31,34 @@ __device__ __forceinline__ void ln_row_stats(const avsd_gemm_desc& p, int m, int
   mr = mean * rstd;
 }
 
+// frame table row of output row m (stats_pos / ln_rowvec, include/avsd.h): [pos_frames][N], frame = (m / pos_hw) % pos_frames
+__device__ __forceinline__ const float* pos_row(const avsd_gemm_desc& p, const float* table, int m) {
+  return table + (int64_t)((m / p.pos_hw) % p.pos_frames) * p.N;
+}
+
+// (sum, sum of squares) of the 16 rounded values a lane has just stored (8 packed pairs, columns ncol .. ncol + 15 in order),
+// optionally of (value + pos[column]) — AVSD_GEMM_ROWSTATS with stats_pos
+__device__ __forceinline__ void rowstats16(const unsigned (&w8)[8], const float* pos16, float& sm, float& sq) {
+  float pv[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) pv[i] = 0.f;
+  if (pos16) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 t = *reinterpret_cast<const float4*>(pos16 + 4 * j);
+      pv[4 * j] = t.x; pv[4 * j + 1] = t.y; pv[4 * j + 2] = t.z; pv[4 * j + 3] = t.w;
+    }
+  }
+  sm = 0.f;
+  sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float lo = lo2f(w8[i]) + pv[2 * i], hi = hi2f(w8[i]) + pv[2 * i + 1];
+    sm += lo + hi;
+    sq = fmaf(lo, lo, fmaf(hi, hi, sq));
+  }
+}
+
 // Big tiles hold 128-160 accumulator registers: letting the compiler batch the loads of ALL fragments of a term would spill.
 // A scheduling fence after each fragment caps the batch at one fragment's loads (4-8 in flight), still one wait per fragment
 // instead of one per vector.
@@ -135,16 +163,24 @@ __device__ __forceinline__ void epilogue_by_term(const avsd_gemm_desc& p, f32x16
       if (have_pre) { rstd[b] = pre_ln[2 * b]; mr[b] = pre_ln[2 * b + 1]; }
       else ln_row_stats(p, mld[b], bz, rstd[b], mr[b]);
     }
+    const float* lrv[FM];
+#pragma unroll
+    for (int b = 0; b < FM; ++b) lrv[b] = p.ln_rowvec ? pos_row(p, p.ln_rowvec, mld[b]) : nullptr;
 #pragma unroll
     for (int a = 0; a < FN; ++a)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 cs = *reinterpret_cast<const float4*>(p.ln_colsum + min(n_base + a * 32 + 8 * q + hsel, nmax));
+        const int nc = min(n_base + a * 32 + 8 * q + hsel, nmax);
+        const float4 cs = *reinterpret_cast<const float4*>(p.ln_colsum + nc);
         const float c4[4] = {cs.x, cs.y, cs.z, cs.w};
 #pragma unroll
-        for (int b = 0; b < FM; ++b)
+        for (int b = 0; b < FM; ++b) {
+          float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);        // LayerNorm(A + pos): W'.pos[frame] joins the product inside the rstd scaling
+          if (p.ln_rowvec) pv = *reinterpret_cast<const float4*>(lrv[b] + nc);
+          const float p4[4] = {pv.x, pv.y, pv.z, pv.w};
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[a][b][4 * q + i] = fmaf(p.alpha * acc[a][b][4 * q + i], rstd[b], -mr[b] * c4[i]);
+          for (int i = 0; i < 4; ++i) acc[a][b][4 * q + i] = fmaf(p.alpha * acc[a][b][4 * q + i] + p4[i], rstd[b], -mr[b] * c4[i]);
+        }
         if (q == 3) epilogue_fence<FN, FM>();
       }
   } else {
@@ -263,15 +299,10 @@ __device__ __forceinline__ void epilogue_by_term(const avsd_gemm_desc& p, f32x16
         *reinterpret_cast<uint4*>(op) = make_uint4(x[0][0], x[0][1], x[1][0], x[1][1]);
         *reinterpret_cast<uint4*>(op + 8) = make_uint4(y[0][0], y[0][1], y[1][0], y[1][1]);
         if (rs_out) {
-          // (sum, sum of squares) of the 16 rounded values this lane just stored, plus the partner lane's 16
-          float sm = 0.f, sq = 0.f;
+          // (sum, sum of squares) of the 16 rounded values this lane just stored (+ stats_pos), plus the partner lane's 16
+          float sm, sq;
           const unsigned w8[8] = {x[0][0], x[0][1], x[1][0], x[1][1], y[0][0], y[0][1], y[1][0], y[1][1]};
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const float lo = lo2f(w8[i]), hi = hi2f(w8[i]);
-            sm += lo + hi;
-            sq = fmaf(lo, lo, fmaf(hi, hi, sq));
-          }
+          rowstats16(w8, p.stats_pos ? pos_row(p, p.stats_pos, m) + nb + 4 * hsel : nullptr, sm, sq);
           const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(sm), __float_as_uint(sm), false, false);
           const auto u = __builtin_amdgcn_permlane32_swap(__float_as_uint(sq), __float_as_uint(sq), false, false);
           // lanes 0-31: t = (own, partner's); fixed order low half + high half on both lanes
@@ -321,6 +352,7 @@ __device__ __forceinline__ void epilogue_by_fragment(const avsd_gemm_desc& p, f3
     const int m = m_base + b * mstride + frow;
     if (m >= p.M) continue;
     const float* rv = p.rowvec ? p.rowvec + (int64_t)(m / p.rows_per_vec) * p.ldv : nullptr;
+    const float* lrv = (lnfuse && p.ln_rowvec) ? pos_row(p, p.ln_rowvec, m) : nullptr;
     // AVSD_GEMM_LNFUSE: LayerNorm statistics of this lane's row of A (rstd, mean * rstd)
     float ln_rstd = 1.f, ln_mr = 0.f;
     if (lnfuse) {
@@ -336,6 +368,10 @@ __device__ __forceinline__ void epilogue_by_fragment(const avsd_gemm_desc& p, f3
       for (int i = 0; i < 4; ++i) v[i] = p.alpha * acc[a][b][4 * q + i];
       if (lnfuse) {
         const float4 cs = *reinterpret_cast<const float4*>(p.ln_colsum + n);
+        if (lrv) {
+          const float4 pv = *reinterpret_cast<const float4*>(lrv + n);
+          v[0] += pv.x; v[1] += pv.y; v[2] += pv.z; v[3] += pv.w;
+        }
         v[0] = fmaf(v[0], ln_rstd, -ln_mr * cs.x); v[1] = fmaf(v[1], ln_rstd, -ln_mr * cs.y);
         v[2] = fmaf(v[2], ln_rstd, -ln_mr * cs.z); v[3] = fmaf(v[3], ln_rstd, -ln_mr * cs.w);
       }
@@ -416,15 +452,10 @@ __device__ __forceinline__ void epilogue_by_fragment(const avsd_gemm_desc& p, f3
         *reinterpret_cast<uint4*>(op) = make_uint4(x[0][0], x[0][1], x[1][0], x[1][1]);
         *reinterpret_cast<uint4*>(op + 8) = make_uint4(y[0][0], y[0][1], y[1][0], y[1][1]);
         if (rs_out) {
-          // (sum, sum of squares) of the 16 rounded values this lane just stored, plus the partner lane's 16
-          float sm = 0.f, sq = 0.f;
+          // (sum, sum of squares) of the 16 rounded values this lane just stored (+ stats_pos), plus the partner lane's 16
+          float sm, sq;
           const unsigned w8[8] = {x[0][0], x[0][1], x[1][0], x[1][1], y[0][0], y[0][1], y[1][0], y[1][1]};
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const float lo = lo2f(w8[i]), hi = hi2f(w8[i]);
-            sm += lo + hi;
-            sq = fmaf(lo, lo, fmaf(hi, hi, sq));
-          }
+          rowstats16(w8, p.stats_pos ? pos_row(p, p.stats_pos, m) + nb + 4 * hsel : nullptr, sm, sq);
           const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(sm), __float_as_uint(sm), false, false);
           const auto u = __builtin_amdgcn_permlane32_swap(__float_as_uint(sq), __float_as_uint(sq), false, false);
           // lanes 0-31: t = (own, partner's); fixed order low half + high half on both lanes

@@ -410,6 +410,10 @@ extern "C" int avsd_cross_attention_block(const avsd_xattn_desc* dp, void* strea
   e.flags = (d.res_f32 ? AVSD_GEMM_RES1_F32 : 0) | (d.rowstats ? AVSD_GEMM_ROWSTATS : 0);
   e.rowstats = d.rowstats; e.out_master = d.out_master; e.ldm = d.ldm;
   if (d.out_master) AVSD_REQUIRE(d.ldm % 4 == 0 && d.ldm >= d.C, "cross_attention_block: bad ldm");
+  if (d.stats_pos) {
+    AVSD_REQUIRE(d.rowstats && d.pos_hw > 0 && d.pos_frames > 0, "cross_attention_block: stats_pos needs rowstats, pos_hw > 0 and pos_frames > 0");
+    e.stats_pos = d.stats_pos; e.pos_hw = d.pos_hw; e.pos_frames = d.pos_frames;
+  }
   a.epi = e;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (d.lk_pad) {

@@ -100,8 +100,8 @@ def _stream() -> int:
 # AVSD_AUTOTUNE=1 / set_autotune(True) switches on the measuring tuner for shapes missing from the table: every
 # candidate is timed with HIP events on the caller's real buffers and the winner is cached for the life of the
 # process (measure, don't guess) — that is how the table is produced; results then depend on timing noise.
-TILE_CANDIDATES = ((4, 1), (6, 1), (7, 1), (8, 1), (9, 1), (3, 1), (11, 1), (12, 1), (13, 1), (14, 1), (17, 1), (19, 1),
-                   (20, 1), (21, 1), (22, 1), (23, 1), (24, 1), (25, 1), (30, 1), (31, 1), (32, 1), (38, 1))
+TILE_CANDIDATES = ((4, 1), (6, 1), (7, 1), (9, 1), (3, 1), (11, 1), (12, 1), (13, 1), (14, 1), (17, 1), (19, 1),
+                   (20, 1), (24, 1), (25, 1), (30, 1), (31, 1), (38, 1))
 # extra (tile, split_k) candidates for GEMMs whose output is too small to fill 256 CUs with big tiles
 SPLITK_CANDIDATES = ((6, 2), (6, 4), (6, 8), (9, 2), (9, 4), (4, 2), (4, 4), (4, 8), (7, 2), (7, 4),
                      (20, 2), (20, 4), (24, 2), (24, 4), (24, 8), (25, 2), (25, 4),
@@ -233,13 +233,11 @@ def _heuristic_tile(M: int, N: int, K: int, geglu: bool, splitk_ok: bool):
     nk = (K + 63) // 64
     # measured (profiles/r2_probes.md, tools/tile_probe.py): 256x128 wins once it fills the chip — with loader waves and a
     # 3-deep ring for long K, the 2-stage form for short K; 256x256 only pays at K >= 4096 and is left to the tuned table;
-    # N = 320 layers lose 17 % of a 128-wide tile to padding and take 128x64 (or the 96x320 full-row tile for long K)
+    # N = 320 layers lose 17 % of a 128-wide tile to padding and take 128x64
     if N >= 512 and tiles(256, 128) >= 224:
         return (20 if nk >= 16 else 14), 1
     if N >= 512 and tiles(128, 128) >= 224:
         return (30 if nk >= 8 else 11), 1
-    if N == 320 and M % 96 == 0 and M // 96 >= 224 and nk >= 30:
-        return 32, 1
     if tiles(128, 64) >= 224:
         return (24 if nk >= 16 else 12), 1
     t64 = tiles(64, 64)
@@ -452,6 +450,8 @@ def gemm(
     gelu: bool = False,
     rowstats: Optional[torch.Tensor] = None,   # out: f32 [M, N/32, 2] (sum, sumsq) of the rounded outputs per 32 columns
     ln: Optional[tuple] = None,                # (stats [rows, K/32, 2] f32, colsum [N] f32, eps): LayerNorm(A) folded in
+    stats_pos: Optional[tuple] = None,         # (pos [frames, N] f32, hw, frames): rowstats of out + pos[frame of the row]
+    ln_pos: Optional[tuple] = None,            # (pos . W'^T [frames, N] f32, hw, frames) with ln: LayerNorm(A + pos[frame]) folded in
     out_f32: bool = False,
     out: Optional[torch.Tensor] = None,
     master: Optional[torch.Tensor] = None,     # out: f32 [M, N] un-rounded copy of the result (f32 residual stream)
@@ -471,7 +471,7 @@ def gemm(
         # un-rounded f32 partial for the second's epilogue — the same sum
         if res1 is not None and res2 is not None:
             raise ValueError("gemm: split precision with an unaligned two-source A supports one residual")
-        if gelu or geglu or rowstats is not None or ln is not None or master is not None or n is not None or k is not None or m is not None \
+        if gelu or geglu or rowstats is not None or ln is not None or stats_pos is not None or ln_pos is not None or master is not None or n is not None or k is not None or m is not None \
                 or tile or split_k != 1:
             # (GELU would be applied to the second partial alone; the other options are not forwarded by this two-launch form)
             raise ValueError("gemm: split precision with an unaligned two-source A takes bias / rowvec / one residual / alpha only")
@@ -558,6 +558,19 @@ def gemm(
             raise ValueError("gemm: ln = (stats [rows, K/32, 2], colsum [N], eps)")
         d.ln_stats, d.ln_colsum, d.ln_nblk, d.ln_eps = _p(st), _p(colsum), st.shape[-2], float(eps)
         d.flags |= LNFUSE
+    for name, arg in (("stats_pos", stats_pos), ("ln_pos", ln_pos)):
+        if arg is None:
+            continue
+        tbl, hw_, fr_ = arg
+        _req(tbl, F32, name)
+        if P.SPLIT or not tbl.is_contiguous() or tbl.shape != (fr_, N) or hw_ <= 0 or (rowstats is None if name == "stats_pos" else ln is None):
+            raise ValueError(f"gemm: {name} = (f32 [frames, N], hw, frames) goes with " + ("rowstats" if name == "stats_pos" else "ln") +
+                             "; not in split precision")
+        if name == "stats_pos":
+            d.stats_pos = _p(tbl)
+        else:
+            d.ln_rowvec = _p(tbl)
+        d.pos_hw, d.pos_frames = int(hw_), int(fr_)
     # XCD banding: the 8 L2s are not shared, so whichever operand is NOT banded is fetched by all 8 of them
     a_bytes = M * (K // 9 if mode == CONV3 else K // 3 if mode == TMIX else K)
     if _XCD_MODE == "n" or (_XCD_MODE == "auto" and N * K > a_bytes):
@@ -638,7 +651,7 @@ def gemm(
         fam = ("gemm_plain", "gemm_tmix", "gemm_conv3")[mode]
         dc = GemmDesc.from_buffer_copy(d)
         _TIMER.add_replay(fam, lambda dc=dc: check(_lib.lib().avsd_gemm_bf16(C.byref(dc), _stream()), "avsd_gemm_bf16"),
-                          (a, a2, w, out, bias, rowvec, res1, res2, ws, rowstats, ln, master))
+                          (a, a2, w, out, bias, rowvec, res1, res2, ws, rowstats, ln, master, stats_pos, ln_pos))
         _TIMER.stop(ev, fam, 2.0 * M * N * K * (3 if P.SPLIT else 1), 2.0 * M * K * (1.0 / 9 if mode == CONV3 else 1.0 / 3 if mode == TMIX else 1.0)
                     + 2.0 * N * K + _nbytes(out, res1, res2))
     return out
@@ -857,7 +870,7 @@ def cross_attention_block(h: torch.Tensor, stats: torch.Tensor, wq: torch.Tensor
                           k: torch.Tensor, vt: torch.Tensor, lk: int, wo: torch.Tensor, o_bias: torch.Tensor, *, res: torch.Tensor,
                           heads: int, L: int, q_per_kv: int, eps: float = 1e-5, scale: Optional[float] = None,
                           rowstats: Optional[torch.Tensor] = None, master: Optional[torch.Tensor] = None,
-                          out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                          out: Optional[torch.Tensor] = None, stats_pos: Optional[tuple] = None) -> torch.Tensor:
     """out = res + to_out(softmax((LN(h) Wq^T) K^T scale) V) in one launch; see avsd_cross_attention_block (include/avsd.h).
     k [nkv, lk_pad, C], vt [nkv, C, lk_pad] are the cached, padded (and for audio mask-gathered) K / V^T."""
     if P.SPLIT:
@@ -895,13 +908,19 @@ def cross_attention_block(h: torch.Tensor, stats: torch.Tensor, wq: torch.Tensor
     if rowstats is not None:
         _req(rowstats, F32, "rowstats")
         d.rowstats = _p(rowstats)
+    if stats_pos is not None:
+        tbl, hw_, fr_ = stats_pos
+        _req(tbl, F32, "stats_pos")
+        if rowstats is None or not tbl.is_contiguous() or tbl.shape != (fr_, Cc) or hw_ <= 0:
+            raise ValueError("cross_attention_block: stats_pos = (f32 [frames, C], hw, frames) goes with rowstats")
+        d.stats_pos, d.pos_hw, d.pos_frames = _p(tbl), int(hw_), int(fr_)
     ev = _TIMER.start() if _TIMER is not None else None
     check(_lib.lib().avsd_cross_attention_block(C.byref(d), _stream()), "avsd_cross_attention_block")
     if ev is not None:
         dc = XAttnDesc.from_buffer_copy(d)
         _TIMER.add_replay("cross_attention_block", lambda dc=dc: check(_lib.lib().avsd_cross_attention_block(C.byref(dc), _stream()),
                                                                          "avsd_cross_attention_block"),
-                          (h, stats, wq, q_colsum, q_bias, k, vt, wo, o_bias, res, out, master, rowstats))
+                          (h, stats, wq, q_colsum, q_bias, k, vt, wo, o_bias, res, out, master, rowstats, stats_pos))
         _TIMER.stop(ev, "cross_attention_block", 4.0 * M * Cc * Cc + 4.0 * M * lk * Cc, _nbytes(h, out, res, master) + 4.0 * Cc * Cc)
     return out
 

@@ -36,6 +36,7 @@ MID_TYPES = ("FFSpatioAudioTempCrossAttnUNetMidBlock3D", "FFSpatioTempCrossAttnU
 
 
 _FUSE_LN = True    # fold LayerNorm 1 / audio / 2 / 3 into the GEMMs around them
+_FUSE_LN_TEMP = True    # ... and norm_temp (LayerNorm of h + temporal position embedding) too
 # f32 residual stream: every tensor that is later ADDED to (ResBlock input/output, the transformer's h, skips) also keeps an
 # un-rounded f32 master written by the epilogue that produced it; matrix operands and norms still read the 16-bit copy.
 # Removes the ~100 chained roundings of the residual stream (the dominant error term of the 16-bit path) for one extra f32
@@ -358,7 +359,10 @@ class Packer:
         else:
             p.wq = reg(pack_linear(wq))
             p.wkv = reg(pack_linear(torch.cat([wk, wv], 0)))
-        if norm is not None:
+        if norm is not None and fuse_qkv:       # norm_temp: LayerNorm(h + pos) in front of the fused q|k|v projection (AVSD_GEMM_LNFUSE + ln_rowvec)
+            wf, cs, cb = self.lnfold(torch.cat([wq, wk, wv], 0), norm)
+            p.wqkv_ln, p.sqkv_ln, p.bqkv_ln = reg(wf), reg(cs), reg(cb)
+        elif norm is not None:
             wf, cs, cb = self.lnfold(wq, norm)
             p.wq_ln, p.sq_ln, p.bq_ln = reg(wf), reg(cs), reg(cb)
             if fold_kv:
@@ -386,7 +390,7 @@ class Packer:
                 norm1=self.aff(b.norm1), attn1=self.attn(b.attn1, False, b.norm1, fold_kv=True),
                 norm2=self.aff(b.norm2), attn2=self.attn(b.attn2, False, b.norm2),
                 w1_ln=reg(w1_ln), b1_ln=reg(b1_ln), s1_ln=reg(from_act(w1_ln).sum(1)),
-                norm_temp=self.aff(b.norm_temp), attn_temp=self.attn(b.attn_temp, True),
+                norm_temp=self.aff(b.norm_temp), attn_temp=self.attn(b.attn_temp, True, b.norm_temp),
                 pos1=self.lin(b.pos_embedding_temp.linear_1), pos2=self.lin(b.pos_embedding_temp.linear_2),
                 norm3=self.aff(b.norm3), w1=reg(w1), b1=reg(b1), ff2=self.lin(b.ff.net[2]),
                 dim=m.proj_in.weight.shape[0], audio=hasattr(b, "attn_audio"))
@@ -835,6 +839,9 @@ class AudioUNet3DConditionModel(nn.Module):
         emb = ops.timestep_embedding(ar, C)
         hid = ops.linear_small_m(emb, tp.pos1.w, tp.pos1.b, act_out=True)
         c.pos = ops.linear_small_m(hid, tp.pos2.w, tp.pos2.b)
+        # pos . W'^T of the LayerNorm-folded q|k|v projection of the temporal attention: with it, LayerNorm(h + pos) needs no kernel
+        # (avsd_gemm_desc.ln_rowvec).  The same rounded W' the GEMM multiplies h with, so W'.h + W'.pos = W'.(h + pos) exactly.
+        c.posw = None if P.SPLIT else ops.linear_small_m(c.pos, tp.attn_temp.wqkv_ln, None)
         AudioUNet3DConditionModel._xa_caches(c, tp, key_index, idx_frames if idx_frames is not None else frames, frames)
         return c
 
@@ -1032,23 +1039,24 @@ def _transformer(st, x: _Act, p, hw, heads, split: int = 1) -> _Act:
     fused = C % 32 == 0 and st.fuse_ln
     # LayerNorms 1 / audio / 2 / 3 (fused): not launched — the GEMM that produces the residual stream also emits per-row
     # (sum, sumsq) pairs, and the projections that follow fold mean / rstd into their epilogue (gain and shift live
-    # in the packed weights: Packer.lnfold).  norm_temp (+ position table) stays a kernel.
+    # in the packed weights: Packer.lnfold); norm_temp (+ position table) likewise, see step 4.
     # Unfused: channel counts the 32-column statistics blocks do not tile (tiny test configurations), or fuse_layernorm off.
     eps = 1e-5
     M = B * Fr * L
     stats = [torch.empty((M, C // 32, 2), dtype=torch.float32, device=n.device) for _ in range(2)] if fused else None
     si = 0
 
-    def stream(a, w, bias, res, want_stats=True):
-        """h' = a . w^T + bias (+ res): a residual-stream update (16-bit copy + optional f32 master + LayerNorm statistics)"""
+    def stream(a, w, bias, res, want_stats=True, stats_pos=None):
+        """h' = a . w^T + bias (+ res): a residual-stream update (16-bit copy + optional f32 master + LayerNorm statistics;
+        stats_pos: the statistics are those of h' + pos[frame], for norm_temp)"""
         nonlocal si
         m = _master(st, a, w.shape[0])
         if fused and want_stats:
             si ^= 1
-            return _Act(ops.gemm(a, w, bias=bias, res1=None if res is None else res.res, rowstats=stats[si], master=m), m)
+            return _Act(ops.gemm(a, w, bias=bias, res1=None if res is None else res.res, rowstats=stats[si], master=m, stats_pos=stats_pos), m)
         return _Act(ops.gemm(a, w, bias=bias, res1=None if res is None else res.res, master=m), m)
 
-    def cross(h, a, norm, xa, want_stats, unfused):
+    def cross(h, a, norm, xa, want_stats, unfused, stats_pos=None):
         """h + to_out(attention(LN(h) Wq, cached K, V)): one launch where the fused kernel is built, else q-proj + attention
         + out-proj"""
         nonlocal si
@@ -1060,9 +1068,9 @@ def _transformer(st, x: _Act, p, hw, heads, split: int = 1) -> _Act:
                 si ^= 1
                 s_out = stats[si]
             out = ops.cross_attention_block(h.lo, s_in, a.wq_ln, a.sq_ln, a.bq_ln, xa.k, xa.vt, xa.lk, a.wo, a.bo, res=h.res,
-                                            heads=heads, L=L, q_per_kv=xa.q_per_kv, eps=eps, rowstats=s_out, master=m)
+                                            heads=heads, L=L, q_per_kv=xa.q_per_kv, eps=eps, rowstats=s_out, master=m, stats_pos=stats_pos)
             return _Act(out, m)
-        return stream(unfused(), a.wo, a.bo, h, want_stats=want_stats)
+        return stream(unfused(), a.wo, a.bo, h, want_stats=want_stats, stats_pos=stats_pos)
 
     def proj(h, norm, wl, bl, sl, w_plain):
         """Linear(LayerNorm(h)): folded into one GEMM on the raw stream, or LayerNorm kernel + plain GEMM"""
@@ -1112,10 +1120,16 @@ def _transformer(st, x: _Act, p, hw, heads, split: int = 1) -> _Act:
         return ops.attention(q, c.text_kv[:, :C], c.text_kv[:, C:], bq=B * Fr, lq=L, lk=c.text_len, kv_rows=c.text_len,
                              heads=heads, q_per_kv=Fr if c.text_pf == 1 else 1, frames=Fr, fp8=st.fp8)
 
-    h = cross(h, a2, p.norm2, getattr(c, "xa_text", None), False, text_attention)   # norm_temp below is a kernel of its own
-    # 4. temporal attention across frames per pixel; LN(h + pos[f]); residual is h itself (:346-358)
-    nt = ops.layernorm(h.lo, p.norm_temp.g, p.norm_temp.b, pos=c.pos, hw=L, frames=Fr)
-    qkv = ops.gemm(nt, p.attn_temp.wqkv)
+    # 4. temporal attention across frames per pixel; LN(h + pos[f]); residual is h itself (:346-358).  Folded like the other LayerNorms:
+    # the text cross-attention's output projection emits the row statistics of h + pos[frame], and the q|k|v projection reads the raw h
+    # with pos . W'^T added inside its LayerNorm epilogue (avsd_gemm_desc.stats_pos / ln_rowvec) — no LayerNorm launch, no (M, C) round trip
+    fold_temp = fused and _FUSE_LN_TEMP and getattr(c, "posw", None) is not None and hasattr(p.attn_temp, "wqkv_ln")
+    h = cross(h, a2, p.norm2, getattr(c, "xa_text", None), fold_temp, text_attention, stats_pos=(c.pos, L, Fr) if fold_temp else None)
+    if fold_temp:
+        qkv = ops.gemm(h.lo, p.attn_temp.wqkv_ln, bias=p.attn_temp.bqkv_ln, ln=(stats[si], p.attn_temp.sqkv_ln, eps), ln_pos=(c.posw, L, Fr))
+    else:
+        nt = ops.layernorm(h.lo, p.norm_temp.g, p.norm_temp.b, pos=c.pos, hw=L, frames=Fr)
+        qkv = ops.gemm(nt, p.attn_temp.wqkv)
     o = ops.temporal_attention(qkv, b=B, frames=Fr, hw=L, heads=heads)
     h = stream(o, p.attn_temp.wo, p.attn_temp.bo, h)
     # 5. GEGLU feed-forward, activation fused in the first GEMM's epilogue (:361-371)

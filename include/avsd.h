@@ -33,7 +33,7 @@ extern "C" {
 #define AVSD_ELAUNCH (-2)  /* hipLaunch / runtime error                          */
 #define AVSD_ENODEV (-3)   /* no gfx950 device / wrong architecture              */
 
-#define AVSD_ABI_VERSION 7
+#define AVSD_ABI_VERSION 8
 
 /* ---- library ------------------------------------------------------------------------ */
 int avsd_abi_version(void);
@@ -156,6 +156,15 @@ typedef struct avsd_gemm_desc {
    * W.A + Wr.A + W.Ar (three MFMA passes into one f32 accumulator); 16-bit residuals are read as main + rest and the output
    * is written as main = round16(v), rest = round16(v - main).  LDS-direct tiles 7, 11, 13, 24, 25, 34, 35, 36 only. */
   int64_t a_lo, a2_lo, w_lo, out_lo, res1_lo, res2_lo;
+  /* LayerNorm(x + pos[frame]) folded like the plain LayerNorm above (ff_spatio_audio_temp_transformer_3d.py:346-356: norm_temp of
+   * h + the temporal position embedding feeds the q|k|v projection of the temporal attention).  Row m belongs to frame
+   * f(m) = (m / pos_hw) % pos_frames.  Producer side, `stats_pos` f32 [pos_frames][N] with AVSD_GEMM_ROWSTATS: the row statistics are
+   * those of (rounded output + stats_pos[f(m)]) — `out` itself is unchanged.  Consumer side, `ln_rowvec` f32 [pos_frames][N] =
+   * pos . W'^T with AVSD_GEMM_LNFUSE: v = rstd[m] * (alpha * acc + ln_rowvec[f(m)][n] - mean[m] * ln_colsum[n]) + bias[n], i.e.
+   * LayerNorm(A + pos) . W^T + b with A un-normalised and pos never added to it.  Not with AVSD_GEMM_X2. */
+  const float* stats_pos;
+  const float* ln_rowvec;
+  int32_t pos_hw, pos_frames;
 } avsd_gemm_desc;
 
 int avsd_gemm_bf16(const avsd_gemm_desc* desc_host, void* stream);
@@ -195,6 +204,8 @@ typedef struct avsd_xattn_desc {
   void* out;
   float* out_master;    int32_t ldm;   int32_t reserved0;
   float* rowstats;
+  const float* stats_pos;   /* as avsd_gemm_desc.stats_pos: [pos_frames][C], the row statistics are those of out + stats_pos[frame of the row] */
+  int32_t pos_hw, pos_frames;
 } avsd_xattn_desc;
 int avsd_cross_attention_block_supported(int C, int heads, int lk_pad);
 int avsd_cross_attention_block(const avsd_xattn_desc* desc_host, void* stream);

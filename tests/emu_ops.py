@@ -20,7 +20,7 @@ F32 = torch.float32
 
 def gemm(a, w, *, n=None, k=None, a2=None, bias=None, rowvec=None, rows_per_vec=0, res1=None, res2=None, alpha=1.0,
          geglu=False, gelu=False, out_f32=False, out=None, mode=PLAIN, tmix=None, conv=None, m=None, tile=0, split_k=1,
-         rowstats=None, ln=None, master=None):
+         rowstats=None, ln=None, master=None, stats_pos=None, ln_pos=None):
     assert a.dtype == P.ACT and w.dtype == P.ACT
     wf = w.float()
     if mode == PLAIN:
@@ -49,6 +49,9 @@ def gemm(a, w, *, n=None, k=None, a2=None, bias=None, rowvec=None, rows_per_vec=
     assert x.shape[1] == wf.shape[1], (x.shape, wf.shape)
     acc = alpha * (x @ wf.T)
     if ln is not None:          # LayerNorm(A) folded in: W carries gamma, bias carries beta . W^T (see avsd.h)
+        if ln_pos is not None:  # LayerNorm(A + pos[frame]): pos . W'^T joins the product inside the rstd scaling
+            tbl, hw_, fr_ = ln_pos
+            acc = acc + tbl[(torch.arange(x.shape[0]) // hw_) % fr_]
         acc = _ln_fold(acc, ln, torch.arange(x.shape[0]), x.shape[1])
     if not geglu:
         v = acc
@@ -70,7 +73,11 @@ def gemm(a, w, *, n=None, k=None, a2=None, bias=None, rowvec=None, rows_per_vec=
     if master is not None:
         master.copy_(v)
     if rowstats is not None:
-        r = v.to(P.ACT).float().reshape(v.shape[0], -1, 32)
+        r = v.to(P.ACT).float()
+        if stats_pos is not None:
+            tbl, hw_, fr_ = stats_pos
+            r = r + tbl[(torch.arange(v.shape[0]) // hw_) % fr_]
+        r = r.reshape(v.shape[0], -1, 32)
         rowstats.copy_(torch.stack([r.sum(-1), (r * r).sum(-1)], -1))
     if out is not None:
         out.copy_(v.to(out.dtype))
@@ -165,7 +172,7 @@ def cross_attention_block_supported(C, heads, lk_pad, M, L):
 
 
 def cross_attention_block(h, stats, wq, q_colsum, q_bias, k, vt, lk, wo, o_bias, *, res, heads, L, q_per_kv, eps=1e-5, scale=None,
-                          rowstats=None, master=None, out=None):
+                          rowstats=None, master=None, out=None, stats_pos=None):
     """same rounding points as the fused kernel: q, P and o are rounded to the storage type"""
     M, C = h.shape
     d = C // heads
@@ -177,7 +184,7 @@ def cross_attention_block(h, stats, wq, q_colsum, q_bias, k, vt, lk, wo, o_bias,
     s = torch.einsum("blhd,bkhd->bhlk", q, kk) * scale
     pr = torch.softmax(s, -1).to(P.ACT).float()
     o = torch.einsum("bhlk,bhdk->blhd", pr, vv).reshape(M, C).to(P.ACT)
-    return gemm(o, wo, bias=o_bias, res1=res, rowstats=rowstats, master=master, out=out)
+    return gemm(o, wo, bias=o_bias, res1=res, rowstats=rowstats, master=master, out=out, stats_pos=stats_pos)
 
 
 def temporal_attention(qkv, *, b, frames, hw, heads, scale=None, out=None):

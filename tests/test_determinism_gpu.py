@@ -17,11 +17,11 @@ CHILD = r"""
 import hashlib, json, os, sys, torch
 sys.path.insert(0, {root!r})
 from oracle.filler import seeded_randn
-from tests.helpers import GOLDEN, filled_unet
 from tests.test_host_cpu import _filled_vae, TINY_VAE
 from asva_amd.conditioning import audio_segment_mask
-cfg = json.load(open(os.path.join(GOLDEN, "unet_sd15_config.json")))
-m = filled_unet(cfg).to("cuda")
+import bench
+m = bench.build_unet(torch.device("cuda", 0), 0, 1)      # SD1.5 shape, weights drawn on the device from a fixed seed (seconds, not the
+                                                         # ~40 s the host-side closed-form filler takes for 1.17 B parameters)
 lat = seeded_randn(1, 1, 4, 12, 32, 32)
 x = torch.cat([lat, lat]).cuda()
 text = seeded_randn(2, 1, 77, 768).expand(2, 77, 768).cuda()
@@ -48,7 +48,7 @@ def _collect(proc):
 
 
 def test_two_processes_give_bit_identical_outputs():
-    pa, pb = _spawn(), _spawn()          # side by side (each spends most of its time filling 1.17 B parameters on the host)
+    pa, pb = _spawn(), _spawn()          # side by side
     a, b = _collect(pa), _collect(pb)
     print("UNet output sha256", a[0][:16], "| VAE frames sha256", a[1][:16])
     assert a == b

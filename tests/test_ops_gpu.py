@@ -58,7 +58,7 @@ def test_device_is_gfx950():
 # ---- GEMM ------------------------------------------------------------------------------------------
 # tile ids built into the library (csrc/gemm.hip dispatch_tile): 1-3 register-staged, the rest LDS-direct; 0 = table / rule
 V1_TILES = [1, 2, 3]
-V2_TILES = [4, 6, 7, 8, 9, 11, 12, 13, 14, 17, 19, 20, 21, 22, 23, 24, 25, 30, 31, 32, 38]
+V2_TILES = [4, 6, 7, 9, 11, 12, 13, 14, 17, 19, 20, 24, 25, 30, 31, 38]
 @pytest.mark.parametrize("tile", V1_TILES + V2_TILES + [0])
 @pytest.mark.parametrize("M,N,K", [(384, 320, 320), (1000, 640, 1280), (128, 64, 64), (77, 132, 200), (2048, 1280, 768)])
 def test_gemm_plain(ops, tile, M, N, K):
@@ -96,7 +96,7 @@ def test_gemm_strided_views_two_residuals_rowvec_alpha(ops):
     assert rel_l2(out, ref) < TOL_BF16
 
 
-@pytest.mark.parametrize("tile", [0, 2, 4, 7, 9, 19, 20, 22, 25])
+@pytest.mark.parametrize("tile", [0, 2, 4, 7, 9, 19, 20, 24, 25])
 @pytest.mark.parametrize("M,N,K1,K2", [(512, 320, 640, 320), (8, 160, 160, 160), (200, 80, 160, 80), (1000, 1280, 1280, 640)])
 def test_gemm_two_source_concat(ops, tile, M, N, K1, K2):
     a1, a2 = rnd(M, K1, seed=1), rnd(M, K2, seed=2)
@@ -298,7 +298,46 @@ def test_gemm_layernorm_fusion(ops, tile, split):
         assert rel_l2(yb, refb) < TOL_BF16
 
 
-@pytest.mark.parametrize("tile,split", [(4, 2), (6, 4), (7, 3), (9, 2), (8, 5), (20, 4), (22, 2), (25, 3), (19, 2), (24, 3), (30, 3), (31, 2), (32, 3), (38, 2)])
+@pytest.mark.parametrize("tile,split", [(0, 1), (3, 1), (6, 1), (11, 1), (14, 1), (20, 1), (7, 2), (24, 4), (61, 1), (63, 1), (66, 1), (65, 2)])
+def test_gemm_layernorm_fusion_with_frame_positions(ops, tile, split):
+    """LayerNorm(h + pos[frame]) folded into the GEMMs around it (norm_temp of the temporal attention,
+    ff_spatio_audio_temp_transformer_3d.py:346-356): the producer's statistics are those of (rounded h + stats_pos[frame]) while h itself
+    is stored unchanged, and the consumer reads the raw h with pos . W'^T added inside the rstd scaling (ln_rowvec)."""
+    torch.manual_seed(0)
+    B, Fr, hw, C, N = 2, 12, 40, 640, 1920
+    M = B * Fr * hw
+    a = rnd(M, C, seed=1)
+    wp = (0.05 * torch.randn(C, C, device=dev())).bfloat16()
+    res = rnd(M, C, seed=2) * 3 + 1.5
+    pos = torch.randn(Fr, C, device=dev()) * 0.7 + 0.2
+    frame = (torch.arange(M, device=dev()) // hw) % Fr
+    stats, plain = torch.empty(M, C // 32, 2, device=dev()), torch.empty(M, C // 32, 2, device=dev())
+    bias = torch.randn(C, device=dev())
+    h = ops.gemm(a, wp, bias=bias, res1=res, rowstats=stats, stats_pos=(pos, hw, Fr), tile=tile, split_k=split)
+    assert torch.equal(h, ops.gemm(a, wp, bias=bias, res1=res, rowstats=plain, tile=tile, split_k=split))      # the output does not see pos
+    u = (h.float() + pos[frame]).reshape(M, C // 32, 32)
+    assert torch.allclose(stats[..., 0], u.sum(-1), atol=2e-3, rtol=1e-5) and torch.allclose(stats[..., 1], (u * u).sum(-1), rtol=1e-5, atol=1e-3)
+    assert not torch.equal(stats, plain)
+    g, be = 1 + 0.2 * torch.randn(C, device=dev()), 0.3 * torch.randn(C, device=dev())
+    w = 0.05 * torch.randn(N, C, device=dev())
+    wf = (w * g).bfloat16()
+    colsum = wf.float().sum(1)
+    bias2 = w @ be
+    posw = ops.linear_small_m(pos, wf, None)
+    assert rel_l2(posw, pos @ wf.float().T) < 1e-5
+    y = ops.gemm(h, wf, bias=bias2, ln=(stats, colsum, 1e-5), ln_pos=(posw, hw, Fr), tile=tile, split_k=split)
+    ref = F.layer_norm(h.float() + pos[frame], (C,), g, be, 1e-5) @ w.T
+    assert rel_l2(y, ref) < TOL_BF16
+    # and it is the LayerNorm kernel + plain GEMM path within the 16-bit rounding of the normalised tensor
+    nt = ops.layernorm(h, g, be, pos=pos, hw=hw, frames=Fr)
+    assert rel_l2(y, ops.gemm(nt, w.bfloat16())) < TOL_BF16
+    with pytest.raises((RuntimeError, ValueError)):
+        ops.gemm(h, wf, bias=bias2, ln_pos=(posw, hw, Fr), tile=tile)            # ln_rowvec without the LayerNorm fold
+    with pytest.raises((RuntimeError, ValueError)):
+        ops.gemm(a, wp, stats_pos=(pos, hw, Fr), tile=tile)                      # stats_pos without rowstats
+
+
+@pytest.mark.parametrize("tile,split", [(4, 2), (6, 4), (7, 3), (9, 2), (14, 5), (20, 4), (25, 3), (19, 2), (24, 3), (30, 3), (31, 2), (38, 2)])
 def test_gemm_split_k(ops, tile, split):
     from asva_amd.weights import pack_conv3x3
 
@@ -658,6 +697,14 @@ def test_cross_attention_block_matches_separate_kernels_and_fp32(ops, kind, lk, 
     assert torch.allclose(stats_out[..., 0], ob.sum(-1), atol=1e-3, rtol=1e-5) and torch.allclose(stats_out[..., 1], (ob * ob).sum(-1), atol=1e-2, rtol=1e-5)
     if f32_res:
         assert rel_l2(master, ref) < 2e-3 and rel_l2(master.to(torch.bfloat16), out) < 1e-6
+    # statistics of out + pos[frame] (the LayerNorm of the temporal attention, folded): same output bits, shifted statistics
+    pos = rndf(Fr, C, seed=12)
+    stats_pos = torch.empty_like(stats)
+    out2 = ops.cross_attention_block(h, stats, wq_f, q_colsum, q_bias, k_pad, vt_pad, lk, wo, bo, res=res, heads=heads, L=L,
+                                     q_per_kv=q_per_kv, rowstats=stats_pos, stats_pos=(pos, L, Fr))
+    assert torch.equal(out2, out)
+    up = (out.float() + pos[(torch.arange(M, device=dev()) // L) % Fr]).reshape(M, C // 32, 32)
+    assert torch.allclose(stats_pos[..., 0], up.sum(-1), atol=1e-3, rtol=1e-5) and torch.allclose(stats_pos[..., 1], (up * up).sum(-1), atol=1e-2, rtol=1e-5)
 
 
 # ---- FP8 (e4m3) Q/K/V attention: BASELINE cfg 5 -----------------------------------------------------------------------

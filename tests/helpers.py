@@ -29,8 +29,20 @@ def filled_unet(cfg, dtype=torch.float32, heavy_tail=False):
     from oracle.filler import fill_module_
 
     m = AudioUNet3DConditionModel.from_config(cfg).eval()
-    fill_module_(m, heavy_tail=heavy_tail)
+    # the SD1.5-shaped model is filled a dozen times per session (1.17 B values from a single-threaded generator, ~5 s each):
+    # keep the last filled state_dict of a configuration and copy it
+    key = (json.dumps(dict(cfg), sort_keys=True, default=str), bool(heavy_tail))
+    if _FILLED.get("key") == key:
+        m.load_state_dict(_FILLED["sd"])
+    else:
+        fill_module_(m, heavy_tail=heavy_tail)
+        if sum(p.numel() for p in m.parameters()) > 100_000_000:
+            _FILLED.clear()
+            _FILLED.update(key=key, sd={k: v.detach().clone() for k, v in m.state_dict().items()})
     return m.to(dtype)
+
+
+_FILLED: dict = {}
 
 
 def bf16_round_state_dict(sd):

@@ -20,7 +20,8 @@ SOURCES = ["lib.hip", "attention.hip", "attention_x2.hip", "gemm_f32.hip", "gemm
 # gemm.hip instantiates ~290 kernels: compiled as six translation units (one per A-loader mode, the entry point, and two for
 # the split-precision tiles)
 GEMM_UNITS = 6
-HEADERS = [os.path.join(CSRC, "avsd_common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(HERE, "..", "include", "avsd.h")]
+HEADERS = [os.path.join(CSRC, "avsd_common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "gemm4_loops.inc"),
+           os.path.join(HERE, "..", "include", "avsd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

@@ -11,6 +11,7 @@ Register map (per lane): v0-v31 stay the compiler's; from v32: vector offsets VA
 stage x plane), fragment sets XF[sets][planes][FM] WF[sets][planes][FN] (4 registers each), staging G[NSTG][planes][NA + NW]
 (4 registers each), and for tmix the per-vector segment jumps D01[NA] D12[NA].
 """
+import os
 import sys
 
 ROWB = 144
@@ -241,11 +242,16 @@ def gen(FM, FN, NSTG, mfma_op, ablate="", deep=None, tmix=False, planes=1, base=
                 if "b" not in ablate:
                     emit("s_barrier")
             elif deep:
-                emit(f"s_waitcnt lgkmcnt({(NFR + nwr) * P})")   # the reads issued ONE k-step earlier (older than this k-step's) are in
+                # the reads issued ONE k-step earlier (older than this k-step's) are in.  lgkmcnt is a 4-bit counter: with this k-step's operations
+                # still out and the next k-step's on top, the 128 x 128 tile could stand at 16 if LDS answered nothing for a whole k-step.  Never
+                # more than 15 outstanding, whatever LDS does (`worst` below checks the whole stream and inserts waits where a burst exceeds it).
+                nwr_next = max(0, min(WPK, NL - (ks + 1) * WPK)) if ks + 1 < NWK else 0
+                emit(f"s_waitcnt lgkmcnt({min((NFR + nwr) * P, 15 - (NFR + nwr_next) * P)})")
             elif ks == 3:
                 emit("s_waitcnt lgkmcnt(0)")
             else:
-                emit(f"s_waitcnt lgkmcnt({nwr * P})")
+                nwr_next = max(0, min(WPK, NL - (ks + 1) * WPK)) if ks + 1 < NWK else 0
+                emit(f"s_waitcnt lgkmcnt({min(nwr * P, 15 - (NFR + nwr_next) * P)})")
 
     # K tile t multiplies LDS stage t & 1 and refills staging set (t + 1) % NSTG: the loop body repeats every L = lcm(2, NSTG) tiles
     import math
@@ -265,9 +271,42 @@ def gen(FM, FN, NSTG, mfma_op, ablate="", deep=None, tmix=False, planes=1, base=
             emit("s_cmp_lt_u32 %[t], %[nk]")
             emit("s_cbranch_scc1 L_loop_%=")
     emit("L_end_%=:")
-    emit("s_waitcnt vmcnt(0)")
+    # NOTHING may be in flight when the block ends: on the exit paths of the deep schedule the fragment prefetch of the (non-existent)
+    # next K tile is still out, and a ds_read that lands AFTER the block overwrites whatever the compiler has put into those VGPRs by
+    # then (it only knows them as clobbered: the epilogue keeps accumulator values there).  Found as 1-2 % grossly wrong launches of
+    # the 128 x 128 / 64 x 128 tiles — always the same accumulator registers — once a second process kept the CUs' LDS busy
+    # (tests/test_determinism_gpu.py runs its two children side by side since round 4); never on an exclusive GPU, where the data
+    # lands within the two s_nop below.  36 000 contended launches clean with this wait.
+    emit("s_waitcnt vmcnt(0) lgkmcnt(0)")
     emit("s_nop 15")
     emit("s_nop 15")
+
+    # worst case of the two memory counters over the whole instruction stream (nothing completes until a wait forces it; the loop body
+    # walked twice): lgkmcnt holds 0..15, vmcnt 0..63, and both WRAP
+    def worst(prefix, wait_re, limit, fix=None):
+        import re
+        while True:
+            lo = next(i for i, ln in enumerate(out) if ln.startswith("L_loop_"))
+            hi = next(i for i, ln in enumerate(out) if ln.startswith("L_end_"))
+            cnt = peak = 0
+            over = None
+            for i in list(range(hi)) + list(range(lo, hi)):
+                ln = out[i]
+                m = re.match(wait_re, ln)
+                if m:
+                    cnt = min(cnt, int(m.group(1)))
+                elif ln.startswith(prefix):
+                    cnt += 1
+                    peak = max(peak, cnt)
+                    if cnt > limit:
+                        over = i
+                        break
+            if over is None:
+                return peak
+            assert fix is not None, (FM, FN, P, tmix, prefix, peak)
+            out.insert(over, fix)               # the oldest operation completes before this one is issued
+    worst(("ds_read", "ds_write"), r"s_waitcnt lgkmcnt\((\d+)\)", 15, "s_waitcnt lgkmcnt(14)")
+    worst(("buffer_load",), r"s_waitcnt vmcnt\((\d+)\)", 63)
 
     name = f"g4_loop_{FM}x{FN}_s{NSTG}" + (f"_ab_{ablate}" if ablate else "") + ("_tmix" if tmix else "") + ("_x2" if P == 2 else "")
     nacc = FM * FN

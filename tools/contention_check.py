@@ -49,8 +49,16 @@ def main():
         for _ in range(a.rounds):
             out = unet(xin, 981, t2, a2, audio_attention_mask=audio_segment_mask(12)).sample
             hashes.append(hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:12])
-        print("UNet forward hashes:", hashes, flush=True)
-        ok = total == 0 and len(set(hashes)) == 1
+        print("UNet forward hashes:", sorted(set(hashes)), f"over {a.rounds} rounds", flush=True)
+        # the VAE decode of a clip (resident 3x3 convolution tiles, wide-head attention, GroupNorm at 256 x 256)
+        from asva_amd.vae import AutoencoderKL
+        torch.manual_seed(1)
+        with torch.device(dev):
+            vae = AutoencoderKL(**bench.SD15_VAE).eval()
+        z = torch.randn(12, 4, 32, 32, device=dev)
+        vh = [hashlib.sha256(vae.decode(z, postprocess="uint8", return_dict=False)[0].cpu().numpy().tobytes()).hexdigest()[:12] for _ in range(max(2, a.rounds // 4))]
+        print("VAE decode hashes:", sorted(set(vh)), f"over {len(vh)} rounds", flush=True)
+        ok = total == 0 and len(set(hashes)) == 1 and len(set(vh)) == 1
         print("CONTENTION CHECK", "OK" if ok else "FAILED", flush=True)
         return 0 if ok else 1
     finally:

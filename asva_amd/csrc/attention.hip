@@ -701,6 +701,8 @@ int launch_tattn(const TAttnArgs& a0, int B, hipStream_t s) {
     while (a.hpb > 1 && a.hpb % 2 == 0 && (size_t)a.frames * 2 * a.hpb * D * sizeof(h16_t) * 2 > 160 * 1024) a.hpb /= 2;
   }
   const size_t lds = (size_t)a.frames * 2 * a.hpb * D * sizeof(h16_t) * (X2 ? 2 : 1);
+  AVSD_REQUIRE(lds <= 160 * 1024, "temporal attention: K / V of %d frames x %d heads per workgroup x %d channels need %zu B of LDS (160 KB; the head count per "
+               "workgroup only halves while it is even)", a.frames, a.hpb, D, lds);
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tattn_kernel<D, FMAX, X2>),

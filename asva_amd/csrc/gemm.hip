@@ -977,6 +977,8 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
     if (d.split_k > 1) AVSD_REQUIRE(d.splitk_ws != nullptr, "gemm: split_k needs a workspace");
     return avsd_gemm_dispatch_conv3r(d, reinterpret_cast<hipStream_t>(stream));
   }
+  // every kernel below reads the A operand of a convolution / temporal mix from ONE buffer: a second source would be ignored silently
+  AVSD_REQUIRE(d.mode == AVSD_GEMM_PLAIN || !d.A2, "gemm: a two-source A needs the PLAIN mode or a resident convolution tile (40..54), got mode %d tile %d", d.mode, d.tile);
   const bool asm_tile = d.tile >= AVSD_GEMM_TILE_ASM_FIRST && d.tile <= AVSD_GEMM_TILE_ASM_LAST;
   if (asm_tile && !(d.flags & AVSD_GEMM_X2)) return avsd_gemm_dispatch_asm(d, reinterpret_cast<hipStream_t>(stream));
   if (d.split_k > 1 && !asm_tile) {

@@ -254,6 +254,11 @@ def test_gemm_conv3_resident_refuses_other_convolutions(ops):
         ops.gemm(rnd(2 * 16 * 16, 32, seed=1), pack_conv3x3(rnd(64, 32, 3, 3, seed=2)), mode=ops.CONV3, conv=(2, 16, 16, 1, 0), tile=44)
     with pytest.raises(RuntimeError):                                                # more slices than chunks
         ops.gemm(x, wp, mode=ops.CONV3, conv=(2, 16, 16, 1, 0), tile=44, split_k=2)
+    # a two-source convolution on a tile that reads one buffer (tap-major LDS-direct, asm): refused at the C ABI, not half-read
+    x2, w2 = rnd(2 * 16 * 16, 128, seed=3), pack_conv3x3(rnd(64, 128, 3, 3, seed=4))
+    for t in (9, 25):
+        with pytest.raises((RuntimeError, ValueError), match="two-source"):
+            ops.gemm(x2[:, :64].contiguous(), w2, a2=x2[:, 64:].contiguous(), mode=ops.CONV3, conv=(2, 16, 16, 1, 0), tile=t)
 
 
 @pytest.mark.parametrize("tile,split", [(0, 1), (3, 1), (6, 1), (13, 1), (17, 1), (20, 1), (25, 1), (7, 2), (24, 4), (63, 1), (65, 2)])

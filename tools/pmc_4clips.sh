@@ -7,5 +7,5 @@ done
 M=$(find /tmp/pmc4_SQ_VALU_MFMA_BUSY_CYCLES -name "*.db" | head -1)
 F=$(find /tmp/pmc4_FETCH_SIZE -name "*.db" | head -1)
 W=$(find /tmp/pmc4_WRITE_SIZE -name "*.db" | head -1)
-python tools/pmc_step.py $M $F $W --skip 1 > gpurun_out/r3_pmc_step_4clips.md
-cat gpurun_out/r3_pmc_step_4clips.md
+python tools/pmc_step.py $M $F $W --skip 1 > gpurun_out/r4_pmc_step_4clips.md
+cat gpurun_out/r4_pmc_step_4clips.md

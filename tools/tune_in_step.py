@@ -31,7 +31,13 @@ def main():
     ap.add_argument("--reps", type=int, default=15)
     ap.add_argument("--max-keys", type=int, default=80)
     ap.add_argument("--clips", type=int, default=1)
+    ap.add_argument("--modes", default="0,1,2", help="A-loader modes of the keys to visit: 0 plain, 1 temporal mix, 2 conv3x3")
+    ap.add_argument("--split", action="store_true", help="tune the split-precision step (AVSD_GEMM_X2 keys)")
     a = ap.parse_args()
+    if a.split:
+        from asva_amd import precision as P
+
+        P.set_split(True)
     dev = torch.device("cuda", 0)
     unet = bench.build_unet(dev, 0, 1)
     lat, text, audio, null_audio = bench.synthetic_clip(dev, 1000, n=a.clips)
@@ -65,7 +71,8 @@ def main():
     base = step_ms(a.reps)
     noise = abs(step_ms(a.reps) - base)
     print(f"{len(keys)} table keys in one forward; step {base:.4f} ms (repeat differs by {noise * 1e3:.1f} us)", flush=True)
-    order = sorted((k for k in keys if keys[k]["n"] >= a.min_launches and k in table), key=lambda k: -keys[k]["n"] * keys[k]["flops"])[:a.max_keys]
+    modes = {int(m) for m in a.modes.split(",")}
+    order = sorted((k for k in keys if keys[k]["n"] >= a.min_launches and k in table and k[0] in modes), key=lambda k: -keys[k]["n"] * keys[k]["flops"])[:a.max_keys]
     t0 = time.time()
     changed = []
     for k in order:
@@ -74,7 +81,8 @@ def main():
         best_c, best_t = inc, cur
         tried = 0
         # shortlist: the asm tiles and the staple LDS-direct tiles (the isolated tuner already ranked the rest)
-        short = [c for c in keys[k]["cands"] if c[0] >= 60 or (c[0] in (7, 11, 13, 20, 24, 25, 30) and c[1] <= 2)]
+        # (+ every resident-convolution tile / split the geometry admits; split precision: its own short tile list)
+        short = [c for c in keys[k]["cands"] if c[0] >= 40 or (c[0] in (7, 11, 13, 20, 24, 25, 30, 34, 35, 36) and c[1] <= (8 if a.split else 2))]
         for c in short:
             if c == inc:
                 continue

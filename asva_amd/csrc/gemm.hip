@@ -298,8 +298,17 @@ __device__ __forceinline__ unsigned a_voffset(const avsd_gemm_desc& p, const Row
 // X2 (AVSD_GEMM_X2, split precision): every operand is a (main, rest) pair of planes.  A stage holds both planes of both
 // operands ([A | W | A rest | W rest]; the rest planes are fetched with the same per-lane offsets through a second buffer
 // descriptor), and every fragment pair contributes three MFMAs: W.A + Wr.A + W.Ar.
+// waves per SIMD the tile's LDS footprint admits, capped at 3: the second __launch_bounds__ argument (HIP: minimum waves per execution
+// unit).  Without it the 128 x 128 x 4-wave tile (64 KB: two workgroups per CU) compiled to 193 + 64 = 257 registers — one wave per
+// SIMD, half its occupancy — after an unrelated epilogue change.
+constexpr int gemm2_min_waves(int bm, int bn, int stages, bool x2, int waves) {
+  const int lds = stages * (bm + bn) * 128 * (x2 ? 2 : 1);
+  const int wgs = (160 * 1024) / lds < 1 ? 1 : (160 * 1024) / lds;
+  const int w = (wgs * waves + 3) / 4;
+  return w > 3 ? 3 : w;
+}
 template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int LW = 0, bool X2 = false>
-__global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm2_kernel(const avsd_gemm_desc p) {
+__global__ __launch_bounds__(64 * (WM * WN + LW), gemm2_min_waves(BM, BN, STAGES, X2, WM * WN + LW)) void gemm2_kernel(const avsd_gemm_desc p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem2[];
   constexpr int NC = WM * WN;               // MFMA waves
   constexpr int NWAVES = LW > 0 ? LW : NC;  // waves that issue loads
@@ -620,7 +629,34 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm2_kernel(const avsd_g
                 make_float4(acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]);
         }
     }
-    return;      // splitk_reduce_kernel folds the slabs and applies the epilogue
+    // splitk_reduce_kernel folds the slabs and applies the epilogue.  The fold below is NEVER taken (avsd_gemm_bf16 refuses a split_k
+    // beyond the K tiles): it is what is left of round 3's in-launch reduction, kept because of what it does to the register allocator —
+    // with a path that redefines every accumulator between the main loop and the epilogue, hipcc 7.2 gives the same kernels 12-56
+    // fewer VGPRs (128x128x8w: 201 -> 168 = 3 waves per SIMD, 256x128 + loader waves: 137 -> 125 = 4, 256x320: 96 spilled
+    // registers -> 4); without it the VAE decode lost 12 % and cfg 4 10 % between round 3 and round 4 (found with
+    // -Rpass-analysis=kernel-resource-usage against the round-3 tree; same-box A/B in profiles/r4_regalloc_ab.txt).
+    if (p.split_k != 0x7fffffff) return;
+#pragma unroll
+    for (int a = 0; a < FN; ++a)
+#pragma unroll
+      for (int b = 0; b < FM; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    for (int sl = 0; sl < nsplit; ++sl) {
+      const float* slab = p.splitk_ws + (int64_t)sl * p.M * p.N;
+#pragma unroll
+      for (int b = 0; b < FM; ++b) {
+        const int m = min(tm * BM + wm * (BM / WM) + b * 32 + (lane & 31), p.M - 1);
+#pragma unroll
+        for (int a = 0; a < FN; ++a)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int n = min(tn * BN + wn * (BN / WN) + a * 32 + 8 * q + hsel, p.N - 4);
+            const float4 v = *reinterpret_cast<const float4*>(slab + (int64_t)m * p.N + n);
+            acc[a][b][4 * q] += v.x; acc[a][b][4 * q + 1] += v.y; acc[a][b][4 * q + 2] += v.z; acc[a][b][4 * q + 3] += v.w;
+          }
+      }
+    }
   }
   if constexpr (X2) epilogue_x2<FN, FM>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
   else epilogue<FN, FM, (64 * (WM * WN + LW) > 512)>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);

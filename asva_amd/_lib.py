@@ -39,7 +39,7 @@ class GemmDesc(C.Structure):
         ("tile", C.c_int32),
         ("split_k", C.c_int32), ("splitk_ws", c_void_p),
         ("rowstats", c_void_p), ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("ln_nblk", C.c_int32), ("ln_eps", C.c_float),
-        ("out_master", c_void_p), ("ldm", C.c_int32), ("reserved0", C.c_int32),
+        ("out_master", c_void_p), ("ldm", C.c_int32), ("raster_g", C.c_int32),
         ("a_lo", C.c_int64), ("a2_lo", C.c_int64), ("w_lo", C.c_int64), ("out_lo", C.c_int64), ("res1_lo", C.c_int64),
         ("res2_lo", C.c_int64),
         ("stats_pos", c_void_p), ("ln_rowvec", c_void_p), ("pos_hw", C.c_int32), ("pos_frames", C.c_int32),

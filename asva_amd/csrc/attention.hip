@@ -566,6 +566,8 @@ int launch_attn_wide(const AttnArgs& a, int Bq, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
 struct TAttnArgs {
   const h16_t* QKV; h16_t* O;
   int64_t qkv_lo, o_lo;   // split-precision planes (avsd_common.h): offsets to the rest planes, 0 = single plane
@@ -576,17 +578,23 @@ struct TAttnArgs {
 
 // One thread per (head, query frame, d-slice): the head dimension is cut into DS slices of SL channels held by DS
 // adjacent lanes (partial dot products are summed with 1-2 shuffles), so d = 160 runs 4x the threads of d = 40.
-template <int D, int FMAX, bool X2>
-__global__ __launch_bounds__(1024) void tattn_kernel(const TAttnArgs p) {
+// EXACT: frames == FMAX at compile time (the step's 12 frames, cfg 4's 24) and at most 256 threads: no per-key guards, and the
+// 256-register budget of a 256-thread bound (the fully unrolled form spills under the 128 registers of a 1024-thread bound).
+// Round 5: the K / V staging issues ALL of a thread's loads (<= U per pass) before the first LDS store — the earlier
+// `for (v ...) sKV[v] = g[v]` loop compiled to load / s_waitcnt vmcnt(0) / ds_write per iteration, 7-8 dependent HBM round trips per
+// workgroup (26 us for 63 MB at the 32 x 32 level: 2.4 TB/s); and the score dot products run as two independent chains.
+template <int D, int FMAX, bool X2, bool EXACT>
+__global__ __launch_bounds__(EXACT ? 256 : 1024) void tattn_kernel(const TAttnArgs p) {
   constexpr int SL = (D % 40 == 0) ? 40 : 32;   // slice length
   constexpr int DS = D / SL;                    // 1, 2 or 4 lanes per (head, frame)
   constexpr int NV = SL / 8;                    // 16-byte vectors per slice
+  constexpr int U = X2 ? 4 : 8;                 // staging vectors in flight per thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_t[];
   h16_t* sKV = reinterpret_cast<h16_t*>(smem_t);  // [frames][2*C] : k | v
   const int C = p.heads * D;
   const int Cg = p.hpb * D;             // channels of this workgroup's head group
   const int c0g = blockIdx.y * Cg;      // first channel of the group
-  const int F = p.frames;
+  const int F = EXACT ? FMAX : p.frames;
   const int b = blockIdx.x / p.hw;
   const int pix = blockIdx.x - b * p.hw;
   const int64_t row0 = ((int64_t)b * F) * p.hw + pix;  // row of frame f = row0 + f*hw
@@ -614,38 +622,68 @@ __global__ __launch_bounds__(1024) void tattn_kernel(const TAttnArgs p) {
 
   const int vec_per_row = 2 * Cg / 8;   // [k slice | v slice] of the group
   h16_t* sKVr = sKV + F * 2 * Cg;       // X2: the rest planes of the same rows
-  for (int v = tid; v < F * vec_per_row; v += blockDim.x) {
-    const int f = v / vec_per_row;
-    const int cv = (v - f * vec_per_row) * 8;
-    const int src = cv < Cg ? C + c0g + cv : 2 * C + c0g + (cv - Cg);
-    const h16_t* g = p.QKV + (row0 + (int64_t)f * p.hw) * p.ldqkv + src;
-    *reinterpret_cast<uint4*>(sKV + f * 2 * Cg + cv) = *reinterpret_cast<const uint4*>(g);
-    if constexpr (X2) *reinterpret_cast<uint4*>(sKVr + f * 2 * Cg + cv) = *reinterpret_cast<const uint4*>(g + p.qkv_lo);
+  const int total = F * vec_per_row;
+  const int nthr = blockDim.x;
+  for (int base = tid; base < total; base += U * nthr) {
+    u32x4v t[U], tr[X2 ? U : 1];
+    int dst[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int v = min(base + u * nthr, total - 1);          // (clamped: the load is unconditional, the store is not)
+      const int f = v / vec_per_row;
+      const int cv = (v - f * vec_per_row) * 8;
+      const int src = cv < Cg ? C + c0g + cv : 2 * C + c0g + (cv - Cg);
+      const h16_t* g = p.QKV + (row0 + (int64_t)f * p.hw) * p.ldqkv + src;
+      dst[u] = f * 2 * Cg + cv;
+      // (volatile: hipcc otherwise sinks each load next to its store — one s_waitcnt vmcnt(0) per vector; the loads must all be
+      // issued before the first store)
+      t[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4v*>(g));
+      if constexpr (X2) tr[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4v*>(g + p.qkv_lo));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (base + u * nthr < total) {
+        *reinterpret_cast<u32x4v*>(sKV + dst[u]) = t[u];
+        if constexpr (X2) *reinterpret_cast<u32x4v*>(sKVr + dst[u]) = tr[u];
+      }
+    }
   }
   __syncthreads();
 
+  float a[NV][8];
+#pragma unroll
+  for (int d = 0; d < NV; ++d) {
+    unpack8(qv[d], a[d]);
+    if constexpr (X2) {
+      float a2[8];
+      unpack8(qr[d], a2);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[d][e] += a2[e];
+    }
+  }
   float sc[FMAX];
   float mx = -1e30f;
 #pragma unroll
   for (int j = 0; j < FMAX; ++j) {
     float dot = 0.f;
-    if (j < F) {
+    if (EXACT || j < F) {
       const h16_t* krow = sKV + j * 2 * Cg + loff;
+      float d0 = 0.f, d1 = 0.f;         // two chains: even / odd channels
 #pragma unroll
       for (int d = 0; d < NV; ++d) {
-        float a[8], k[8];
-        unpack8(qv[d], a);
+        float k[8];
         unpack8(*reinterpret_cast<const uint4*>(krow + d * 8), k);
         if constexpr (X2) {
-          float a2[8], k2[8];
-          unpack8(qr[d], a2);
+          float k2[8];
           unpack8(*reinterpret_cast<const uint4*>(krow + (sKVr - sKV) + d * 8), k2);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { a[e] += a2[e]; k[e] += k2[e]; }
+          for (int e = 0; e < 8; ++e) k[e] += k2[e];
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dot = fmaf(a[e], k[e], dot);
+        for (int e = 0; e < 8; e += 2) { d0 = fmaf(a[d][e], k[e], d0); d1 = fmaf(a[d][e + 1], k[e + 1], d1); }
       }
+      dot = d0 + d1;
 #pragma unroll
       for (int o = DS / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
       dot *= p.scale;
@@ -656,7 +694,7 @@ __global__ __launch_bounds__(1024) void tattn_kernel(const TAttnArgs p) {
   float sum = 0.f;
 #pragma unroll
   for (int j = 0; j < FMAX; ++j) {
-    const float e = (j < F) ? __expf(sc[j] - mx) : 0.f;
+    const float e = (EXACT || j < F) ? __expf(sc[j] - mx) : 0.f;
     sc[j] = e;
     sum += e;
   }
@@ -671,7 +709,7 @@ __global__ __launch_bounds__(1024) void tattn_kernel(const TAttnArgs p) {
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
 #pragma unroll
     for (int j = 0; j < FMAX; ++j) {
-      if (j < F) {
+      if (EXACT || j < F) {
         float vv[8];
         unpack8(*reinterpret_cast<const uint4*>(sKV + j * 2 * Cg + Cg + loff + d * 8), vv);
         if constexpr (X2) {
@@ -690,6 +728,23 @@ __global__ __launch_bounds__(1024) void tattn_kernel(const TAttnArgs p) {
   }
 }
 
+template <int D, int FMAX, bool X2, bool EXACT>
+int launch_tattn_e(const TAttnArgs& a, int B, size_t lds, int threads, hipStream_t s) {
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tattn_kernel<D, FMAX, X2, EXACT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      avsd_set_error("temporal attention: %zu B LDS: %s", lds, hipGetErrorString(e));
+      return AVSD_ELAUNCH;
+    }
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL((tattn_kernel<D, FMAX, X2, EXACT>), dim3((unsigned)(B * a.hw), (unsigned)(a.heads / a.hpb)), dim3(threads), lds, s, a);
+  AVSD_CHECK_LAUNCH("temporal attention launch");
+  return AVSD_OK;
+}
+
 template <int D, int FMAX, bool X2>
 int launch_tattn(const TAttnArgs& a0, int B, hipStream_t s) {
   constexpr int DS = D / ((D % 40 == 0) ? 40 : 32);
@@ -703,24 +758,13 @@ int launch_tattn(const TAttnArgs& a0, int B, hipStream_t s) {
   const size_t lds = (size_t)a.frames * 2 * a.hpb * D * sizeof(h16_t) * (X2 ? 2 : 1);
   AVSD_REQUIRE(lds <= 160 * 1024, "temporal attention: K / V of %d frames x %d heads per workgroup x %d channels need %zu B of LDS (160 KB; the head count per "
                "workgroup only halves while it is even)", a.frames, a.hpb, D, lds);
-  static size_t attr_lds = 0;
-  if (lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tattn_kernel<D, FMAX, X2>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      avsd_set_error("temporal attention: %zu B LDS: %s", lds, hipGetErrorString(e));
-      return AVSD_ELAUNCH;
-    }
-    attr_lds = lds;
-  }
   int threads = (a.hpb * a.frames * DS + 63) / 64 * 64;
   if (threads > 1024) {
     avsd_set_error("temporal attention: heads*frames*%d = %d threads exceeds 1024", DS, a.hpb * a.frames * DS);
     return AVSD_EINVAL;
   }
-  hipLaunchKernelGGL((tattn_kernel<D, FMAX, X2>), dim3((unsigned)(B * a.hw), (unsigned)(a.heads / a.hpb)), dim3(threads), lds, s, a);
-  AVSD_CHECK_LAUNCH("temporal attention launch");
-  return AVSD_OK;
+  if (a.frames == FMAX && threads <= 256) return launch_tattn_e<D, FMAX, X2, true>(a, B, lds, threads, s);
+  return launch_tattn_e<D, FMAX, X2, false>(a, B, lds, threads, s);
 }
 
 template <int D>

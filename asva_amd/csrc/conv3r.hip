@@ -92,7 +92,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void conv3r_kernel(const avsd_
     ksplit = c - wg * nsplit;
   }
   int tm, tn;
-  tile_of_item(wg, ntm, ntn, (p.flags & AVSD_GEMM_XCD_N) != 0, p.reserved0, tm, tn);
+  tile_of_item(wg, ntm, ntn, (p.flags & AVSD_GEMM_XCD_N) != 0, p.raster_g, tm, tn);
   const int m0 = tm * BM;
   const int ws = p.ws;
   const int ar = BM + 2 * ws;                 // staged rows
@@ -302,8 +302,13 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void conv3r_kernel(const avsd_
     }
     return;
   }
-  const float pre_ln[2 * FM] = {};
-  epilogue<FN, FM, (64 * (WM * WN + LW) > 512)>(p, acc, m0 + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, 0, pre_ln, false);
+  if constexpr (FN * FM >= 8) {      // (the resident tiles never fold a LayerNorm: ops.gemm offers them only when ln is None)
+    const float pre_ln[2 * FM] = {};
+    epilogue_each<FN, FM, (64 * (WM * WN + LW) > 512)>(p, acc, m0 + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, 0, pre_ln, false);
+  } else {
+    const float pre_ln[2 * FM] = {};
+    epilogue<FN, FM, (64 * (WM * WN + LW) > 512)>(p, acc, m0 + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, 0, pre_ln, false);
+  }
 }
 
 // ---- 2-D tiles: TH image rows x 32 pixels --------------------------------------------------------------------------------
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void conv3r2d_kernel(const avs
     ksplit = c - wg * nsplit;
   }
   int tm, tn;
-  tile_of_item(wg, ntm, ntn, (p.flags & AVSD_GEMM_XCD_N) != 0, p.reserved0, tm, tn);
+  tile_of_item(wg, ntm, ntn, (p.flags & AVSD_GEMM_XCD_N) != 0, p.raster_g, tm, tn);
   const int img = tm / tpi;
   const int trem = tm - img * tpi;
   const int ty0 = (trem / tpr) * TH, tx0 = (trem % tpr) * 32;
@@ -529,8 +534,13 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void conv3r2d_kernel(const avs
     }
     return;
   }
-  const float pre_ln[2 * FM] = {};
-  epilogue<FN, FM, (64 * (WM * WN + LW) > 512)>(p, acc, m_wave, tn * BN + wn * (BN / WN), lane, 0, pre_ln, false, W);
+  if constexpr (FN * FM >= 8) {
+    const float pre_ln[2 * FM] = {};
+    epilogue_each<FN, FM, (64 * (WM * WN + LW) > 512)>(p, acc, m_wave, tn * BN + wn * (BN / WN), lane, 0, pre_ln, false, W);
+  } else {
+    const float pre_ln[2 * FM] = {};
+    epilogue<FN, FM, (64 * (WM * WN + LW) > 512)>(p, acc, m_wave, tn * BN + wn * (BN / WN), lane, 0, pre_ln, false, W);
+  }
 }
 
 template <int BM, int BN, int WM, int WN, int STAGES, int LW>

@@ -353,7 +353,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW), gemm2_min_waves(BM, BN, STAGES
   // fetches that band of A once while EVERY XCD streams all of W.  AVSD_GEMM_XCD_N: column-major, an XCD covers a
   // band of N — W is fetched once chip-wide and A by every XCD (the host picks whichever operand is larger).
   int tm, tn;
-  tile_of_item(wg, ntm, ntn, (p.flags & AVSD_GEMM_XCD_N) != 0, p.reserved0, tm, tn);
+  tile_of_item(wg, ntm, ntn, (p.flags & AVSD_GEMM_XCD_N) != 0, p.raster_g, tm, tn);
   const int64_t bz = blockIdx.z;
   // split-K: this workgroup owns K tiles [kt0, kt1)
   const int nk_all = (p.K + BK - 1) / BK;
@@ -659,6 +659,8 @@ __global__ __launch_bounds__(64 * (WM * WN + LW), gemm2_min_waves(BM, BN, STAGES
     }
   }
   if constexpr (X2) epilogue_x2<FN, FM>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
+  else if constexpr (FN * FM >= 10)      // 64 x 160 wave tiles (tile 19): the 10-fragment epilogue is not unrolled -> accumulators in scratch (gemm_common.h)
+    epilogue_each<FN, FM, (64 * (WM * WN + LW) > 512)>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
   else epilogue<FN, FM, (64 * (WM * WN + LW) > 512)>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
 }
 
@@ -965,6 +967,7 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
   AVSD_REQUIRE(d.N % 4 == 0 && d.ldc % 4 == 0, "gemm: N (%d) and ldc (%d) must be multiples of 4", d.N, d.ldc);
   AVSD_REQUIRE(d.lda % 8 == 0, "gemm: lda (%d) must be a multiple of 8", d.lda);
   if (d.batch <= 0) d.batch = 1;
+  AVSD_REQUIRE(d.raster_g >= 0 && d.raster_g <= 64, "gemm: raster_g (%d) must be 0 (library default) .. 64", d.raster_g);
   if (d.flags & AVSD_GEMM_GEGLU) AVSD_REQUIRE(d.N % 32 == 0, "gemm: GEGLU needs N %% 32 == 0 (got %d)", d.N);
   AVSD_REQUIRE(!((d.flags & AVSD_GEMM_GEGLU) && (d.flags & AVSD_GEMM_GELU)), "gemm: GEGLU and GELU are exclusive");
   if (d.flags & AVSD_GEMM_ROWSTATS) {

@@ -20,7 +20,11 @@
 // Tiles past the end of K re-read the last tile (never consumed), so the loop has no tail code.
 //
 // Same math, operand layout, XCD banding, split-K slabs and epilogue as gemm2_kernel (gemm.hip); f32 order per element: K ascending
-// -> bit-identical to the LDS-direct tiles.
+// -> bit-identical to the LDS-direct tiles ON THE UNROTATED WALK ONLY (AVSD_GEMM_KROT clear; AVSD_KROT=0 on the host).  With the rotated
+// walk — the host's default wherever 2 N K <= 16 MB — row band tm starts at K tile (tm nk) / ntm: the summation order of an output
+// element then depends on the tile height BM, on M (how many clips share the launch) and on the table's tile pick, so results agree
+// across those only to f32 rounding.  They stay bit-repeatable run to run and rank to rank (same table, same shapes: the witness-clip
+// checksum of bench.py / asva_amd/dist.py checks exactly that).
 // Replaces (reference file:line): as gemm.hip — nn.Linear / 1x1 nn.Conv2d at avgen/models/unets/utils.py:123-131,159;
 // ff_spatio_audio_temp_transformer_3d.py:66,92,276,361-371 (the GEGLU projection is the widest GEMM of a step).
 #include <utility>
@@ -42,16 +46,6 @@ constexpr int ROWB = 144;          // LDS row pitch: 64 values + 8 pad = 144 B -
 #endif
 
 #include "gemm4_loops.inc"
-
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), in order: the index is a compile-time constant inside f
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
 
 // The loop leaves the accumulators in AGPRs ("=&a" outputs).  Read through the compiler, all of them are copied to VGPRs right behind
 // the loop (the value's register class is decided at its definition), which the 256 x 256 tile cannot hold: 100-132 registers went to
@@ -99,7 +93,7 @@ __global__ __launch_bounds__(256, 1) void gemm4_kernel(const avsd_gemm_desc p) {
     ksplit = c - wg * nsplit;
   }
   int tm, tn;
-  tile_of_item(wg, ntm, ntn, (p.flags & AVSD_GEMM_XCD_N) != 0, p.reserved0, tm, tn);
+  tile_of_item(wg, ntm, ntn, (p.flags & AVSD_GEMM_XCD_N) != 0, p.raster_g, tm, tn);
   const int nk_all = p.K / BK;
   const int per_split = (nk_all + nsplit - 1) / nsplit;
   const int kt0 = ksplit * per_split;

@@ -1,11 +1,23 @@
 // Pieces shared by the GEMM family (gemm.hip) and the fused kernels built on its main loop (xattn.hip):
 // the f32 epilogue, the LayerNorm-fold row statistics, counted vmcnt waits and the LDS-direct tile addressing.
 #pragma once
+#include <utility>
+
 #include "avsd_common.h"
 
 namespace {
 
 constexpr int BK = 64;
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), in order: the index is a compile-time constant inside f
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 // LayerNorm statistics of row m of A folded from the producer's per-32-column (sum, sumsq) pairs -> (rstd, mean * rstd)
 __device__ __forceinline__ void ln_row_stats(const avsd_gemm_desc& p, int m, int64_t bz, float& rstd, float& mr) {
@@ -551,6 +563,34 @@ __device__ __forceinline__ void epilogue(const avsd_gemm_desc& p, f32x16 (&acc)[
   else epilogue_by_fragment<FN, FM>(p, acc, m_base, n_base, lane, bz, pre_ln, have_pre, mstride);
 }
 
+// Wave tiles of 8+ fragments whose epilogue the compiler does NOT unroll (hipcc 7.2: "loop not unrolled" on the 5 x 2 and 4 x 2
+// fragment forms of conv3r.hip) index the accumulator array at run time: the whole array then lives in scratch memory — 160 registers
+// stored behind the main loop and read back piecewise, 1.2 KB per lane and ~360 scratch instructions per wave in the 256 x 160
+// resident-convolution tile (tools/resource_usage.py; profiles/r5_resource_usage.txt).  This form hands the shared epilogue ONE fragment
+// at a time with compile-time indices, so every accumulator is consumed from the register it was computed in.  Same terms in the same
+// order per element; the LayerNorm-fold row statistics are folded once per row band and handed to the fragments.
+template <int FN, int FM, bool TIGHT = false>
+__device__ __forceinline__ void epilogue_each(const avsd_gemm_desc& p, f32x16 (&acc)[FN][FM], int m_base, int n_base, int lane, int64_t bz,
+                                              const float (&pre_ln)[2 * FM], bool have_pre, int mstride = 32) {
+  const bool lnfuse = (p.flags & AVSD_GEMM_LNFUSE) != 0;
+  static_for<FM>([&](auto b_c) {
+    constexpr int B = decltype(b_c)::value;
+    // LayerNorm fold: the row statistics of this lane's row, folded ONCE per row band (the one-fragment calls below take them as given)
+    float pl[2] = {1.f, 0.f};
+    if (lnfuse) {
+      if (have_pre) { pl[0] = pre_ln[2 * B]; pl[1] = pre_ln[2 * B + 1]; }
+      else ln_row_stats(p, min(m_base + B * mstride + (lane & 31), p.M - 1), bz, pl[0], pl[1]);
+    }
+    static_for<FN>([&](auto a_c) {
+      constexpr int A = decltype(a_c)::value;
+      __builtin_amdgcn_sched_barrier(0);          // fragments are independent: keep each one's loads and stores together
+      f32x16 one[1][1];
+      one[0][0] = acc[A][B];
+      epilogue<1, 1, TIGHT>(p, one, m_base + B * mstride, n_base + 32 * A, lane, bz, pl, lnfuse, mstride);
+    });
+  });
+}
+
 // ---- AVSD_GEMM_X2 epilogue: same terms and f32 order as above; 16-bit residuals are read as main + rest, the result is
 // written as main = round16(v), rest = round16(v - main); LayerNorm row statistics are taken from main + rest (what the
 // consumer reconstructs).  Fragment-at-a-time, 8-byte stores (the precise tier trades the wide-store form for one code path).
@@ -693,7 +733,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // dimension (M by default, N under AVSD_GEMM_XCD_N: the operand of the band is what the XCD's L2 fetches once); on big grids the
 // ~32 workgroups an XCD runs at a time cover a G x (32 / G) BLOCK of tiles instead of one row of 32, so the L2 fetches
 // G + 32 / G operand panels per K tile instead of 33 (measured on the asm tiles: 8192^3 1090 -> 850 us, 6144 x 5120 x 640
-// 64 -> 54 us; G = 4 .. 8 equal, profiles/r4_raster_probe.txt).  `g_override` > 0 replaces G (probe knob, avsd_gemm_desc.reserved0).
+// 64 -> 54 us; G = 4 .. 8 equal, profiles/r4_raster_probe.txt).  `g_override` > 0 replaces G (probe knob, avsd_gemm_desc.raster_g: 0..64, checked by avsd_gemm_bf16).
 __device__ __forceinline__ void tile_of_item(int wg, int ntm, int ntn, bool nmaj, int g_override, int& tm, int& tn) {
   const int nmajor = nmaj ? ntn : ntm, nminor = nmaj ? ntm : ntn;      // wg = major * nminor + minor
   int tmaj, tmin;

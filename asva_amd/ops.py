@@ -81,6 +81,17 @@ def set_timer(t: Optional[KernelTimer]) -> None:
     _TIMER = t
 
 
+def _timed(family: str, flops: float, nbytes: float, keep, *calls) -> None:
+    """issues `calls` (zero-argument callables, one library launch each, reading the current stream when called) and, under a
+    KernelTimer, records their event-pair time and registers them for the graph-replayed per-family timing"""
+    ev = _TIMER.start() if _TIMER is not None else None
+    for c in calls:
+        c()
+    if ev is not None:
+        _TIMER.add_replay(family, lambda: [c() for c in calls], keep)
+        _TIMER.stop(ev, family, flops, nbytes)
+
+
 def _nbytes(*ts) -> float:
     return float(sum(t.numel() * t.element_size() for t in ts if t is not None))
 
@@ -576,7 +587,7 @@ def gemm(
     if _XCD_MODE == "n" or (_XCD_MODE == "auto" and N * K > a_bytes):
         d.flags |= XCD_N
     d.batch = 1
-    d.reserved0 = _RASTER_G
+    d.raster_g = _RASTER_G
     ws = None
     if P.SPLIT:
         if master is not None:
@@ -701,10 +712,9 @@ def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, alpha: float = 1.0, out_f3
 
         picked = _pick_tile(("batched", B, M, N, K, d.flags), lambda t, sk: _launch(t), X2_TILE_CANDIDATES if P.SPLIT else TILE_CANDIDATES)
         d.tile = picked[0] if picked is not None else (_heuristic_tile_x2 if P.SPLIT else _heuristic_tile)(B * M, N, K, False, False)[0]
-    ev = _TIMER.start() if _TIMER is not None else None
-    check(_lib.lib().avsd_gemm_bf16(C.byref(d), _stream()), "avsd_gemm_bf16(batched)")
-    if ev is not None:
-        _TIMER.stop(ev, "gemm_plain", 2.0 * B * M * N * K, 2.0 * B * (M * K + N * K) + _nbytes(out))
+    dc = GemmDesc.from_buffer_copy(d) if _TIMER is not None else d
+    _timed("gemm_plain", 2.0 * B * M * N * K * (3 if P.SPLIT else 1), 2.0 * B * (M * K + N * K) + _nbytes(out), (a, w, out, bias, ln),
+           lambda: check(_lib.lib().avsd_gemm_bf16(C.byref(dc), _stream()), "avsd_gemm_bf16(batched)"))
     return out
 
 
@@ -749,35 +759,34 @@ def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], nb: int, rows_per_ba
     rows = nb * rows_per_batch
     if out is None:
         out = alloc16((rows, c1 + c2), x1.device)
-    s = _stream()
     ld2 = _ld(x2) if x2 is not None else 0
-    ev = _TIMER.start() if _TIMER is not None else None
+    keep = (x1, x2, gamma, beta, out)
     if _GN_FUSED and L.avsd_groupnorm_fused_supported(nb, rows_per_batch, groups, c1, c2, int(P.SPLIT)):
         if P.SPLIT:
-            check(L.avsd_groupnorm_fused_x2(_p(x1), _ld(x1), c1, _lo(x1), _p(x2), ld2, c2, _lo(x2), nb, rows_per_batch, groups, _p(gamma),
-                                            _p(beta), float(eps), int(act), _p(out), _ld(out), _lo(out), s), "avsd_groupnorm_fused_x2")
+            a_ = (_p(x1), _ld(x1), c1, _lo(x1), _p(x2), ld2, c2, _lo(x2), nb, rows_per_batch, groups, _p(gamma), _p(beta), float(eps), int(act),
+                  _p(out), _ld(out), _lo(out))
+            _timed("groupnorm", 0.0, _nbytes(x1, x2) + _nbytes(out), keep, lambda: check(L.avsd_groupnorm_fused_x2(*a_, _stream()), "avsd_groupnorm_fused_x2"))
         else:
-            check(L.avsd_groupnorm_fused(_p(x1), _ld(x1), c1, _p(x2), ld2, c2, nb, rows_per_batch, groups, _p(gamma), _p(beta), float(eps),
-                                         int(act), _p(out), _ld(out), s), "avsd_groupnorm_fused")
-        if ev is not None:
-            _TIMER.stop(ev, "groupnorm", 0.0, _nbytes(x1, x2) + _nbytes(out))
+            a_ = (_p(x1), _ld(x1), c1, _p(x2), ld2, c2, nb, rows_per_batch, groups, _p(gamma), _p(beta), float(eps), int(act), _p(out), _ld(out))
+            _timed("groupnorm", 0.0, _nbytes(x1, x2) + _nbytes(out), keep, lambda: check(L.avsd_groupnorm_fused(*a_, _stream()), "avsd_groupnorm_fused"))
         return out
     nchunks = L.avsd_groupnorm_nchunks(nb, rows_per_batch, c1 + c2)
     partial = torch.empty((L.avsd_groupnorm_scratch_floats(nb, nchunks, groups, c1 + c2),), dtype=F32, device=x1.device)
+    keep = keep + (partial,)
     if P.SPLIT:
-        check(L.avsd_groupnorm_stats_x2(_p(x1), _ld(x1), c1, _lo(x1), _p(x2), ld2, c2, _lo(x2), nb,
-                                        rows_per_batch, groups, _p(partial), nchunks, s), "avsd_groupnorm_stats_x2")
-        check(L.avsd_groupnorm_apply_x2(_p(x1), _ld(x1), c1, _lo(x1), _p(x2), ld2, c2, _lo(x2), nb,
-                                        rows_per_batch, groups, _p(gamma), _p(beta), float(eps), _p(partial), nchunks, int(act),
-                                        _p(out), _ld(out), _lo(out), s), "avsd_groupnorm_apply_x2")
+        s_ = (_p(x1), _ld(x1), c1, _lo(x1), _p(x2), ld2, c2, _lo(x2), nb, rows_per_batch, groups, _p(partial), nchunks)
+        a_ = (_p(x1), _ld(x1), c1, _lo(x1), _p(x2), ld2, c2, _lo(x2), nb, rows_per_batch, groups, _p(gamma), _p(beta), float(eps), _p(partial),
+              nchunks, int(act), _p(out), _ld(out), _lo(out))
+        _timed("groupnorm", 0.0, 2.0 * _nbytes(x1, x2) + _nbytes(out), keep,
+               lambda: check(L.avsd_groupnorm_stats_x2(*s_, _stream()), "avsd_groupnorm_stats_x2"),
+               lambda: check(L.avsd_groupnorm_apply_x2(*a_, _stream()), "avsd_groupnorm_apply_x2"))
     else:
-        check(L.avsd_groupnorm_stats(_p(x1), _ld(x1), c1, _p(x2), ld2, c2, nb, rows_per_batch,
-                                     groups, _p(partial), nchunks, s), "avsd_groupnorm_stats")
-        check(L.avsd_groupnorm_apply(_p(x1), _ld(x1), c1, _p(x2), ld2, c2, nb, rows_per_batch,
-                                     groups, _p(gamma), _p(beta), float(eps), _p(partial), nchunks, int(act), _p(out), _ld(out), s),
-              "avsd_groupnorm_apply")
-    if ev is not None:
-        _TIMER.stop(ev, "groupnorm", 0.0, 2.0 * _nbytes(x1, x2) + _nbytes(out))
+        s_ = (_p(x1), _ld(x1), c1, _p(x2), ld2, c2, nb, rows_per_batch, groups, _p(partial), nchunks)
+        a_ = (_p(x1), _ld(x1), c1, _p(x2), ld2, c2, nb, rows_per_batch, groups, _p(gamma), _p(beta), float(eps), _p(partial), nchunks, int(act),
+              _p(out), _ld(out))
+        _timed("groupnorm", 0.0, 2.0 * _nbytes(x1, x2) + _nbytes(out), keep,
+               lambda: check(L.avsd_groupnorm_stats(*s_, _stream()), "avsd_groupnorm_stats"),
+               lambda: check(L.avsd_groupnorm_apply(*a_, _stream()), "avsd_groupnorm_apply"))
     return out
 
 
@@ -787,7 +796,7 @@ def ln_fold(stats: torch.Tensor) -> torch.Tensor:
     _req(stats, F32, "stats")
     M, nblk = stats.shape[0], stats.shape[1]
     out = torch.empty((M, 1, 2), dtype=F32, device=stats.device)
-    check(_lib.lib().avsd_ln_fold(_p(stats), M, nblk, _p(out), _stream()), "avsd_ln_fold")
+    _timed("ln_fold", 0.0, _nbytes(stats, out), (stats, out), lambda: check(_lib.lib().avsd_ln_fold(_p(stats), M, nblk, _p(out), _stream()), "avsd_ln_fold"))
     return out
 
 
@@ -804,15 +813,13 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
             raise ValueError("layernorm: pos must be contiguous [frames, C]")
     if out is None:
         out = alloc16((M, Cc), x.device)
-    ev = _TIMER.start() if _TIMER is not None else None
     if P.SPLIT:
-        check(_lib.lib().avsd_layernorm_x2(_p(x), _ld(x), _lo(x), _p(out), _ld(out), _lo(out), M, Cc, _p(gamma), _p(beta), float(eps),
-                                           _p(pos), hw, frames, _stream()), "avsd_layernorm_x2")
+        a_ = (_p(x), _ld(x), _lo(x), _p(out), _ld(out), _lo(out), M, Cc, _p(gamma), _p(beta), float(eps), _p(pos), hw, frames)
+        call = lambda: check(_lib.lib().avsd_layernorm_x2(*a_, _stream()), "avsd_layernorm_x2")   # noqa: E731
     else:
-        check(_lib.lib().avsd_layernorm(_p(x), _ld(x), _p(out), _ld(out), M, Cc, _p(gamma), _p(beta), float(eps), _p(pos),
-                                        hw, frames, _stream()), "avsd_layernorm")
-    if ev is not None:
-        _TIMER.stop(ev, "layernorm", 0.0, _nbytes(x, out))
+        a_ = (_p(x), _ld(x), _p(out), _ld(out), M, Cc, _p(gamma), _p(beta), float(eps), _p(pos), hw, frames)
+        call = lambda: check(_lib.lib().avsd_layernorm(*a_, _stream()), "avsd_layernorm")   # noqa: E731
+    _timed("layernorm", 0.0, _nbytes(x, out), (x, out, gamma, beta, pos), call)
     return out
 
 
@@ -841,24 +848,23 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, bq: int, lq:
         out = alloc16((bq * lq, Cc), q.device)
     if scale is None:
         scale = float(d) ** -0.5
-    ev = _TIMER.start() if _TIMER is not None else None
     if P.SPLIT:
         if fp8 is not None:
             raise ValueError("attention: fp8 Q/K/V and split precision are exclusive")
-        check(_lib.lib().avsd_attention_x2(_p(q), _ld(q), _lo(q), _p(k), _ld(k), _lo(k), _p(v), _ld(v), _lo(v), _p(out), _ld(out),
-                                           _lo(out), bq, lq, lk, kv_rows, heads, d, q_per_kv, _p(key_index), frames, float(scale),
-                                           _stream()), "avsd_attention_x2")
+        a_ = (_p(q), _ld(q), _lo(q), _p(k), _ld(k), _lo(k), _p(v), _ld(v), _lo(v), _p(out), _ld(out), _lo(out), bq, lq, lk, kv_rows, heads, d,
+              q_per_kv, _p(key_index), frames, float(scale))
+        call = lambda: check(_lib.lib().avsd_attention_x2(*a_, _stream()), "avsd_attention_x2")   # noqa: E731
     elif fp8 is not None:
         qs, ks, vs = (float(x) for x in fp8)
-        check(_lib.lib().avsd_attention_fp8(_p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(out), _ld(out), bq, lq, lk, kv_rows,
-                                            heads, d, q_per_kv, _p(key_index), frames, float(scale), qs, ks, vs, _stream()),
-              "avsd_attention_fp8")
+        a_ = (_p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(out), _ld(out), bq, lq, lk, kv_rows, heads, d, q_per_kv, _p(key_index), frames,
+              float(scale), qs, ks, vs)
+        call = lambda: check(_lib.lib().avsd_attention_fp8(*a_, _stream()), "avsd_attention_fp8")   # noqa: E731
     else:
-        check(_lib.lib().avsd_attention(_p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(out), _ld(out), bq, lq, lk, kv_rows,
-                                        heads, d, q_per_kv, _p(key_index), frames, float(scale), _stream()),
-              "avsd_attention")
-    if ev is not None:
-        _TIMER.stop(ev, "attention", 4.0 * bq * heads * lq * lk * d, _nbytes(q, out) + 4.0 * (bq // q_per_kv) * lk * Cc)
+        a_ = (_p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(out), _ld(out), bq, lq, lk, kv_rows, heads, d, q_per_kv, _p(key_index), frames,
+              float(scale))
+        call = lambda: check(_lib.lib().avsd_attention(*a_, _stream()), "avsd_attention")   # noqa: E731
+    _timed("attention", 4.0 * bq * heads * lq * lk * d * (3 if P.SPLIT else 1), _nbytes(q, out) + 4.0 * (bq // q_per_kv) * lk * Cc,
+           (q, k, v, out, key_index), call)
     return out
 
 
@@ -934,15 +940,13 @@ def temporal_attention(qkv: torch.Tensor, *, b: int, frames: int, hw: int, heads
         out = alloc16((qkv.shape[0], Cc), qkv.device)
     if scale is None:
         scale = float(d) ** -0.5
-    ev = _TIMER.start() if _TIMER is not None else None
     if P.SPLIT:
-        check(_lib.lib().avsd_temporal_attention_x2(_p(qkv), _ld(qkv), _lo(qkv), _p(out), _ld(out), _lo(out), b, frames, hw, heads, d,
-                                                    float(scale), _stream()), "avsd_temporal_attention_x2")
+        a_ = (_p(qkv), _ld(qkv), _lo(qkv), _p(out), _ld(out), _lo(out), b, frames, hw, heads, d, float(scale))
+        call = lambda: check(_lib.lib().avsd_temporal_attention_x2(*a_, _stream()), "avsd_temporal_attention_x2")   # noqa: E731
     else:
-        check(_lib.lib().avsd_temporal_attention(_p(qkv), _ld(qkv), _p(out), _ld(out), b, frames, hw, heads, d, float(scale),
-                                                 _stream()), "avsd_temporal_attention")
-    if ev is not None:
-        _TIMER.stop(ev, "temporal_attention", 4.0 * b * hw * heads * frames * frames * d, _nbytes(qkv, out))
+        a_ = (_p(qkv), _ld(qkv), _p(out), _ld(out), b, frames, hw, heads, d, float(scale))
+        call = lambda: check(_lib.lib().avsd_temporal_attention(*a_, _stream()), "avsd_temporal_attention")   # noqa: E731
+    _timed("temporal_attention", 4.0 * b * hw * heads * frames * frames * d, _nbytes(qkv, out), (qkv, out), call)
     return out
 
 

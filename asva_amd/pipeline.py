@@ -367,8 +367,9 @@ def generate_videos_for_dataset(exp_root: str, checkpoint: int, dataset: str = "
     # torch.device("cuda") = cuda:0, which would stack all ranks on one GPU.
     rank, local_rank, world = adist.env_rank_world()
     if world > 1 and torch.cuda.is_available() and torch.device(device).type == "cuda":
-        torch.cuda.set_device(local_rank)
-        device = torch.device("cuda", local_rank)
+        idx = adist.device_index(local_rank)      # cuda:LOCAL_RANK; refuses more ranks than GPUs unless AVSD_DIST_SAME_DEVICE=1
+        torch.cuda.set_device(idx)
+        device = torch.device("cuda", idx)
     ckpt = f"{exp_root}/ckpts/checkpoint-{checkpoint}/modules"
     save_root = (f"{exp_root}/evaluations/checkpoint-{checkpoint}/AG-{audio_guidance_scale}_TG-{text_guidance_scale}/"
                  f"seed-{random_seed}/videos")

@@ -779,8 +779,10 @@ class AudioUNet3DConditionModel(nn.Module):
             if not bool(m.all()):
                 key_index = key_index_for(m, dev)
                 idx_frames = m.shape[0]
+        # (precision mode and the identity of the packed weights are part of the signature: the cached tables — K / V projections,
+        # `posw` = pos . W'^T of the LayerNorm-folded temporal q|k|v — were computed from THAT blob in THAT storage format)
         sig = (tuple(text.shape), text_pf, None if audio is None else tuple(audio.shape), audio_pf,
-               None if key_index is None else tuple(key_index.shape), idx_frames, Fr)
+               None if key_index is None else tuple(key_index.shape), idx_frames, Fr, P.NAME, P.SPLIT, id(pk))
         nb = text.shape[0] // text_pf
         # which branch counts r see the same text in all r batch chunks (once per clip; a host sync is fine here)
         share = {r: bool(nb % r == 0 and all(torch.equal(text[: text.shape[0] // r], c) for c in text.chunk(r)[1:])) for r in (2, 3)}
@@ -1123,7 +1125,7 @@ def _transformer(st, x: _Act, p, hw, heads, split: int = 1) -> _Act:
     # 4. temporal attention across frames per pixel; LN(h + pos[f]); residual is h itself (:346-358).  Folded like the other LayerNorms:
     # the text cross-attention's output projection emits the row statistics of h + pos[frame], and the q|k|v projection reads the raw h
     # with pos . W'^T added inside its LayerNorm epilogue (avsd_gemm_desc.stats_pos / ln_rowvec) — no LayerNorm launch, no (M, C) round trip
-    fold_temp = fused and _FUSE_LN_TEMP and getattr(c, "posw", None) is not None and hasattr(p.attn_temp, "wqkv_ln")
+    fold_temp = fused and _FUSE_LN_TEMP and not P.SPLIT and getattr(c, "posw", None) is not None and hasattr(p.attn_temp, "wqkv_ln")
     h = cross(h, a2, p.norm2, getattr(c, "xa_text", None), fold_temp, text_attention, stats_pos=(c.pos, L, Fr) if fold_temp else None)
     if fold_temp:
         qkv = ops.gemm(h.lo, p.attn_temp.wqkv_ln, bias=p.attn_temp.bqkv_ln, ln=(stats[si], p.attn_temp.sqkv_ln, eps), ln_pos=(c.posw, L, Fr))

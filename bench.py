@@ -101,8 +101,11 @@ def spawn_ranks(n: int) -> int:
     import socket
     import subprocess
 
-    if torch.cuda.device_count() < n:
-        raise SystemExit(f"--gpus {n} but only {torch.cuda.device_count()} GPU(s) are visible")
+    from asva_amd import dist as adist
+
+    if torch.cuda.device_count() < n and not adist.same_device():
+        raise SystemExit(f"--gpus {n} but only {torch.cuda.device_count()} GPU(s) are visible "
+                         "(tests: AVSD_DIST_SAME_DEVICE=1 AVSD_DIST_BACKEND=gloo run the ranks on one GPU)")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -239,9 +242,13 @@ def main():
     rank, local_rank, world = adist.env_rank_world()
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    adist.init_process_group("nccl")
+    try:
+        dev_index = adist.device_index(local_rank)
+    except RuntimeError as e:
+        raise SystemExit(str(e))
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    adist.init_process_group(adist.backend_name("nccl"))
     import torch.distributed as tdist
 
     world_observed = tdist.get_world_size() if tdist.is_initialized() else 1
@@ -302,7 +309,9 @@ def main():
     ms_per_step = max_wall / a.steps * 1e3
     out = {
         "metric": "UNet denoising steps/sec, 12x256x256 bf16, CFG on",
-        "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "world_size_rccl": world_observed, "steps": a.steps, "warmup": a.warmup,
+        "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "world_size_rccl": world_observed,
+        "dist_backend": (tdist.get_backend() if tdist.is_initialized() else None), "ranks_share_one_gpu": bool(adist.same_device() and world > 1),
+        "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" + (" (fp8 e4m3 attention Q/K/V)" if a.fp8_attention else "") + (" + f32 residual stream" if a.f32_residual else ""),
         "data": "synthetic",
@@ -329,25 +338,38 @@ def main():
                              "workload": f"SD1.5 AutoencoderKL decoder, {12 * cpg} x (4,32,32) latents -> uint8 256x256 frames, "
                                          f"{vae_reps} reps, random-init weights; 7.47 TFLOP and >= 6.4 GB per 12-frame clip (SURVEY 8d)"}
 
-    if not a.no_roofline:
+    def roofline_of(latents_, clips):
+        """instrumented eager forward (one forward = `clips` steps) -> (roofline dict of the GEMM family, per-family table).
+        Every family's time is the GPU time of its launches of that forward re-issued back to back from ONE captured graph —
+        the clock of a rocprofv3 trace of the graph-replayed step; the per-launch event pairs of the eager pass (each carries
+        ~4 us of command-processor time) are kept beside it as `ms_event_pairs`."""
         timer = ops.KernelTimer()
         ops.set_timer(timer)
-        unet.denoise_forward(latents, torch.full((1,), 501.0, device=device), rep=2)   # one forward = cpg steps
+        unet.denoise_forward(latents_, torch.full((1,), 501.0, device=device), rep=2)
         ops.set_timer(None)
         fam = timer.summary()
-        mm = [fam[k] for k in ("gemm_plain", "gemm_tmix", "gemm_conv3") if k in fam]
-        ms_events = sum(f["ms"] for f in mm)            # sum of per-launch event pairs of the eager pass
+        gemm_fams = tuple(k for k in ("gemm_plain", "gemm_tmix", "gemm_conv3") if k in fam)
+        mm = [fam[k] for k in gemm_fams]
+        ms_events = sum(f["ms"] for f in mm)
         fl = sum(f["flops"] for f in mm)
         launches = sum(f["launches"] for f in mm)
-        # the family's launches of that step re-issued back to back from one captured graph: the event pairs of the eager
-        # pass each carry ~4 us of command-processor time that the graph-replayed step (and its rocprofv3 trace) does not
-        ms = timer.replay_ms(("gemm_plain", "gemm_tmix", "gemm_conv3")) if not a.no_graph else ms_events
+        fam_ms = {k: (timer.replay_ms((k,)) if not a.no_graph else v["ms"]) for k, v in fam.items()}
+        ms = timer.replay_ms(gemm_fams) if not a.no_graph else ms_events
         ach = fl / (ms * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": "GEMM family: gemm2_kernel<BM,BN,...,MODE> (linear / temporal-mix / strided conv3x3 implicit GEMM) + conv3r_kernel (conv3x3, input tile resident in LDS)",
-                           "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                           "traffic": None, "launches_per_step": launches, "ms_per_step": round(ms, 4),
-                           "ms_per_step_event_pairs": round(ms_events, 4),
-                           "avg_launch_us": round(ms * 1e3 / launches, 2), "tflop_per_step": round(fl / 1e12, 4)}
+        roof = {"bound": "mfma", "kernel": "GEMM family: gemm4_kernel (hand-scheduled tiles) / gemm2_kernel<BM,BN,...,MODE> (linear / temporal-mix / strided conv3x3 implicit GEMM) + conv3r_kernel (conv3x3, input tile resident in LDS), split-K reduce launches included",
+                "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                "traffic": None, "launches_per_step": launches // clips, "clips_per_forward": clips, "ms_per_step": round(ms / clips, 4),
+                "ms_per_forward": round(ms, 4), "ms_per_step_event_pairs": round(ms_events / clips, 4),
+                "family_ms_sum": round(sum(fam_ms[k] for k in gemm_fams) / clips, 4),
+                "avg_launch_us": round(ms * 1e3 / launches, 2), "tflop_per_step": round(fl / clips / 1e12, 4),
+                "algorithmic_bytes_per_launch": round(sum(f["bytes"] for f in mm) / launches)}
+        table = {k: {"launches": v["launches"], "ms": round(fam_ms[k], 4), "ms_event_pairs": round(v["ms"], 4),
+                     "tflops": round(v["flops"] / (fam_ms[k] * 1e-3) / 1e12, 2) if v["flops"] else None,
+                     "gbs": round(v["bytes"] / (fam_ms[k] * 1e-3) / 1e9, 1)} for k, v in fam.items()}
+        return roof, table
+
+    if not a.no_roofline:
+        out["roofline"], out["kernel_families"] = roofline_of(latents, cpg)
         # HBM-side traffic of the same family from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected in separate
         # runs of this script, FETCH_SIZE doubled per the gfx950 correction); counters cannot be read from inside
         # the timed process, so the committed summary of the last profiled run is reported, with its provenance
@@ -360,34 +382,43 @@ def main():
                                                                     "launches_profiled", "source", "build_id") if k in tr}
             # the counters were collected from the build whose id the summary carries; say so when this run's differs
             out["roofline"]["traffic_from_this_build"] = tr.get("build_id") == out["build_id"]
-        out["roofline"]["algorithmic_bytes_per_launch"] = round(sum(f["bytes"] for f in mm) / launches)
-        out["kernel_families"] = {
-            k: {"launches": v["launches"], "ms": round(v["ms"], 4),
-                "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
-                "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in fam.items()}
 
     if a.also_clips and a.also_clips != cpg and world == 1:
-        # BASELINE cfg 3's per-GPU shape: several independent clips in one forward (UNet batch 2 x clips) — same kernels,
-        # 4x the rows per launch; reported next to the headline, never instead of it
-        n = a.also_clips
-        lat_b, text_b, audio_b, null_b = synthetic_clip(device, seed=2000, n=n)
-        eng_b = DenoiseEngine(unet, DDIMScheduler(), audio_guidance_scale=4.0, use_graph=not a.no_graph)
-        eng_b.set_conditioning(text_b, audio_b, null_b, audio_segment_mask(12), 12)
-        lb = lat_b.clone()
-        eng_b.prepare(lb, n_sched)
-        ks = max(10, a.steps // 2)
-        for i in range(5):
-            eng_b.step(lb, i)
-        torch.cuda.synchronize()
-        tb = time.perf_counter()
-        for i in range(ks):
-            eng_b.step(lb, (5 + i) % n_sched)
-        torch.cuda.synchronize()
-        tb = time.perf_counter() - tb
-        out["batched"] = {"clips_per_gpu": n, "unet_batch": 2 * n, "value": round(ks * n / tb, 3), "unit": "steps/s",
-                          "ms_per_forward": round(tb / ks * 1e3, 4), "steps": ks,
-                          "step_mfma_frac": round(ALGORITHMIC_TFLOP_PER_STEP * n / (tb / ks) / PEAK_BF16_TFLOPS, 4),
-                          "workload": f"BASELINE configs[2] per-GPU shape: {n} clips per forward"}
+        # Several independent clips in one forward (UNet batch 2 x clips; BASELINE cfg 3 runs 4 per GPU) — same kernels, more rows
+        # per launch; reported next to the headline, never instead of it.  `batched` = the --also-clips count with its own GEMM
+        # roofline; `clips_sweep` = {2, 4, 8} clips per forward, the measured approach to north_star's >= 0.40 MFMA fraction.
+        def batched_leg(n, with_roofline):
+            lat_b, text_b, audio_b, null_b = synthetic_clip(device, seed=2000, n=n)
+            eng_b = DenoiseEngine(unet, DDIMScheduler(), audio_guidance_scale=4.0, use_graph=not a.no_graph)
+            eng_b.set_conditioning(text_b, audio_b, null_b, audio_segment_mask(12), 12)
+            lb = lat_b.clone()
+            eng_b.prepare(lb, n_sched)
+            ks = max(10, a.steps // max(2, n // 2))
+            for i in range(3):
+                eng_b.step(lb, i)
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            for i in range(ks):
+                eng_b.step(lb, (3 + i) % n_sched)
+            torch.cuda.synchronize()
+            tb = time.perf_counter() - tb
+            row = {"clips_per_gpu": n, "unet_batch": 2 * n, "value": round(ks * n / tb, 3), "unit": "steps/s",
+                   "ms_per_forward": round(tb / ks * 1e3, 4), "steps": ks,
+                   "step_mfma_frac": round(ALGORITHMIC_TFLOP_PER_STEP * n / (tb / ks) / PEAK_BF16_TFLOPS, 4)}
+            if with_roofline and not a.no_roofline:
+                row["roofline"], _ = roofline_of(lb, n)
+            del eng_b
+            torch.cuda.empty_cache()
+            return row
+
+        out["batched"] = batched_leg(a.also_clips, True)
+        out["batched"]["workload"] = f"BASELINE configs[2] per-GPU shape: {a.also_clips} clips per forward"
+        out["clips_sweep"] = [{"clips_per_gpu": cpg, "value": out["value"], "step_mfma_frac": out["step_mfma_frac"]}]
+        for n in (2, 4, 8):
+            if n == cpg:
+                continue
+            r = out["batched"] if n == a.also_clips else batched_leg(n, False)
+            out["clips_sweep"].append({k: r[k] for k in ("clips_per_gpu", "value", "ms_per_forward", "step_mfma_frac")})
     if world == 1 and not a.no_precise:
         # the mode that meets BASELINE.json's stated tolerance (<= 1e-3 rel-L2 vs the reference's fp32 pipeline; measured
         # 3e-5 on this forward, tests/test_precise_gpu.py): split-precision storage (bf16 main + rest planes), every matrix

@@ -150,7 +150,10 @@ typedef struct avsd_gemm_desc {
   float ln_eps;
   float* out_master;                    /* f32 [M][ldm] or NULL: un-rounded copy of the result (not with GEGLU) */
   int32_t ldm;
-  int32_t reserved0;
+  int32_t raster_g;                     /* scheduling knob, no effect on the result: rows of the tile blocks an XCD walks (tile_of_item,
+                                           gemm_common.h: 0 = the library default of 8; 1..64 = probe values, tools/asm_bench.py).  Must be
+                                           0..64: avsd_gemm_bf16 refuses anything else (a large value would overflow the work-item -> tile
+                                           map and drop or duplicate tiles).  Was `reserved0` up to ABI v8. */
   /* AVSD_GEMM_X2 (split precision, see "split-precision storage" below): every 16-bit operand is a pair of planes; these are
    * the ELEMENT offsets from each main plane to its rest plane (same strides).  The product is accumulated as
    * W.A + Wr.A + W.Ar (three MFMA passes into one f32 accumulator); 16-bit residuals are read as main + rest and the output

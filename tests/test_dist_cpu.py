@@ -107,3 +107,27 @@ def test_shard_clips_partition():
             parts = [shard_clips(n, r, world) for r in range(world)]
             assert sorted(sum(parts, [])) == list(range(n))
             assert max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+def test_device_index_and_backend_switches(monkeypatch):
+    """AVSD_DIST_SAME_DEVICE / AVSD_DIST_BACKEND (tests/test_multirank_gpu.py runs two ranks on the one leased GPU with them)"""
+    from asva_amd import dist as adist
+
+    monkeypatch.delenv("AVSD_DIST_SAME_DEVICE", raising=False)
+    monkeypatch.delenv("AVSD_DIST_BACKEND", raising=False)
+    assert adist.same_device() is False and adist.device_index(3) == 3          # no GPU visible here: nothing to check against
+    assert adist.backend_name("nccl") == "nccl" and adist.backend_name() == "gloo"
+    monkeypatch.setenv("AVSD_DIST_SAME_DEVICE", "1")
+    assert adist.same_device() is True and adist.device_index(0) == 0 and adist.device_index(5) == 0
+    monkeypatch.setenv("AVSD_DIST_BACKEND", "gloo")
+    assert adist.backend_name("nccl") == "gloo"
+    monkeypatch.setenv("AVSD_DIST_BACKEND", "mpi")
+    with pytest.raises(ValueError):
+        adist.backend_name()
+    # more ranks than GPUs without the switch is refused
+    monkeypatch.delenv("AVSD_DIST_SAME_DEVICE")
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    assert adist.device_index(0) == 0
+    with pytest.raises(RuntimeError):
+        adist.device_index(1)

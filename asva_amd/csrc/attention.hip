@@ -651,12 +651,12 @@ __global__ __launch_bounds__(EXACT ? 256 : 1024) void tattn_kernel(const TAttnAr
   }
   __syncthreads();
 
-  float a[NV][8];
+  float a[X2 ? NV : 1][8];
+  if constexpr (X2) {
 #pragma unroll
-  for (int d = 0; d < NV; ++d) {
-    unpack8(qv[d], a[d]);
-    if constexpr (X2) {
+    for (int d = 0; d < NV; ++d) {
       float a2[8];
+      unpack8(qv[d], a[d]);
       unpack8(qr[d], a2);
 #pragma unroll
       for (int e = 0; e < 8; ++e) a[d][e] += a2[e];
@@ -669,19 +669,25 @@ __global__ __launch_bounds__(EXACT ? 256 : 1024) void tattn_kernel(const TAttnAr
     float dot = 0.f;
     if (EXACT || j < F) {
       const h16_t* krow = sKV + j * 2 * Cg + loff;
-      float d0 = 0.f, d1 = 0.f;         // two chains: even / odd channels
+      float d0 = 0.f, d1 = 0.f;         // two independent chains
 #pragma unroll
       for (int d = 0; d < NV; ++d) {
-        float k[8];
-        unpack8(*reinterpret_cast<const uint4*>(krow + d * 8), k);
+        const uint4 kv = *reinterpret_cast<const uint4*>(krow + d * 8);
         if constexpr (X2) {
-          float k2[8];
+          float k[8], k2[8];
+          unpack8(kv, k);
           unpack8(*reinterpret_cast<const uint4*>(krow + (sKVr - sKV) + d * 8), k2);
 #pragma unroll
           for (int e = 0; e < 8; ++e) k[e] += k2[e];
-        }
 #pragma unroll
-        for (int e = 0; e < 8; e += 2) { d0 = fmaf(a[d][e], k[e], d0); d1 = fmaf(a[d][e + 1], k[e + 1], d1); }
+          for (int e = 0; e < 8; e += 2) { d0 = fmaf(a[d][e], k[e], d0); d1 = fmaf(a[d][e + 1], k[e + 1], d1); }
+        } else {
+          // the products of 16-bit values are exact in f32 either way; the packed dot product takes the pairs as stored (the
+          // per-pixel sequences are tiny — this kernel is bound by its VALU work, not by HBM: 12 x 12 x d MACs per head and pixel
+          // with every K element unpacked once per query frame)
+          d0 = dot2h(qv[d].x, kv.x, d0); d1 = dot2h(qv[d].y, kv.y, d1);
+          d0 = dot2h(qv[d].z, kv.z, d0); d1 = dot2h(qv[d].w, kv.w, d1);
+        }
       }
       dot = d0 + d1;
 #pragma unroll

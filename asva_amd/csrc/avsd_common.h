@@ -64,6 +64,15 @@ __device__ __forceinline__ f32x16 mfma32x32x16(h16x8 a, h16x8 b, f32x16 c, int, 
 }
 #endif
 
+// c + a.lo * b.lo + a.hi * b.hi on packed 16-bit pairs, f32 result (v_dot2c_f32_bf16 / v_dot2c_f32_f16): no unpacking
+__device__ __forceinline__ float dot2h(uint32_t a, uint32_t b, float c) {
+#ifdef AVSD_F16
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(hw_h16x2, a), __builtin_bit_cast(hw_h16x2, b), c, false);
+#else
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(hw_h16x2, a), __builtin_bit_cast(hw_h16x2, b), c, false);
+#endif
+}
+
 // two f32 -> one packed pair, round-to-nearest-even in both builds (v_cvt_pk_bf16_f32 / v_cvt_f16_f32 x2)
 __device__ __forceinline__ uint32_t pack2h(float lo, float hi) {
   const hw_f32x2 v = {lo, hi};

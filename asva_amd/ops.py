@@ -431,6 +431,38 @@ def from_act(t: torch.Tensor) -> torch.Tensor:
     return t.float() + torch.as_strided(t, t.shape, t.stride(), t.storage_offset() + half).float()
 
 
+def alloc_planes(shape, device):
+    """(main, rest): two 16-bit planes of one allocation, whatever the process-wide mode — operands of an explicit three-pass
+    product (gemm(..., a_rest=, w_rest=)) under the per-layer precision plan (asva_amd/precision.py)"""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    npad = (n + 7) // 8 * 8
+    buf = torch.empty((2, npad), dtype=P.ACT, device=device)
+    return buf[0, :n].view(tuple(shape)), buf[1, :n].view(tuple(shape))
+
+
+def split_planes(x: torch.Tensor):
+    """f32 device tensor -> (main, rest) 16-bit planes: main = round16(x), rest = round16(x - main) (one launch)"""
+    x = x.contiguous()
+    _req(x, F32, "x")
+    main, rest = alloc_planes(tuple(x.shape), x.device)
+    check(_lib.lib().avsd_split_f32(_p(x), _p(main), _rest_off(main, rest), x.numel(), _stream()), "avsd_split_f32")
+    return main, rest
+
+
+def _rest_off(main: torch.Tensor, rest: Optional[torch.Tensor]) -> int:
+    """element offset from `main` to its explicit rest plane (same shape and strides)"""
+    if rest is None:
+        return 0
+    if rest.dtype != main.dtype or rest.shape != main.shape or rest.stride() != main.stride():
+        raise ValueError("rest plane must match its main plane in dtype, shape and strides")
+    off = rest.data_ptr() - main.data_ptr()
+    if off == 0 or off % 16:
+        raise ValueError("rest plane must be a distinct tensor, a multiple of 8 elements away from its main plane")
+    return off // 2
+
+
 def _req(t: torch.Tensor, dtype, name: str):
     if t.dtype != dtype:
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
@@ -472,11 +504,25 @@ def gemm(
     m: Optional[int] = None,
     tile: int = 0,
     split_k: int = 1,
+    a_rest: Optional[torch.Tensor] = None,     # explicit rest planes of a / a2 / w: THIS product runs as three MFMA passes (AVSD_GEMM_X2)
+    a2_rest: Optional[torch.Tensor] = None,    # whatever the process-wide mode (per-layer precision plan); f32 output and f32 residuals
+    w_rest: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """out = epilogue(alpha * A' . W^T); see avsd_gemm_bf16 in include/avsd.h."""
     _req(a, P.ACT, "a")
     _req(w, P.ACT, "w")
-    if P.SPLIT and mode == PLAIN and a2 is not None and a.shape[1] % 64 != 0:
+    planes = w_rest is not None
+    if planes:
+        if P.SPLIT:
+            raise ValueError("gemm: explicit rest planes are for the non-split modes (split precision carries them implicitly)")
+        if a_rest is None or (a2 is not None) != (a2_rest is not None) or not out_f32 or master is not None or rowstats is not None or ln is not None:
+            raise ValueError("gemm: a three-pass product needs a_rest and w_rest (a2_rest with a2), f32 output, no master / rowstats / LayerNorm fold")
+        if any(r is not None and r.dtype != F32 for r in (res1, res2)):
+            raise ValueError("gemm: a three-pass product reads f32 residuals")
+    elif a_rest is not None or a2_rest is not None:
+        raise ValueError("gemm: a_rest / a2_rest without w_rest")
+    x2 = P.SPLIT or planes
+    if x2 and mode == PLAIN and a2 is not None and a.shape[1] % 64 != 0:
         # the LDS-direct loader switches source buffers per 64-wide K tile and the register-staged tiles have no split form:
         # a concat split inside a K tile (tiny test networks: 160-channel skips) runs as two launches, the first leaving its
         # un-rounded f32 partial for the second's epilogue — the same sum
@@ -487,9 +533,9 @@ def gemm(
             # (GELU would be applied to the second partial alone; the other options are not forwarded by this two-launch form)
             raise ValueError("gemm: split precision with an unaligned two-source A takes bias / rowvec / one residual / alpha only")
         k1 = a.shape[1]
-        part = gemm(a, w[:, :k1], alpha=alpha, out_f32=True)
+        part = gemm(a, w[:, :k1], alpha=alpha, out_f32=True, a_rest=a_rest, w_rest=None if w_rest is None else w_rest[:, :k1])
         return gemm(a2, w[:, k1:], bias=bias, rowvec=rowvec, rows_per_vec=rows_per_vec, res1=part, res2=res1 if res1 is not None else res2,
-                    alpha=alpha, out_f32=out_f32, out=out)
+                    alpha=alpha, out_f32=out_f32, out=out, a_rest=a2_rest, w_rest=None if w_rest is None else w_rest[:, k1:])
     d = GemmDesc()
     N = w.shape[0] if n is None else n
     lda = _ld(a)
@@ -589,7 +635,10 @@ def gemm(
     d.batch = 1
     d.raster_g = _RASTER_G
     ws = None
-    if P.SPLIT:
+    if planes:
+        d.flags |= X2
+        d.a_lo, d.a2_lo, d.w_lo = _rest_off(a, a_rest), (_rest_off(a2, a2_rest) if a2 is not None else 0), _rest_off(w, w_rest)
+    elif P.SPLIT:
         if master is not None:
             raise ValueError("gemm: split precision has no f32 master (the planes carry 16 bits)")
         d.flags |= X2
@@ -613,31 +662,31 @@ def gemm(
             _set(t, sk)
             check(_lib.lib().avsd_gemm_bf16(C.byref(d), _stream()), "avsd_gemm_bf16")
 
-        cands = X2_TILE_CANDIDATES if P.SPLIT else TILE_CANDIDATES
+        cands = X2_TILE_CANDIDATES if x2 else TILE_CANDIDATES
         nk = (K + 63) // 64
         two_src_unaligned = a2 is not None and (a.shape[1] % 64 != 0)     # C falls back to register-staged tiles
         if not geglu and not two_src_unaligned and ((M + 127) // 128) * ((N + 127) // 128) < 256 and nk >= 16:
-            cands = cands + tuple(c for c in (X2_SPLITK_CANDIDATES if P.SPLIT else SPLITK_CANDIDATES) if nk // c[1] >= 4)
+            cands = cands + tuple(c for c in (X2_SPLITK_CANDIDATES if x2 else SPLITK_CANDIDATES) if nk // c[1] >= 4)
         splitk_ok = not geglu and not two_src_unaligned
         two_src_conv = mode == CONV3 and a2 is not None           # only the LDS-resident tiles read a second source
         if two_src_conv:
             cands = conv3r_candidates(d.hs, d.ws, d.cin, M, N)
             if not cands:
                 raise ValueError("gemm: no LDS-resident convolution tile takes this two-source geometry")
-        elif (_CONV3R and mode == CONV3 and not P.SPLIT and d.stride == 1 and d.ups == 0 and d.pad == 1 and ln is None):
+        elif (_CONV3R and mode == CONV3 and not x2 and d.stride == 1 and d.ups == 0 and d.pad == 1 and ln is None):
             cands = cands + conv3r_candidates(d.hs, d.ws, d.cin, M, N)
         # 16-bit convolutions are keyed by the image geometry too: which LDS-resident tiles apply depends on (hs, ws)
         key = (mode, M, N, K, d.flags, d.stride, d.ups, d.pad, int(master is not None))
-        if mode == CONV3 and not P.SPLIT:
+        if mode == CONV3 and not x2:
             key = key + (d.hs, d.ws)
         if two_src_conv:
             key = key + ("a2", d.k_split)                         # a table entry of the one-source shape may name a tile that never reads A2
         asm = ()
         if (_ASM_TILES and a2 is None and K % 64 == 0 and M * lda < (1 << 29) and N * _ld(w) < (1 << 29) and
                 (mode == PLAIN or (mode == TMIX and d.cseg % 64 == 0 and ln is None))):
-            asm = ASM_X2_CANDIDATES if P.SPLIT else tuple(c for c in ASM_CANDIDATES if mode == PLAIN or c[0] != 60)
+            asm = ASM_X2_CANDIDATES if x2 else tuple(c for c in ASM_CANDIDATES if mode == PLAIN or c[0] != 60)
             if splitk_ok and ((M + 127) // 128) * ((N + 127) // 128) < 256 and nk >= 8:
-                asm = asm + tuple(c for c in (ASM_X2_SPLITK_CANDIDATES if P.SPLIT else ASM_SPLITK_CANDIDATES)
+                asm = asm + tuple(c for c in (ASM_X2_SPLITK_CANDIDATES if x2 else ASM_SPLITK_CANDIDATES)
                                   if nk // c[1] >= 4 and (c[1] - 1) * -(-nk // c[1]) < nk)      # (no empty K slice: the asm tiles refuse it)
         if RECORD_KEYS is not None:          # tools/tune_in_step.py: which table keys a forward uses, how often, and what could run them
             rec = RECORD_KEYS.setdefault(key, {"n": 0, "cands": tuple(dict.fromkeys(tuple(cands) + tuple(asm))), "flops": 2.0 * M * N * K})
@@ -651,7 +700,7 @@ def gemm(
             picked = None
         if picked is not None and two_src_conv and picked not in cands:
             picked = None
-        heur = _heuristic_tile_x2 if P.SPLIT else _heuristic_tile
+        heur = _heuristic_tile_x2 if x2 else _heuristic_tile
         if picked is None and two_src_conv:
             picked = _heuristic_conv3r(cands, M, N)
         tile, split_k = picked if picked is not None else heur(M, N, K, geglu, splitk_ok)
@@ -662,8 +711,8 @@ def gemm(
         fam = ("gemm_plain", "gemm_tmix", "gemm_conv3")[mode]
         dc = GemmDesc.from_buffer_copy(d)
         _TIMER.add_replay(fam, lambda dc=dc: check(_lib.lib().avsd_gemm_bf16(C.byref(dc), _stream()), "avsd_gemm_bf16"),
-                          (a, a2, w, out, bias, rowvec, res1, res2, ws, rowstats, ln, master, stats_pos, ln_pos))
-        _TIMER.stop(ev, fam, 2.0 * M * N * K * (3 if P.SPLIT else 1), 2.0 * M * K * (1.0 / 9 if mode == CONV3 else 1.0 / 3 if mode == TMIX else 1.0)
+                          (a, a2, w, out, bias, rowvec, res1, res2, ws, rowstats, ln, master, stats_pos, ln_pos, a_rest, a2_rest, w_rest))
+        _TIMER.stop(ev, fam, 2.0 * M * N * K * (3 if x2 else 1), 2.0 * M * K * (1.0 / 9 if mode == CONV3 else 1.0 / 3 if mode == TMIX else 1.0)
                     + 2.0 * N * K + _nbytes(out, res1, res2))
     return out
 
@@ -788,6 +837,38 @@ def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], nb: int, rows_per_ba
                lambda: check(L.avsd_groupnorm_stats(*s_, _stream()), "avsd_groupnorm_stats"),
                lambda: check(L.avsd_groupnorm_apply(*a_, _stream()), "avsd_groupnorm_apply"))
     return out
+
+
+def groupnorm_planes(x1: torch.Tensor, x1_rest: torch.Tensor, nb: int, rows_per_batch: int, groups: int, gamma: torch.Tensor,
+                     beta: torch.Tensor, eps: float, act: bool):
+    """GroupNorm(+SiLU) of a two-plane tensor into two planes, whatever the process-wide mode: the input of a three-pass product under
+    the per-layer precision plan (conv_out reads conv_norm_out's result).  -> (main, rest)"""
+    _req(x1, P.ACT, "x1")
+    L = _lib.lib()
+    c1 = x1.shape[1]
+    out, out_rest = alloc_planes((nb * rows_per_batch, c1), x1.device)
+    lo_in, lo_out = _rest_off(x1, x1_rest), _rest_off(out, out_rest)
+    nchunks = L.avsd_groupnorm_nchunks(nb, rows_per_batch, c1)
+    partial = torch.empty((L.avsd_groupnorm_scratch_floats(nb, nchunks, groups, c1),), dtype=F32, device=x1.device)
+    s_ = (_p(x1), _ld(x1), c1, lo_in, None, 0, 0, 0, nb, rows_per_batch, groups, _p(partial), nchunks)
+    a_ = (_p(x1), _ld(x1), c1, lo_in, None, 0, 0, 0, nb, rows_per_batch, groups, _p(gamma), _p(beta), float(eps), _p(partial), nchunks, int(act),
+          _p(out), _ld(out), lo_out)
+    _timed("groupnorm", 0.0, 4.0 * _nbytes(x1) + 2.0 * _nbytes(out), (x1, x1_rest, gamma, beta, out, out_rest, partial),
+           lambda: check(L.avsd_groupnorm_stats_x2(*s_, _stream()), "avsd_groupnorm_stats_x2"),
+           lambda: check(L.avsd_groupnorm_apply_x2(*a_, _stream()), "avsd_groupnorm_apply_x2"))
+    return out, out_rest
+
+
+def ncfhw_to_rows_planes(x: torch.Tensor, cpad: int, rep: int = 1, scale: float = 1.0):
+    """ncfhw_to_rows into (main, rest) planes, whatever the process-wide mode (conv_in as a three-pass product)"""
+    _req(x, F32, "x")
+    if not x.is_contiguous():
+        raise ValueError("ncfhw_to_rows: x must be contiguous")
+    B, Cc, Fr, H, W = x.shape
+    out, rest = alloc_planes((rep * B * Fr * H * W, cpad), x.device)
+    check(_lib.lib().avsd_ncfhw_to_rows_x2(_p(x), _p(out), _rest_off(out, rest), B, Cc, Fr, H * W, cpad, rep, float(scale), _stream()),
+          "avsd_ncfhw_to_rows_x2")
+    return out, rest
 
 
 def ln_fold(stats: torch.Tensor) -> torch.Tensor:

@@ -43,7 +43,53 @@ def set_precision(name: str) -> None:
     NAME, ACT = name, _NAMES[name]
 
 
+# ---- per-layer precision plan (round 5) --------------------------------------------------------------------------------------
+# Split precision pays three MFMA passes and two planes for EVERY tensor; its 2.6e-5 leaves 40x of BASELINE.json's 1e-3 unspent.
+# oracle/precision_sensitivity.py measured where the fp16 modes lose their accuracy (profiles/r5_precision_sensitivity.json): of the
+# 1.46e-3 of "fp16 + f32 residual stream", 1.33e-3 comes from ~40 cheap products that sit ON the residual path — the 1x1 shortcut
+# convolutions of the ResBlocks and their temporal mixes, the down / up samplers, conv_in and conv_out; everything else (the 3x3
+# convolutions inside the ResBlocks, every transformer projection, the attentions) adds up to ~5e-4.  The plan
+# (asva_amd/precision_plan.json) therefore runs the whole network in IEEE-half storage with the f32 residual stream — the fast
+# one-pass kernels, LDS-resident convolution and fused cross-attention block included — and only the listed product kinds as
+# three-pass split products: their A operand is split into (main, rest) planes from the f32 master of the stream, their weights are
+# packed as two planes, their result is written in f32.
+PLAN = None
+PLAN_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "precision_plan.json")
+
+
+def set_plan(on=True, path=None) -> None:
+    """switches the per-layer precision plan on (fp16 storage + f32 residual stream + the plan's three-pass products) or off
+    (back to bf16); models are repacked on next use"""
+    global PLAN
+    if not on:
+        PLAN = None
+        set_precision("bf16")
+        return
+    import json
+
+    with open(path or PLAN_PATH) as f:
+        plan = json.load(f)
+    if plan.get("storage") != "fp16" or plan.get("residual_stream") != "f32":
+        raise ValueError("precision plan: storage must be fp16 with an f32 residual stream")
+    unknown = set(plan["three_pass"]) - {"conv_in", "conv_out", "shortcut", "shortcut_temp", "sampler", "sampler_temp"}
+    if unknown:
+        raise ValueError(f"precision plan: three-pass kinds {sorted(unknown)} are not built (asva_amd/unet.py _ffconv)")
+    set_split(False)
+    set_precision("fp16")
+    PLAN = {"three_pass": frozenset(plan["three_pass"]), "name": plan.get("name", "plan")}
+
+
+def three_pass(kind) -> bool:
+    return PLAN is not None and kind in PLAN["three_pass"]
+
+
+def plan_key():
+    return None if PLAN is None else tuple(sorted(PLAN["three_pass"]))
+
+
 if os.environ.get("AVSD_PRECISION"):
     set_precision(os.environ["AVSD_PRECISION"])
 if os.environ.get("AVSD_SPLIT", "0") != "0":
     set_split(True)
+if os.environ.get("AVSD_PRECISION_PLAN", "0") != "0":
+    set_plan(True)

@@ -24,7 +24,7 @@ from . import precision as P
 
 from . import ops
 from .conditioning import mask_to_key_index
-from .weights import from_act, is_twin, pack_conv1x1, pack_conv3x3, pack_geglu, pack_linear, rest_of, to_act
+from .weights import from_act, is_twin, pack_conv1x1, pack_conv3x3, pack_geglu, pack_linear, rest_of, to_act, to_planes
 
 CONFIG_NAME = "config.json"
 SAFETENSORS_NAME = "diffusion_pytorch_model.safetensors"
@@ -273,10 +273,19 @@ class _Pk:
 class _Act:
     """Activation rows [M, C]: `lo` = 16-bit tensor (matrix operand / norm input); `hi` = f32 master of the same values before
     rounding (f32 residual stream) or None.  `res` is what a residual add should read."""
-    __slots__ = ("lo", "hi")
+    __slots__ = ("lo", "hi", "rest")
 
-    def __init__(self, lo, hi=None):
+    def __init__(self, lo, hi=None, rest=None):
         self.lo, self.hi = lo, hi
+        self.rest = rest       # per-layer precision plan: an explicit rest plane of `lo` (input of a three-pass product)
+
+    def planes(self):
+        """(main, rest) 16-bit planes of the un-rounded values: kept ones, or split from the f32 master (one launch)"""
+        if self.rest is not None:
+            return self.lo, self.rest
+        if self.hi is None:
+            raise RuntimeError("a three-pass product needs the f32 master (or kept planes) of its input: enable the f32 residual stream")
+        return ops.split_planes(self.hi)
 
     @property
     def res(self):
@@ -312,26 +321,44 @@ class Packer:
     def aff(self, m: _Affine):
         return _Pk(g=self.reg(m.weight.detach().float()), b=self.reg(m.bias.detach().float()))
 
-    def ffconv(self, m: _FFConv):
+    def ffconv(self, m: _FFConv, kind: Optional[str] = None):
+        """kind: "conv_in" / "conv_out" / "shortcut" / "sampler" (None: the 3x3 convolutions inside a ResBlock) — under the per-layer
+        precision plan (precision.py) the spatial convolution of a listed kind and / or its temporal mix ("<kind>_temp"; conv_in and
+        conv_out as a whole) also get the REST planes of their weights: w_r / wt_r, the second operand plane of a three-pass product"""
         reg = self.reg
         cout, cin = m.weight.shape[:2]
         cop = (cout + 7) // 8 * 8
         cip = (cin + 7) // 8 * 8
         w = m.weight.detach().float()
+        whole = kind in ("conv_in", "conv_out")
+        x3 = kind is not None and P.three_pass(kind)
+        x3t = kind is not None and P.three_pass(kind if whole else kind + "_temp")
         if m.kernel == 3:
-            wp = pack_conv3x3(w, cip, cop)
+            wf = torch.zeros((cop, 3, 3, cip), dtype=torch.float32, device=w.device)
+            wf[:cout, :, :, :cin] = w.permute(0, 2, 3, 1)
+            wf = wf.reshape(cop, 9 * cip)
         else:
-            wp = torch.zeros(cop, cip, device=w.device)
-            wp[:cout, :cin] = w.reshape(cout, cin)
-            wp = to_act(wp)
+            wf = torch.zeros(cop, cip, device=w.device)
+            wf[:cout, :cin] = w.reshape(cout, cin)
         b = torch.zeros(cop, device=w.device)
         b[:cout] = m.bias.detach().float()
         wt = torch.zeros(cop, 3, cop, device=w.device)
         wt[:cout, :, :cout] = m.conv_temp.weight.detach().float().reshape(cout, 3, cout)
+        wt = wt.reshape(cop, 3 * cop)
         bt = torch.zeros(cop, device=w.device)
         bt[:cout] = m.conv_temp.bias.detach().float()
-        return _Pk(w=reg(wp), b=reg(b), wt=reg(to_act(wt.reshape(cop, 3 * cop))), bt=reg(bt),
-                   cout=cop, cin=cip, k=m.kernel)
+        p = _Pk(b=reg(b), bt=reg(bt), cout=cop, cin=cip, k=m.kernel, w_r=None, wt_r=None)
+        if x3:
+            wm, wr = to_planes(wf)
+            p.w, p.w_r = reg(wm), reg(wr)
+        else:
+            p.w = reg(to_act(wf))
+        if x3t:
+            tm, tr = to_planes(wt)
+            p.wt, p.wt_r = reg(tm), reg(tr)
+        else:
+            p.wt = reg(to_act(wt))
+        return p
 
     def conv1(self, m: _Conv):
         return _Pk(w=self.reg(pack_conv1x1(m.weight.float())), b=self.reg(m.bias.detach().float()))
@@ -372,7 +399,7 @@ class Packer:
 
     def res(self, m: _ResBlock):
         p = _Pk(norm1=self.aff(m.norm1), conv1=self.ffconv(m.conv1), norm2=self.aff(m.norm2), conv2=self.ffconv(m.conv2),
-                shortcut=self.ffconv(m.conv_shortcut) if hasattr(m, "conv_shortcut") else None,
+                shortcut=self.ffconv(m.conv_shortcut, "shortcut") if hasattr(m, "conv_shortcut") else None,
                 temb_off=self.temb_off, cout=m.conv1.weight.shape[0])
         self.temb_w.append(m.time_emb_proj.weight.detach().float())
         self.temb_b.append(m.time_emb_proj.bias.detach().float())
@@ -402,8 +429,8 @@ class Packer:
     def block(self, m: _Block):
         return _Pk(resnets=[self.res(r) for r in m.resnets],
                    attentions=[self.tr(a) for a in m.attentions] if hasattr(m, "attentions") else None,
-                   down=self.ffconv(m.downsamplers[0].conv) if hasattr(m, "downsamplers") else None,
-                   up=self.ffconv(m.upsamplers[0].conv) if hasattr(m, "upsamplers") else None)
+                   down=self.ffconv(m.downsamplers[0].conv, "sampler") if hasattr(m, "downsamplers") else None,
+                   up=self.ffconv(m.upsamplers[0].conv, "sampler") if hasattr(m, "upsamplers") else None)
 
     def finish(self, pk: _Pk, device, meta: bool = False) -> _Pk:
         """Adds the concatenated time_emb_proj matrix of every ResBlock registered so far, lays all items out in one
@@ -447,6 +474,7 @@ class Packer:
         pk.blob = blob
         pk.act_dtype = P.ACT
         pk.split = P.SPLIT
+        pk.plan = P.plan_key()
         return pk
 
 
@@ -720,7 +748,7 @@ class AudioUNet3DConditionModel(nn.Module):
             if device.type == "cuda" and device.index is None:
                 device = torch.device("cuda", torch.cuda.current_device())
         if (self._packed is not None and self._packed.act_dtype == P.ACT and getattr(self._packed, "split", False) == P.SPLIT
-                and (device is None or self._packed.blob.device == device)):
+                and getattr(self._packed, "plan", None) == P.plan_key() and (device is None or self._packed.blob.device == device)):
             return self._packed
         device = device if device is not None else self.device
         if device.type == "meta":
@@ -729,9 +757,9 @@ class AudioUNet3DConditionModel(nn.Module):
             raise RuntimeError("AudioUNet3DConditionModel.pack: the MI355X path needs a cuda (HIP) device; "
                                "move the model with .to('cuda') first — there is no CPU compute path")
         pr = Packer()
-        pk = _Pk(conv_in=pr.ffconv(self.conv_in), t1=pr.lin(self.time_embedding.linear_1), t2=pr.lin(self.time_embedding.linear_2),
+        pk = _Pk(conv_in=pr.ffconv(self.conv_in, "conv_in"), t1=pr.lin(self.time_embedding.linear_1), t2=pr.lin(self.time_embedding.linear_2),
                  down=[pr.block(b) for b in self.down_blocks], mid=pr.block(self.mid_block), up=[pr.block(b) for b in self.up_blocks],
-                 norm_out=pr.aff(self.conv_norm_out), conv_out=pr.ffconv(self.conv_out))
+                 norm_out=pr.aff(self.conv_norm_out), conv_out=pr.ffconv(self.conv_out, "conv_out"))
         self._packed = pr.finish(pk, device, meta=next(self.parameters()).is_meta)
         return self._packed
 
@@ -939,14 +967,18 @@ class AudioUNet3DConditionModel(nn.Module):
         st = _Pk(B=B, F=Fr, temb=temb, temb_rows=(Fr if (t.numel() == B and B > 1) else B * Fr), cond=cond, tr_i=0,
                  groups=self.config.norm_num_groups, eps=float(self.config.norm_eps),
                  heads=_per_block(self.config.attention_head_dim, nblk), fuse_ln=getattr(self, "fuse_layernorm", _FUSE_LN),
-                 f32_stream=getattr(self, "f32_residual", _F32_RES) and not P.SPLIT,     # split planes already carry 16 bits
+                 f32_stream=(getattr(self, "f32_residual", _F32_RES) or P.PLAN is not None) and not P.SPLIT,     # split planes already carry 16 bits; the plan's three-pass products read the f32 masters
                  fp8=(tuple(getattr(self, "fp8_scales", (1.0, 1.0, 1.0))) if getattr(self, "fp8_attention", _ATTN_FP8) else None))
 
         # branches that are still identical (see _SHARE_PREFIX): run them once until the first audio cross-attention
         pre = rep if (_SHARE_PREFIX and rep > 1 and t.numel() == 1 and getattr(cond, "share", {}).get(rep, False)
                       and pk.down[0].attentions and pk.down[0].attentions[0].audio) else 1
         st.B = B // pre
-        h = _Act(ops.ncfhw_to_rows(x32, cpad=pk.conv_in.cin, rep=rep // pre))
+        if pk.conv_in.w_r is not None:       # precision plan: conv_in is a three-pass product, its input arrives as two planes
+            hm, hr = ops.ncfhw_to_rows_planes(x32, cpad=pk.conv_in.cin, rep=rep // pre)
+            h = _Act(hm, None, hr)
+        else:
+            h = _Act(ops.ncfhw_to_rows(x32, cpad=pk.conv_in.cin, rep=rep // pre))
         hw = (H, W)
         h = _ffconv(st, h, pk.conv_in, hw)
         skips = [h]
@@ -976,8 +1008,12 @@ class AudioUNet3DConditionModel(nn.Module):
                 h = _ffconv(st, h, blk.up, hw, ups=1)
                 hw = (hw[0] * 2, hw[1] * 2)
         rows_b = Fr * hw[0] * hw[1]
-        a = ops.groupnorm(h.lo, None, B, rows_b, st.groups, pk.norm_out.g, pk.norm_out.b, st.eps, True)
-        o = _ffconv(st, _Act(a), pk.conv_out, hw, out_f32=True)
+        if pk.conv_out.w_r is not None:      # precision plan: conv_norm_out -> conv_out on two planes
+            am, ar = ops.groupnorm_planes(*h.planes(), B, rows_b, st.groups, pk.norm_out.g, pk.norm_out.b, st.eps, True)
+            a = _Act(am, None, ar)
+        else:
+            a = _Act(ops.groupnorm(h.lo, None, B, rows_b, st.groups, pk.norm_out.g, pk.norm_out.b, st.eps, True))
+        o = _ffconv(st, a, pk.conv_out, hw, out_f32=True)
         return ops.rows_to_ncfhw(o.lo, B, self.config.out_channels, Fr, H, W)
 
 
@@ -999,11 +1035,36 @@ def _ffconv(st, x: _Act, p, hw, stride=1, ups=0, temb=None, res: Optional[_Act] 
         rows = x.lo.shape[0]
     # f32 residual stream: the conv output y is itself a residual term (out = y + conv_temp(...), utils.py:53) — keep its
     # un-rounded copy for that addition; the 16-bit copy feeds the temporal-mix product
-    ym = torch.empty((rows, p.cout), dtype=torch.float32, device=x.lo.device) if (st.f32_stream and _F32_CONV_Y) else None
-    if p.k == 3:
+    x3, x3t = getattr(p, "w_r", None) is not None, getattr(p, "wt_r", None) is not None     # three-pass products of the precision plan
+    ym = torch.empty((rows, p.cout), dtype=torch.float32, device=x.lo.device) if (st.f32_stream and _F32_CONV_Y and not x3) else None
+    yr = None
+    if x3:
+        # three MFMA passes on (main, rest) planes of the input and of the weights, f32 result; its planes feed the temporal mix
+        xm, xr = x.planes()
+        if p.k == 3:
+            ym = ops.gemm(xm, p.w, bias=p.b, mode=ops.CONV3, conv=(n_img, hw[0], hw[1], stride, ups), out_f32=True, a_rest=xr, w_rest=p.w_r)
+        else:
+            x2m, x2r = (None, None) if x2 is None else x2.planes()
+            ym = ops.gemm(xm, p.w, a2=x2m, bias=p.b, out_f32=True, a_rest=xr, a2_rest=x2r, w_rest=p.w_r)
+        y, yr = ops.split_planes(ym)
+    elif p.k == 3:
         y = ops.gemm(x.lo, p.w, bias=p.b, mode=ops.CONV3, conv=(n_img, hw[0], hw[1], stride, ups), master=ym)
     else:
         y = ops.gemm(x.lo, p.w, a2=None if x2 is None else x2.lo, bias=p.b, master=ym)
+    if x3t:
+        if ym is None:
+            raise RuntimeError("a three-pass temporal mix needs the f32 copy of the convolution output (f32 residual stream)")
+        if yr is None:
+            y, yr = ops.split_planes(ym)
+        if res is not None and res.hi is None:
+            raise RuntimeError("a three-pass temporal mix adds f32 residuals only")
+        outm = ops.gemm(y, p.wt, bias=p.bt, res1=ym, res2=None if res is None else res.hi, rowvec=temb,
+                        rows_per_vec=(st.temb_rows * ho * wo) if temb is not None else 0,
+                        mode=ops.TMIX, tmix=(ho * wo, st.F), out_f32=True, a_rest=yr, w_rest=p.wt_r)
+        if out_f32:
+            return _Act(outm)
+        o16, o16r = ops.split_planes(outm)
+        return _Act(o16, outm if master else None, o16r)
     m = _master(st, y, p.cout) if (master and not out_f32) else None
     out = ops.gemm(y, p.wt, bias=p.bt, res1=y if ym is None else ym, res2=None if res is None else res.res, rowvec=temb,
                    rows_per_vec=(st.temb_rows * ho * wo) if temb is not None else 0,

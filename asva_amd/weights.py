@@ -34,6 +34,16 @@ def to_act(w: torch.Tensor) -> torch.Tensor:
     return base[0, :n].view(w.shape)
 
 
+def to_planes(w: torch.Tensor):
+    """f32 values -> (main, rest) as two separate 16-bit tensors, whatever the process-wide mode: the weights of a three-pass
+    product under the per-layer precision plan (precision.py)"""
+    w = w.detach().float().contiguous()
+    main = w.to(P.ACT)
+    if w.device.type == "meta":
+        return main, torch.empty_like(main)
+    return main, (w - main.float()).to(P.ACT)
+
+
 def is_twin(t: torch.Tensor) -> bool:
     """True for a view into the first half of a twin allocation (see to_act)"""
     nb = t.untyped_storage().nbytes()

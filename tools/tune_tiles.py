@@ -35,6 +35,10 @@ def main():
     ap.add_argument("--only-cfg2", action="store_true")
     ap.add_argument("--split", action="store_true", help="tune the split-precision (AVSD_GEMM_X2) shapes of cfg 2 and the VAE "
                                                         "(their table keys carry the X2 flag, so they live beside the 16-bit ones)")
+    ap.add_argument("--clips", default="", help="with --extend: only these clips-per-forward counts at the cfg-2 geometry (e.g. 2,8: the "
+                                                "bench's clips sweep), nothing else")
+    ap.add_argument("--plan", action="store_true", help="with --extend: the per-layer precision plan's shapes (fp16 library, f32 residual stream, "
+                                                       "three-pass products with f32 output: their keys carry the X2 / OUT_F32 / RES_F32 flags)")
     a = ap.parse_args()
     ops.set_autotune(True)
     dev = torch.device("cuda", 0)
@@ -42,6 +46,10 @@ def main():
         from asva_amd import precision as P
 
         P.set_split(True)
+    if a.plan:
+        from asva_amd import precision as P
+
+        P.set_plan(True)
     unet = bench.build_unet(dev, 0, 1)
     t0 = time.time()
 
@@ -61,6 +69,12 @@ def main():
         torch.cuda.synchronize()
         print(f"tuned ({branches * n_clips}, 4, {frames}, {hw}, {hw}): {len(ops.tile_cache())} shapes, {time.time() - t0:.0f} s", flush=True)
 
+    if a.clips or a.plan:
+        for n in ([int(v) for v in a.clips.split(",")] if a.clips else [1]):
+            fwd(n, 12, 32)
+        ops.save_tile_cache(a.out)
+        print(f"wrote {a.out}: {len(ops.tile_cache())} shapes in {time.time() - t0:.0f} s")
+        return
     fwd(1, 12, 32)              # cfg 2
     if a.only_cfg2:
         for row in ops.CHALLENGE_LOG:

@@ -24,11 +24,11 @@
 
 namespace {
 
-template <int NV, bool X2>
-__global__ __launch_bounds__(480) void gn_fused_kernel(const h16_t* x1, int ld1, int c1, int64_t lo1, const h16_t* x2, int ld2, int c2,
+template <int NV, bool X2, int TMAX>
+__global__ __launch_bounds__(TMAX) void gn_fused_kernel(const h16_t* x1, int ld1, int c1, int64_t lo1, const h16_t* x2, int ld2, int c2,
                                                       int64_t lo2, int rows_per_batch, int cg, int gpw, float eps,
                                                       const float* gamma, const float* beta, int act, h16_t* y, int ldy, int64_t loy) {
-  __shared__ float4 red[480];          // per thread: (sum, sumsq) of its first group, (sum, sumsq) of its second
+  __shared__ float4 red[TMAX];         // per thread: (sum, sumsq) of its first group, (sum, sumsq) of its second
   __shared__ float smean[8], srstd[8];
   const int tid = threadIdx.x, T = blockDim.x;
   const int span = gpw * cg, vpr = span / 8;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(480) void gn_fused_kernel(const h16_t* x1, int ld1,
 // T threads (a multiple of the vectors per row), nv vectors per thread.
 struct gn_fused_geo { int gpw, threads, nv; };
 
-bool gn_fused_geometry(int rows_per_batch, int groups, int C, bool x2, gn_fused_geo* out) {
+bool gn_fused_geometry(int nb, int rows_per_batch, int groups, int C, bool x2, gn_fused_geo* out) {
   if (groups <= 0 || C % groups) return false;
   const int cg = C / groups;
   if (cg < 8 && cg != 4) return false;                 // a vector may touch at most two groups
@@ -167,7 +167,6 @@ bool gn_fused_geometry(int rows_per_batch, int groups, int C, bool x2, gn_fused_
   while (gpw <= 8 && gpw <= groups && ((gpw * cg) % 8 != 0 || (gpw * cg < 40 && gpw * 2 <= groups && gpw * 2 <= 8))) gpw *= 2;
   if (gpw > 8 || gpw > groups || groups % gpw || (gpw * cg) % 8) return false;
   const int vpr = gpw * cg / 8;
-  (void)x2;
   for (int T : {240, 480}) {
     if (T % vpr) continue;
     const int rpi = T / vpr;
@@ -179,14 +178,27 @@ bool gn_fused_geometry(int rows_per_batch, int groups, int C, bool x2, gn_fused_
       return true;
     }
   }
+  // Round 5: MANY batches (the per-frame norm of a Transformer3D block at 32 x 32: 24 frames x 8 group-quads = 192 workgroups) keep
+  // the chip busy even with a bigger slab per workgroup — 960 threads, up to 8 vectors each.  The limit above exists for the pooled
+  // ResBlock norms, whose 2 x 32 / gpw workgroups cannot (see the header).  Not in split precision (two planes per vector).
+  if (!x2 && (int64_t)nb * (groups / gpw) >= 128 && 960 % vpr == 0) {
+    const int rpi = 960 / vpr;
+    const int nv = (rows_per_batch + rpi - 1) / rpi;
+    if (nv <= 8) {
+      out->gpw = gpw;
+      out->threads = 960;
+      out->nv = nv;
+      return true;
+    }
+  }
   return false;
 }
 
-template <int NV, bool X2>
+template <int NV, bool X2, int TMAX = 480>
 void launch_gn_fused(dim3 grid, int threads, hipStream_t s, const h16_t* x1, int ld1, int c1, int64_t lo1, const h16_t* x2, int ld2, int c2,
                      int64_t lo2, int rows_per_batch, int cg, int gpw, float eps, const float* gamma, const float* beta, int act, h16_t* y,
                      int ldy, int64_t loy) {
-  hipLaunchKernelGGL((gn_fused_kernel<NV, X2>), grid, dim3((unsigned)threads), 0, s, x1, ld1, c1, lo1, x2, ld2, c2, lo2, rows_per_batch, cg, gpw,
+  hipLaunchKernelGGL((gn_fused_kernel<NV, X2, TMAX>), grid, dim3((unsigned)threads), 0, s, x1, ld1, c1, lo1, x2, ld2, c2, lo2, rows_per_batch, cg, gpw,
                      eps, gamma, beta, act, y, ldy, loy);
 }
 
@@ -196,7 +208,7 @@ extern "C" int avsd_groupnorm_fused_supported(int nb, int rows_per_batch, int gr
   if (nb <= 0 || rows_per_batch <= 0 || c1 <= 0 || c1 % 8 || c2 < 0 || c2 % 8) return 0;
   if (groups < 4 || groups > 64 || (groups & (groups - 1))) return 0;
   gn_fused_geo g;
-  return gn_fused_geometry(rows_per_batch, groups, c1 + c2, split != 0, &g) ? 1 : 0;
+  return gn_fused_geometry(nb, rows_per_batch, groups, c1 + c2, split != 0, &g) ? 1 : 0;
 }
 
 extern "C" int avsd_groupnorm_fused_x2(const void* x1, int ld1, int c1, int64_t lo1, const void* x2, int ld2, int c2, int64_t lo2, int nb,
@@ -213,7 +225,7 @@ extern "C" int avsd_groupnorm_fused_x2(const void* x1, int ld1, int c1, int64_t 
   AVSD_REQUIRE(y && gamma && beta && ldy % 8 == 0 && ldy >= C, "groupnorm_fused: bad output (ldy=%d)", ldy);
   const bool split = lo1 != 0;
   gn_fused_geo g;
-  AVSD_REQUIRE(gn_fused_geometry(rows_per_batch, groups, C, split, &g),
+  AVSD_REQUIRE(gn_fused_geometry(nb, rows_per_batch, groups, C, split, &g),
                "groupnorm_fused: a (%d rows x %d channels / %d groups) batch is outside the one-launch geometry (avsd_groupnorm_fused_supported)",
                rows_per_batch, C, groups);
   const dim3 grid((unsigned)(groups / g.gpw), (unsigned)nb);
@@ -226,7 +238,9 @@ extern "C" int avsd_groupnorm_fused_x2(const void* x1, int ld1, int c1, int64_t 
                                       o, ldy, loy)                                                                                       \
          : launch_gn_fused<NVV, false>(grid, g.threads, s, a, ld1, c1, lo1, bsrc, ld2, c2, lo2, rows_per_batch, cg, g.gpw, eps, gamma, beta, act, \
                                        o, ldy, loy))
-  if (g.nv <= 2) AVSD_GNF(2);
+  if (g.threads > 480)
+    launch_gn_fused<8, false, 960>(grid, g.threads, s, a, ld1, c1, lo1, bsrc, ld2, c2, lo2, rows_per_batch, cg, g.gpw, eps, gamma, beta, act, o, ldy, loy);
+  else if (g.nv <= 2) AVSD_GNF(2);
   else AVSD_GNF(4);
 #undef AVSD_GNF
   AVSD_CHECK_LAUNCH("groupnorm_fused launch");
@@ -237,3 +251,4 @@ extern "C" int avsd_groupnorm_fused(const void* x1, int ld1, int c1, const void*
                                     const float* gamma, const float* beta, float eps, int act, void* y, int ldy, void* stream) {
   return avsd_groupnorm_fused_x2(x1, ld1, c1, 0, x2, ld2, c2, 0, nb, rows_per_batch, groups, gamma, beta, eps, act, y, ldy, 0, stream);
 }
+

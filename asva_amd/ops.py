@@ -789,7 +789,6 @@ def linear_small_m(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
 # one-launch GroupNorm for small batches (csrc/groupnorm_fused.hip); AVSD_GN_FUSED=0: always the pair
 _GN_FUSED = True
 
-
 def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], nb: int, rows_per_batch: int, groups: int,
               gamma: torch.Tensor, beta: torch.Tensor, eps: float, act: bool,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:

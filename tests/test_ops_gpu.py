@@ -426,6 +426,9 @@ def test_linear_small_m(ops):
     (24, 16, 1280, 0, 32, False),
     (12, 256, 512, 0, 32, True),         # 16 channels per group
     (2, 12 * 1024, 320, 0, 32, True),    # 32 x 32 level: stats + apply either way
+    (2, 12 * 1024, 640, 320, 32, True),  # ... its widest skip concat (30 channels per group, 12 vectors per thread)
+    (2, 12 * 256, 1280, 640, 32, True),
+    (24, 1024, 320, 0, 32, False),       # per-frame norm at 32 x 32: the 960-thread one-launch form
     (3, 50, 32, 0, 8, True),             # 4 channels per group: a vector holds two whole groups
 ])
 def test_groupnorm(ops, nb, rows, c1, c2, groups, act, fused, monkeypatch):
@@ -457,8 +460,10 @@ def test_groupnorm_one_launch_geometry():
     # the small batches are one launch: ResBlock norms at 4 x 4, per-frame norms up to 16 x 16
     for nb, rows, c1, c2 in [(2, 192, 1280, 0), (2, 192, 1280, 1280), (24, 256, 640, 0), (24, 64, 1280, 0), (24, 16, 1280, 0)]:
         assert L.avsd_groupnorm_fused_supported(nb, rows, 32, c1, c2, 0) == 1 and L.avsd_groupnorm_fused_supported(nb, rows, 32, c1, c2, 1) == 1
-    for nb, rows, c1, c2 in [(2, 12288, 320, 0), (2, 3072, 640, 0), (2, 768, 1280, 0), (24, 1024, 320, 0), (12, 16384, 256, 0)]:
+    for nb, rows, c1, c2 in [(2, 12288, 320, 0), (2, 3072, 640, 0), (2, 768, 1280, 0), (12, 16384, 256, 0)]:
         assert L.avsd_groupnorm_fused_supported(nb, rows, 32, c1, c2, 0) == 0
+    # many batches keep the chip busy with bigger slabs (960 threads x <= 8 vectors): the per-frame norm at 32 x 32; 16-bit storage only
+    assert L.avsd_groupnorm_fused_supported(24, 1024, 32, 320, 0, 0) == 1 and L.avsd_groupnorm_fused_supported(24, 1024, 32, 320, 0, 1) == 0
     assert L.avsd_groupnorm_fused(None, 320, 320, None, 0, 0, 2, 12288, 32, None, None, 1e-5, 1, None, 320, None) != 0     # refused, not launched
 
 

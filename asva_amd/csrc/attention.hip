@@ -210,6 +210,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
 
       // ---- online softmax: lane owns query l31, keys (r&3) + 8*(r>>2) + 4*half -------------------
       if (tail) {
+        // A REAL branch (the empty asm statement cannot be speculated): hipcc otherwise if-converts this wave-uniform test into 16 x
+        // (add, compare, select) executed on EVERY tile — 48 VALU instructions per tile.  (Measured neutral on the kernel's time, round 5:
+        // neither the VALU count nor the LDS operand latency bounds it — issuing all operand reads of a tile behind the barrier costs 15
+        // registers = one wave per SIMD and ran 72.0 vs 69.3 us at 32 x 32; the kernel lives on its occupancy, profiles/r5_pmc_attention.md)
+        asm volatile("; tail tile" ::: "memory");
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -475,6 +480,7 @@ __global__ __launch_bounds__(256, 1) void attn_wide_kernel(const AttnArgs p) {
       s[4 * j] = tot.x; s[4 * j + 1] = tot.y; s[4 * j + 2] = tot.z; s[4 * j + 3] = tot.w;
     }
     if ((t + 1 == ntiles) && (p.Lk & 31)) {
+      asm volatile("; tail tile" ::: "memory");   // keeps the wave-uniform test a real branch (attn_kernel)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = (r & 3) + 8 * (r >> 2) + 4 * half;

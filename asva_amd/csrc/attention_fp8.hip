@@ -200,6 +200,7 @@ __global__ __launch_bounds__(256, 2) void attn_f8_kernel(const AttnF8Args p) {
       s = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(as_long(kf.x, kf.y), qf[c], s, 0, 0, 0);
     }
     if (tail) {
+      asm volatile("; tail tile" ::: "memory");   // keeps the wave-uniform test a real branch (attention.hip attn_kernel)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = (r & 3) + 8 * (r >> 2) + 4 * half;

@@ -181,6 +181,7 @@ __global__ __launch_bounds__(256, 1) void attn_x2_kernel(const AttnX2Args p) {
     }
     // ---- online softmax: lane owns query l31, keys (r & 3) + 8 (r >> 2) + 4 half -----------------------
     if ((t + 1 == ntiles) && (p.Lk & 31)) {
+      asm volatile("; tail tile" ::: "memory");   // keeps the wave-uniform test a real branch (attention.hip attn_kernel)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -386,6 +387,7 @@ __global__ __launch_bounds__(256, 1) void attn_x2_wide_kernel(const AttnX2Args p
       s[4 * j] = tot.x; s[4 * j + 1] = tot.y; s[4 * j + 2] = tot.z; s[4 * j + 3] = tot.w;
     }
     if ((t + 1 == ntiles) && (p.Lk & 31)) {
+      asm volatile("; tail tile" ::: "memory");   // keeps the wave-uniform test a real branch (attention.hip attn_kernel)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = (r & 3) + 8 * (r >> 2) + 4 * half;

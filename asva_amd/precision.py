@@ -71,7 +71,8 @@ def set_plan(on=True, path=None) -> None:
         plan = json.load(f)
     if plan.get("storage") != "fp16" or plan.get("residual_stream") != "f32":
         raise ValueError("precision plan: storage must be fp16 with an f32 residual stream")
-    unknown = set(plan["three_pass"]) - {"conv_in", "conv_out", "shortcut", "shortcut_temp", "sampler", "sampler_temp"}
+    # entries: a kind (every product of that kind) or "kind@block" for one block's ("sampler@up_blocks.2", "shortcut_temp@down_blocks.1")
+    unknown = {e.split("@")[0] for e in plan["three_pass"]} - {"conv_in", "conv_out", "shortcut", "shortcut_temp", "sampler", "sampler_temp"}
     if unknown:
         raise ValueError(f"precision plan: three-pass kinds {sorted(unknown)} are not built (asva_amd/unet.py _ffconv)")
     set_split(False)
@@ -79,8 +80,9 @@ def set_plan(on=True, path=None) -> None:
     PLAN = {"three_pass": frozenset(plan["three_pass"]), "name": plan.get("name", "plan")}
 
 
-def three_pass(kind) -> bool:
-    return PLAN is not None and kind in PLAN["three_pass"]
+def three_pass(kind, where=None) -> bool:
+    """is this product kind (optionally: of block `where`, e.g. "up_blocks.2") a three-pass split product under the active plan?"""
+    return PLAN is not None and (kind in PLAN["three_pass"] or (where is not None and f"{kind}@{where}" in PLAN["three_pass"]))
 
 
 def plan_key():

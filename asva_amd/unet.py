@@ -321,7 +321,7 @@ class Packer:
     def aff(self, m: _Affine):
         return _Pk(g=self.reg(m.weight.detach().float()), b=self.reg(m.bias.detach().float()))
 
-    def ffconv(self, m: _FFConv, kind: Optional[str] = None):
+    def ffconv(self, m: _FFConv, kind: Optional[str] = None, where: Optional[str] = None):
         """kind: "conv_in" / "conv_out" / "shortcut" / "sampler" (None: the 3x3 convolutions inside a ResBlock) — under the per-layer
         precision plan (precision.py) the spatial convolution of a listed kind and / or its temporal mix ("<kind>_temp"; conv_in and
         conv_out as a whole) also get the REST planes of their weights: w_r / wt_r, the second operand plane of a three-pass product"""
@@ -331,8 +331,8 @@ class Packer:
         cip = (cin + 7) // 8 * 8
         w = m.weight.detach().float()
         whole = kind in ("conv_in", "conv_out")
-        x3 = kind is not None and P.three_pass(kind)
-        x3t = kind is not None and P.three_pass(kind if whole else kind + "_temp")
+        x3 = kind is not None and P.three_pass(kind, where)
+        x3t = kind is not None and P.three_pass(kind if whole else kind + "_temp", where)
         if m.kernel == 3:
             wf = torch.zeros((cop, 3, 3, cip), dtype=torch.float32, device=w.device)
             wf[:cout, :, :, :cin] = w.permute(0, 2, 3, 1)
@@ -397,9 +397,9 @@ class Packer:
                 p.wkv_ln, p.skv_ln, p.bkv_ln = reg(wf), reg(cs), reg(cb)
         return p
 
-    def res(self, m: _ResBlock):
+    def res(self, m: _ResBlock, where: Optional[str] = None):
         p = _Pk(norm1=self.aff(m.norm1), conv1=self.ffconv(m.conv1), norm2=self.aff(m.norm2), conv2=self.ffconv(m.conv2),
-                shortcut=self.ffconv(m.conv_shortcut, "shortcut") if hasattr(m, "conv_shortcut") else None,
+                shortcut=self.ffconv(m.conv_shortcut, "shortcut", where) if hasattr(m, "conv_shortcut") else None,
                 temb_off=self.temb_off, cout=m.conv1.weight.shape[0])
         self.temb_w.append(m.time_emb_proj.weight.detach().float())
         self.temb_b.append(m.time_emb_proj.bias.detach().float())
@@ -426,11 +426,12 @@ class Packer:
             p.attn_audio = self.attn(b.attn_audio, False, b.norm_audio)
         return p
 
-    def block(self, m: _Block):
-        return _Pk(resnets=[self.res(r) for r in m.resnets],
+    def block(self, m: _Block, where: Optional[str] = None):
+        """where: the block's name in the model ("down_blocks.1"), for per-block entries of the precision plan"""
+        return _Pk(resnets=[self.res(r, where) for r in m.resnets],
                    attentions=[self.tr(a) for a in m.attentions] if hasattr(m, "attentions") else None,
-                   down=self.ffconv(m.downsamplers[0].conv, "sampler") if hasattr(m, "downsamplers") else None,
-                   up=self.ffconv(m.upsamplers[0].conv, "sampler") if hasattr(m, "upsamplers") else None)
+                   down=self.ffconv(m.downsamplers[0].conv, "sampler", where) if hasattr(m, "downsamplers") else None,
+                   up=self.ffconv(m.upsamplers[0].conv, "sampler", where) if hasattr(m, "upsamplers") else None)
 
     def finish(self, pk: _Pk, device, meta: bool = False) -> _Pk:
         """Adds the concatenated time_emb_proj matrix of every ResBlock registered so far, lays all items out in one
@@ -758,7 +759,8 @@ class AudioUNet3DConditionModel(nn.Module):
                                "move the model with .to('cuda') first — there is no CPU compute path")
         pr = Packer()
         pk = _Pk(conv_in=pr.ffconv(self.conv_in, "conv_in"), t1=pr.lin(self.time_embedding.linear_1), t2=pr.lin(self.time_embedding.linear_2),
-                 down=[pr.block(b) for b in self.down_blocks], mid=pr.block(self.mid_block), up=[pr.block(b) for b in self.up_blocks],
+                 down=[pr.block(b, f"down_blocks.{i}") for i, b in enumerate(self.down_blocks)], mid=pr.block(self.mid_block, "mid_block"),
+                 up=[pr.block(b, f"up_blocks.{i}") for i, b in enumerate(self.up_blocks)],
                  norm_out=pr.aff(self.conv_norm_out), conv_out=pr.ffconv(self.conv_out, "conv_out"))
         self._packed = pr.finish(pk, device, meta=next(self.parameters()).is_meta)
         return self._packed

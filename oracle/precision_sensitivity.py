@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 from oracle import unet_ref  # noqa: E402
 
+FINE_SAMPLERS = os.environ.get("FINE_SAMPLERS", "0") != "0"
 LEVELS = {"down_blocks.0": "r32", "down_blocks.1": "r16", "down_blocks.2": "r8", "down_blocks.3": "r4", "mid_block": "r4",
           "up_blocks.0": "r4", "up_blocks.1": "r8", "up_blocks.2": "r16", "up_blocks.3": "r32"}
 
@@ -55,7 +56,9 @@ def group_of(name: str) -> str | None:
     # up-block samplers feed the next (finer) level; down-block samplers the next coarser: keep them with their block
     rest = base[len(blk.group(0)):]
     if "samplers" in rest:
-        return ("sampler_temp@" if rest.endswith("conv_temp") else "sampler@") + lvl
+        # FINE_SAMPLERS: down- and up-samplers apart (the plan can list single samplers: "sampler@up_blocks.2")
+        side = ("_down" if rest.startswith("down") else "_up") if FINE_SAMPLERS else ""
+        return ("sampler" + side + "_temp@" if rest.endswith("conv_temp") else "sampler" + side + "@") + lvl
     if rest.startswith("resnets"):
         if "conv_shortcut" in rest:
             return ("shortcut_temp@" if rest.endswith("conv_temp") else "shortcut@") + lvl

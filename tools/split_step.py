@@ -8,7 +8,10 @@ from asva_amd.conditioning import audio_segment_mask
 from asva_amd.engine import DenoiseEngine
 from asva_amd.schedulers import DDIMScheduler
 
-P.set_split(True)
+if os.environ.get("MODE", "split") == "plan":      # MODE=plan: the per-layer precision plan instead (asva_amd/precision_plan.json)
+    P.set_plan(True)
+else:
+    P.set_split(True)
 dev = torch.device("cuda", 0)
 unet = bench.build_unet(dev, 0, 1)
 lat, text, audio, null_audio = bench.synthetic_clip(dev, 1000)
@@ -25,4 +28,4 @@ for i in range(steps):
     eng.step(x, (3 + i) % 50)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
-print(f"split-precision step: {dt * 1e3:.3f} ms ({1 / dt:.2f} steps/s), finite {bool(torch.isfinite(x).all())}")
+print(f"{os.environ.get('MODE', 'split')}-precision step: {dt * 1e3:.3f} ms ({1 / dt:.2f} steps/s), finite {bool(torch.isfinite(x).all())}")

@@ -575,12 +575,14 @@ __device__ __forceinline__ void epilogue_each(const avsd_gemm_desc& p, f32x16 (&
   const bool lnfuse = (p.flags & AVSD_GEMM_LNFUSE) != 0;
   static_for<FM>([&](auto b_c) {
     constexpr int B = decltype(b_c)::value;
-    // LayerNorm fold: the row statistics of this lane's row, folded ONCE per row band (the one-fragment calls below take them as given)
+    // LayerNorm fold: the row statistics of this lane's row, folded ONCE per row band
     float pl[2] = {1.f, 0.f};
     if (lnfuse) {
       if (have_pre) { pl[0] = pre_ln[2 * B]; pl[1] = pre_ln[2 * B + 1]; }
       else ln_row_stats(p, min(m_base + B * mstride + (lane & 31), p.M - 1), bz, pl[0], pl[1]);
     }
+    // one fragment at a time (a whole band in the term-at-a-time form was tried: with 160 accumulators live beside its batched loads the
+    // 256 x 160 convolution tile spilled 1552 registers)
     static_for<FN>([&](auto a_c) {
       constexpr int A = decltype(a_c)::value;
       __builtin_amdgcn_sched_barrier(0);          // fragments are independent: keep each one's loads and stores together

@@ -122,6 +122,16 @@ __global__ __launch_bounds__(512, 2) void xattn_kernel(const XAttnArgs p) {
     issue_pieces<PW, NWAVE>(rsWq, sb_ + A_BYTES, wave, wqoff, (kt_) * BK);                             \
   } while (0)
   XATTN_ISSUE1(0);
+  // K of this tile's conditioning block goes out NOW (round 5): its registers ride through stage 1 and the data has landed when the
+  // stage-1 ring is free to take it — the staging phase between the two products was 17 % of the kernel's cycles (profiles/r5_xattn_phases.txt)
+  constexpr int KV8 = C / 8, VV8 = LKP / 8;                 // 16-byte vectors per K row / per V^T row
+  constexpr int NKV = (LKP * KV8 + 511) / 512, NVV = (C * VV8 + 511) / 512;
+  uint4 kreg[NKV];
+  {
+    const uint4* gk = reinterpret_cast<const uint4*>(p.Kc + (int64_t)kvb * LKP * C);
+#pragma unroll
+    for (int u = 0; u < NKV; ++u) kreg[u] = gk[min(tid + u * 512, LKP * KV8 - 1)];
+  }
   // LayerNorm statistics of this lane's row, fetched while tile 0 is in flight
   float ln_rstd, ln_mr;
   {
@@ -158,14 +168,7 @@ __global__ __launch_bounds__(512, 2) void xattn_kernel(const XAttnArgs p) {
   // ---- K [LKP][C] and V^T [C][LKP] of this tile's conditioning block (L2-resident, shared by every row tile): every
   // global load is issued before anything waits on one — a load / store loop would pay one L2 round trip per iteration —
   // and the Q conversion below runs while they are in flight
-  constexpr int KV8 = C / 8, VV8 = LKP / 8;                 // 16-byte vectors per K row / per V^T row
-  constexpr int NKV = (LKP * KV8 + 511) / 512, NVV = (C * VV8 + 511) / 512;
-  uint4 kreg[NKV], vreg[NVV];
-  {
-    const uint4* gk = reinterpret_cast<const uint4*>(p.Kc + (int64_t)kvb * LKP * C);
-#pragma unroll
-    for (int u = 0; u < NKV; ++u) kreg[u] = gk[min(tid + u * 512, LKP * KV8 - 1)];
-  }
+  uint4 vreg[NVV];
   // ---- q = rstd * acc - mean * rstd * colsum + bias, rounded, as MFMA B operands: k-block kb = 16 channels of the wave ----
   h16x8 qf[2 * FN];
 #pragma unroll
@@ -352,7 +355,10 @@ __global__ __launch_bounds__(512, 2) void xattn_kernel(const XAttnArgs p) {
     }
   }
   const float no_pre[2] = {0.f, 0.f};
-  epilogue<FN, 1>(p.epi, acc, row0 + wm * 32, wn * NCOL, lane, 0, no_pre, false);
+  // term-at-a-time over the wave's five fragments (80 accumulator registers leave room for the batched loads): the fragment-at-a-time form the
+  // shared dispatcher picks for five fragments serialises five dependent L2 round trips per wave — 35 % (audio) / 29 % (text) of this kernel's
+  // cycles with per-phase cycle stamps (tools/xattn_bench.py, AVSD_XATTN_TIMING; profiles/r5_xattn_phases.txt)
+  epilogue_by_term<FN, 1>(p.epi, acc, row0 + wm * 32, wn * NCOL, lane, 0, no_pre, false);
 #undef XATTN_ISSUE1
 }
 

@@ -174,6 +174,33 @@ def test_split_precision_plans_replay_bit_identically(tmp_path, split_precision)
     b.close()
 
 
+@pytest.fixture
+def precision_plan():
+    from asva_amd import precision as P
+
+    P.set_plan(True)
+    yield
+    P.set_plan(False)
+
+
+def test_precision_plan_launch_plans_replay_bit_identically(tmp_path, precision_plan):
+    """The per-layer precision plan (asva_amd/precision_plan.json: fp16 + f32 residual stream, three-pass split products on the residual path)
+    is again only library launches — avsd_split_f32 makes the operand planes, the two-plane weights travel inside the CONST blob, the
+    three-pass products are avsd_gemm_bf16 descriptors with AVSD_GEMM_X2: a bundle recorded in the mode replays from zero-filled buffers bit
+    for bit."""
+    r = _record(tmp_path, "ddim", steps=2)
+    b = r["bundle"]
+    b.bind_fresh(r["lat0"].device)
+    for name, src in (("text", r["text"]), ("audio", r["audio"]), ("x", r["lat0"]), ("t", r["t"]), ("latents", r["lat0"])):
+        b.view(name).copy_(_bytes(src))
+    for p in ("set_conditioning", "forward", "decode"):
+        b.run(p)
+    torch.cuda.synchronize()
+    assert torch.equal(b.view("noise_pred"), _bytes(r["noise"]))
+    assert torch.equal(b.view("frames"), _bytes(r["frames"]))
+    b.close()
+
+
 @pytest.mark.parametrize("kind", ["pndm", "ddim"])
 def test_cpp_host_runs_the_denoising_loop_without_python(tmp_path, kind):
     from asva_amd import _lib, build

@@ -70,6 +70,21 @@ for kind, lk, per_frame in (("audio", 25, True), ("text", 77, False)):
         ops.attention(q, k2, v2, bq=B * Fr, lq=L, lk=lk, kv_rows=lk, heads=heads, q_per_kv=qpk, frames=Fr, out=o)
         ops.gemm(o, wo, bias=bo, res1=h, rowstats=stats_out, out=out)
 
+    if os.environ.get("AVSD_XATTN_TIMING"):      # a library built with per-phase cycle stamps (xattn_dbg, see tools/README.md): phase split per workgroup
+        import ctypes, numpy as np
+        from asva_amd import _lib
+        for _ in range(3):
+            fused()
+        torch.cuda.synchronize()
+        buf = np.zeros(512 * 8, dtype=np.uint64)
+        rc = _lib.lib().avsd_xattn_debug_read(ctypes.c_void_p(buf.ctypes.data))
+        d = buf.reshape(512, 8)[: M // 128].astype(np.float64)
+        ph = np.diff(d[:, :6], axis=1)
+        names = ("stage 1 (Q = LN-fold(h) Wq)", "Q conversion + K / V^T staging", "stage 2 (attention, 8 heads)", "stage 3 (O Wo)", "epilogue")
+        print(f"{kind}: cycles per phase, median over {M // 128} workgroups (100 MHz s_memtime ticks x ?): rc {rc}")
+        for n_, col in zip(names, ph.T):
+            print(f"   {n_:34s} median {np.median(col):9.0f}  min {col.min():9.0f}  max {col.max():9.0f}")
+        print(f"   whole workgroup                    median {np.median(d[:, 5] - d[:, 0]):9.0f};  first start -> last end {d[:, 5].max() - d[:, 0].min():9.0f}")
     t_f, t_s = timed(fused, a.reps), timed(sep, a.reps)
     fl = 4.0 * M * C * C + 4.0 * M * lk * C
     print(f"{kind:6s} lk={lk:3d}: fused {t_f:7.1f} us ({fl / t_f / 1e6:6.1f} TFLOP/s)   separate {t_s:7.1f} us")

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256, 1) void gemm4_kernel(const avsd_gemm_desc p) {
     return;
   }
   // the shared epilogue, one 32-row fragment band at a time (a 16-fragment instantiation does not unroll: the accumulators would
-  // go through scratch memory); a band of FN <= 4 fragments takes the term-at-a-time form with batched operand loads
+  // go through scratch memory); a band of FN <= 5 fragments takes the term-at-a-time form with batched operand loads
   static_for<FM>([&p, &acc, &ln_raw, ln_pre, m_base, n_base, lane](auto b_c) {
     constexpr int B = decltype(b_c)::value;
     // bands are independent, and with 512 registers per lane the scheduler would interleave them (all FM * FN * 16 accumulators
@@ -220,6 +220,7 @@ __global__ __launch_bounds__(256, 1) void gemm4_kernel(const avsd_gemm_desc p) {
       pre_ln[1] = mean * pre_ln[0];
     }
     if constexpr (X2) epilogue_x2<FN, 1>(p, band, m_base + 32 * B, n_base, lane, 0, pre_ln, ln_pre);
+    else if constexpr (FN == 5) epilogue_by_term<FN, 1>(p, band, m_base + 32 * B, n_base, lane, 0, pre_ln, ln_pre);   // (as the fused cross-attention tile)
     else epilogue<FN, 1>(p, band, m_base + 32 * B, n_base, lane, 0, pre_ln, ln_pre);
   });
 }
@@ -279,7 +280,8 @@ int avsd_gemm_dispatch_asm(const avsd_gemm_desc& d, hipStream_t s) {
       case 4: return launch4<2, 1, AVSD_GEMM_TMIX>(d, s);
       case 5: return launch4<1, 2, AVSD_GEMM_TMIX>(d, s);
       case 6: return launch4<1, 1, AVSD_GEMM_TMIX>(d, s);
-      default: AVSD_REQUIRE(false, "gemm/asm tiles: tile %d has no TMIX form (61..66 do)", d.tile);
+      case 7: return launch4<2, 5, AVSD_GEMM_TMIX>(d, s);
+      default: AVSD_REQUIRE(false, "gemm/asm tiles: tile %d has no TMIX form (61..67 do)", d.tile);
     }
   }
   switch (k) {
@@ -290,6 +292,7 @@ int avsd_gemm_dispatch_asm(const avsd_gemm_desc& d, hipStream_t s) {
     case 4: return launch4<2, 1, AVSD_GEMM_PLAIN>(d, s);     // 128 x 64, 54 KB
     case 5: return launch4<1, 2, AVSD_GEMM_PLAIN>(d, s);     // 64 x 128
     case 6: return launch4<1, 1, AVSD_GEMM_PLAIN>(d, s);     // 64 x 64, 36 KB: four workgroups per CU
+    case 7: return launch4<2, 5, AVSD_GEMM_PLAIN>(d, s);     // 128 x 320, 64 x 160 per wave, 126 KB: N = 320 in one column tile
     default: AVSD_REQUIRE(false, "gemm/asm tiles: unknown tile %d", d.tile);
   }
 }

@@ -123,10 +123,11 @@ X2_SPLITK_CANDIDATES = ((34, 2), (34, 4), (35, 2), (35, 4), (36, 2), (36, 4), (7
 # 3x3 stride-1 convolutions with the input tile resident in LDS (csrc/conv3r.hip): tile ids 40-49, geometry-dependent
 # (avsd_gemm_conv3r_supported); split_k cuts the cin / 64 channel chunks
 # 4-wave tiles with a hand-scheduled main loop (csrc/gemm4.hip): 60 = 256x256, 61 = 256x128, 62 = 128x256, 63 = 128x128; PLAIN, K % 64 == 0
-# 64 = 128x64, 65 = 64x128, 66 = 64x64; TMIX (cseg % 64 == 0): 61..66
-ASM_CANDIDATES = ((60, 1), (61, 1), (62, 1), (63, 1), (64, 1), (65, 1), (66, 1))
-ASM_SPLITK_CANDIDATES = ((63, 2), (63, 4), (63, 8), (61, 2), (62, 2), (62, 4), (64, 2), (64, 4), (65, 2), (65, 4), (66, 2), (66, 4))
-ASM_TILES = tuple(range(60, 67))
+# 64 = 128x64, 65 = 64x128, 66 = 64x64, 67 = 128x320 (the N = 320 layers in one column tile); TMIX (cseg % 64 == 0): 61..67
+ASM_CANDIDATES = ((60, 1), (61, 1), (62, 1), (63, 1), (64, 1), (65, 1), (66, 1), (67, 1))
+ASM_SPLITK_CANDIDATES = ((63, 2), (63, 4), (63, 8), (61, 2), (62, 2), (62, 4), (64, 2), (64, 4), (65, 2), (65, 4), (66, 2), (66, 4),
+                         (67, 2), (67, 3), (67, 4), (67, 5), (67, 6))
+ASM_TILES = tuple(range(60, 68))
 ASM_X2_CANDIDATES = ((63, 1), (64, 1), (65, 1), (66, 1))        # split precision: 128x128 ... 64x64
 ASM_X2_SPLITK_CANDIDATES = ((63, 2), (63, 4), (64, 2), (64, 4), (65, 2), (65, 4), (66, 2), (66, 4), (66, 8))
 _ASM_TILES = True          # (module attribute: tools set it to False to time the LDS-direct tiles alone)
@@ -330,6 +331,7 @@ def _time_cold(launch, cand, warm, reps=7):
 
 
 _CHALLENGE = os.environ.get("AVSD_TUNE_CHALLENGE", "0") == "1"     # tools/tune_tiles.py --challenge: re-time table entries against new tiles
+_CHALLENGE_TILES = tuple(int(v) for v in os.environ.get("AVSD_TUNE_CHALLENGE_TILES", "").split(",") if v)      # ... against these tile ids only
 _CHALLENGED: set = set()
 RECORD_KEYS = None
 CHALLENGE_LOG: list = []
@@ -340,6 +342,10 @@ def _challenge(key, launch, challengers, warm):
     interleaved rounds, best-of) and not slower against cold weights"""
     inc = _TILE_CACHE[key]
     _CHALLENGED.add(key)
+    if _CHALLENGE_TILES:
+        challengers = tuple(c for c in challengers if c[0] in _CHALLENGE_TILES)
+        if not challengers:
+            return
     times = {}
     for rnd in range(2):
         for cand in (inc,) + tuple(c for c in challengers if c != inc):

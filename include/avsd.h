@@ -95,9 +95,9 @@ enum { AVSD_GEMM_GEGLU = 1, AVSD_GEMM_OUT_F32 = 2, AVSD_GEMM_GELU = 4, AVSD_GEMM
  * cin % 64 == 0, image width <= 32 and a tile of whole image rows / whole images (avsd_gemm_conv3r_supported); split_k cuts
  * the channel chunks (split_k <= cin / 64).  No AVSD_GEMM_X2 / GEGLU / LNFUSE.  Other descriptors are refused with these ids. */
 /* 4-wave tiles with a hand-scheduled (inline-asm) main loop, register-staged operands (gemm4.hip): 60 = 256 x 256, 61 = 256 x 128,
- * 62 = 128 x 256, 63 = 128 x 128, 64 = 128 x 64, 65 = 64 x 128, 66 = 64 x 64.  PLAIN single-source descriptors with K % 64 == 0, no AVSD_GEMM_X2; every epilogue flag; split_k. */
+ * 62 = 128 x 256, 63 = 128 x 128, 64 = 128 x 64, 65 = 64 x 128, 66 = 64 x 64, 67 = 128 x 320 (PLAIN / TMIX, no AVSD_GEMM_X2).  PLAIN single-source descriptors with K % 64 == 0, no AVSD_GEMM_X2; every epilogue flag; split_k. */
 #define AVSD_GEMM_TILE_ASM_FIRST 60
-#define AVSD_GEMM_TILE_ASM_LAST 66
+#define AVSD_GEMM_TILE_ASM_LAST 67
 #define AVSD_GEMM_TILE_CONV3R_FIRST 40
 #define AVSD_GEMM_TILE_CONV3R_LAST 49
 /* the same convolution with RECTANGULAR resident tiles (TH image rows x 32 pixels + a one-pixel halo, positions outside the image

@@ -371,6 +371,11 @@ template <int FM, int FN, int NS, bool TMIX, bool X2> struct G4Loop;
         put(FM, FN, 2, rot=(FM * FN < 16))
     for FM, FN in ((4, 2), (2, 4), (2, 2), (2, 1), (1, 2), (1, 1)):
         put(FM, FN, 2, tmix=True, deep=(FM * FN <= 4), rot=(FM * FN <= 4))
+    # 128 x 320 (round 5): the N = 320 layers of the 32 x 32 level in ONE column tile — A is read once per row band, no padded columns
+    # (128-column tiles pad 320 to 384), 7 fragment reads per 10 MFMAs.  The temporal-mix form walks K unrotated (an asm statement
+    # takes 30 operands; the rotated temporal-mix walk needs 33 with 10 accumulators) — W of these layers is L2-resident anyway.
+    put(2, 5, 2, rot=True)
+    put(2, 5, 2, tmix=True, deep=False, rot=False)
     # (NSTG = 4, four K tiles of global loads in flight, was built for the three small tiles as ids 67-69: no shape of the
     #  tuned table chose it over NSTG = 2 once the K walk was rotated, so the variants are not emitted; gen() still takes NSTG)
     # split precision (two planes per operand, three MFMA passes)

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--max-keys", type=int, default=80)
     ap.add_argument("--clips", type=int, default=1)
     ap.add_argument("--modes", default="0,1,2", help="A-loader modes of the keys to visit: 0 plain, 1 temporal mix, 2 conv3x3")
+    ap.add_argument("--only-tiles", default="", help="try only these tile ids as candidates (e.g. 67: a newly added tile against the table)")
     ap.add_argument("--split", action="store_true", help="tune the split-precision step (AVSD_GEMM_X2 keys)")
     a = ap.parse_args()
     if a.split:
@@ -83,6 +84,9 @@ def main():
         # shortlist: the asm tiles and the staple LDS-direct tiles (the isolated tuner already ranked the rest)
         # (+ every resident-convolution tile / split the geometry admits; split precision: its own short tile list)
         short = [c for c in keys[k]["cands"] if c[0] >= 40 or (c[0] in (7, 11, 13, 20, 24, 25, 30, 34, 35, 36) and c[1] <= (8 if a.split else 2))]
+        if a.only_tiles:
+            only = {int(v) for v in a.only_tiles.split(",")}
+            short = [c for c in keys[k]["cands"] if c[0] in only]
         for c in short:
             if c == inc:
                 continue

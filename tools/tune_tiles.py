@@ -31,7 +31,8 @@ def main():
     ap.add_argument("--skip-cfg4", action="store_true")
     ap.add_argument("--extend", action="store_true", help="keep the shipped table's entries; tune only the shapes it lacks")
     ap.add_argument("--challenge", action="store_true", help="keep the shipped table; re-time every entry met against the tile ids added since "
-                                                            "(ops.ASM_CANDIDATES) and replace it when one of them is >= 3 %% faster")
+                                                            "(ops.ASM_CANDIDATES; AVSD_TUNE_CHALLENGE_TILES=67 narrows them) and replace it when one of "
+                                                            "them is >= 3 %% faster; combines with --clips / --plan")
     ap.add_argument("--only-cfg2", action="store_true")
     ap.add_argument("--split", action="store_true", help="tune the split-precision (AVSD_GEMM_X2) shapes of cfg 2 and the VAE "
                                                         "(their table keys carry the X2 flag, so they live beside the 16-bit ones)")
@@ -72,6 +73,8 @@ def main():
     if a.clips or a.plan:
         for n in ([int(v) for v in a.clips.split(",")] if a.clips else [1]):
             fwd(n, 12, 32)
+        for row in ops.CHALLENGE_LOG:
+            print("replaced", row)
         ops.save_tile_cache(a.out)
         print(f"wrote {a.out}: {len(ops.tile_cache())} shapes in {time.time() - t0:.0f} s")
         return

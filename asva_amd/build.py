@@ -16,7 +16,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libavsd_hip.so")
 # two builds of the same sources: bfloat16 storage (default) and IEEE-half storage (-DAVSD_F16=1), asva_amd/precision.py
 VARIANTS = {"bf16": ("", LIB, []), "fp16": ("_f16", os.path.join(HERE, "libavsd_hip_f16.so"), ["-DAVSD_F16=1"])}
-SOURCES = ["lib.hip", "attention.hip", "attention_x2.hip", "gemm_f32.hip", "gemm4.hip", "conv3r.hip", "norm.hip", "groupnorm_fused.hip", "elementwise.hip", "audio.hip", "xattn.hip", "attention_fp8.hip", "plan.hip"]
+SOURCES = ["lib.hip", "attention.hip", "attention_x2.hip", "gemm_f32.hip", "gemm4.hip", "nstream.hip", "conv3r.hip", "norm.hip", "groupnorm_fused.hip", "elementwise.hip", "audio.hip", "xattn.hip", "attention_fp8.hip", "plan.hip"]
 # gemm.hip instantiates ~290 kernels: compiled as six translation units (one per A-loader mode, the entry point, and two for
 # the split-precision tiles)
 GEMM_UNITS = 6

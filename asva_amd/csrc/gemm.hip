@@ -939,6 +939,7 @@ int avsd_gemm_dispatch_x2_conv3(const avsd_gemm_desc& d, int tile, hipStream_t s
 #if !defined(AVSD_GEMM_TU) || AVSD_GEMM_TU == 3
 int avsd_gemm_dispatch_conv3r(const avsd_gemm_desc& d, hipStream_t s);      // conv3r.hip
 int avsd_gemm_dispatch_asm(const avsd_gemm_desc& d, hipStream_t s);         // gemm4.hip
+int avsd_gemm_dispatch_nstream(const avsd_gemm_desc& d, hipStream_t s);     // nstream.hip
 
 // the reduce / epilogue launch of a split-K GEMM, for kernels outside this file that write the same slabs (conv3r.hip)
 int avsd_gemm_splitk_reduce(const avsd_gemm_desc& d, hipStream_t s) {
@@ -963,6 +964,8 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
   avsd_gemm_desc d = *dp;
   AVSD_REQUIRE(d.A && d.W && d.out, "gemm: A, W and out must be non-null");
   AVSD_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0, "gemm: M,N,K must be positive (got %d,%d,%d)", d.M, d.N, d.K);
+  AVSD_REQUIRE(!(d.flags & AVSD_GEMM_W_FRAG) || d.tile == AVSD_GEMM_TILE_NSTREAM, "gemm: fragment-ordered W (AVSD_GEMM_W_FRAG) is read by tile %d only (got %d)", AVSD_GEMM_TILE_NSTREAM, d.tile);
+  if (d.flags & AVSD_GEMM_W_FRAG) d.ldw = d.K;
   AVSD_REQUIRE(d.K % 8 == 0 && d.ldw % 8 == 0 && d.ldw >= d.K, "gemm: K (%d) and ldw (%d) must be multiples of 8, ldw >= K", d.K, d.ldw);
   AVSD_REQUIRE(d.N % 4 == 0 && d.ldc % 4 == 0, "gemm: N (%d) and ldc (%d) must be multiples of 4", d.N, d.ldc);
   AVSD_REQUIRE(d.lda % 8 == 0, "gemm: lda (%d) must be a multiple of 8", d.lda);
@@ -1018,6 +1021,7 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
   }
   // every kernel below reads the A operand of a convolution / temporal mix from ONE buffer: a second source would be ignored silently
   AVSD_REQUIRE(d.mode == AVSD_GEMM_PLAIN || !d.A2, "gemm: a two-source A needs the PLAIN mode or a resident convolution tile (40..54), got mode %d tile %d", d.mode, d.tile);
+  if (d.tile == AVSD_GEMM_TILE_NSTREAM) return avsd_gemm_dispatch_nstream(d, reinterpret_cast<hipStream_t>(stream));
   const bool asm_tile = d.tile >= AVSD_GEMM_TILE_ASM_FIRST && d.tile <= AVSD_GEMM_TILE_ASM_LAST;
   if (asm_tile && !(d.flags & AVSD_GEMM_X2)) return avsd_gemm_dispatch_asm(d, reinterpret_cast<hipStream_t>(stream));
   if (d.split_k > 1 && !asm_tile) {

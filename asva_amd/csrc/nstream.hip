@@ -1,0 +1,212 @@
+// A-resident, N-streaming GEMM for the wide short-K projections (gfx950): tile id AVSD_GEMM_TILE_NSTREAM of avsd_gemm_bf16.
+//
+// The GEGLU projection of a transformer block (ff_spatio_audio_temp_transformer_3d.py:276, 361-371) is 24576 x 2560 x 320 at the
+// 32 x 32 level: 40 GFLOP with K = 5 tiles of 64.  As a tiled GEMM it is 960-3840 workgroups that each load an A tile and a W tile,
+// run 5-10 K tiles and drain through an erf-GELU epilogue — prologue and epilogue in series with a main loop too short to hide
+// either (79-95 us on every tile of both families, the library 52-59 us for the plain product).  Here the loop nest
+// is turned around:
+//   * a workgroup owns a band of BM = 32 RF rows and keeps ALL of its A (BM x K, 61 KB at K = 320, 121 KB at K = 640) in LDS for
+//     the whole launch — A is read from memory once per launch (once per N split);
+//   * its 8 waves are INDEPENDENT after that one barrier: wave w walks the 32-column fragments w, w + 8, ... of the workgroup's N
+//     range, for each of them the full K, with RF accumulator fragments (all rows of the band);
+//   * W never touches LDS: it is stored in MFMA-fragment order (AVSD_GEMM_W_FRAG: [N / 32][K / 16][64 lanes][8 values], packed once
+//     with the weights), so a wave's operand of one k-step is ONE coalesced 1-KB load straight into the registers the MFMA reads,
+//     prefetched D k-steps ahead through a register ring that runs on across fragment boundaries — no prologue per fragment;
+//   * two waves share a SIMD and drift half a fragment apart (the second four start late on purpose): while one drains its
+//     accumulators through the epilogue (LayerNorm fold, bias, GEGLU's erf, 16-bit stores — VALU and memory), the other owns the
+//     MFMA pipe.  No barrier, no LDS traffic besides the A fragment reads (3 ds_read_b128 per 3 MFMAs per wave).
+// The epilogue is the shared one (gemm_common.h): same terms, same f32 order per element as every other tile; K is summed in
+// ascending order, so results are bit-identical to the LDS-direct tiles.  The LayerNorm statistics of a wave's rows are folded once
+// per launch (the rows never change), from the producer's K / 32 partial pairs — no avsd_ln_fold launch in front of it.
+// PLAIN single-source descriptors, K = 320 or 640, N % 256 == 0 after the split, no split-K, no AVSD_GEMM_X2.
+#include "gemm_common.h"
+
+namespace {
+
+typedef unsigned u32x4n __attribute__((ext_vector_type(4)));
+
+// FAST: the GEGLU projection's own epilogue, written out (LayerNorm fold + bias + value * gelu(gate), 16-bit wide stores): the same f32
+// operations per element as epilogue_by_term, with the per-column operands (colsum, bias) requested BEFORE the fragment's K loop so the
+// epilogue waits for nothing.  Every other flag combination runs the shared epilogue one fragment at a time (the generic instantiation).
+template <int K, int RF, bool FAST>
+__global__ __launch_bounds__(512, 1) void nstream_kernel(const avsd_gemm_desc p, const int nsplit) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smn[];
+  constexpr int KS = K / 16;                 // k-steps (one 32x32x16 MFMA per row fragment each)
+  constexpr int PITCH = K * 2 + 16;          // LDS row pitch: 164 / 324 dwords = 36 / 4 mod 64 -> ds_read_b128 conflict-free (K = 320) ...
+  constexpr int BM = 32 * RF;
+#ifndef NS_D320
+#define NS_D320 10
+#endif
+  constexpr int D = K == 320 ? NS_D320 : 10;   // k-steps of W in flight per wave (divides KS = 20 / 40)
+  static_assert(KS % D == 0, "the ring index must not depend on the fragment");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int band = blockIdx.x / nsplit, sp = blockIdx.x - band * nsplit;
+  const int m0 = band * BM;
+
+  // ---- A band -> LDS, once -------------------------------------------------------------------------------------------------
+  {
+    constexpr int V = K / 8;                 // 16-byte vectors per row
+    const h16_t* A = reinterpret_cast<const h16_t*>(p.A);
+#pragma unroll 4
+    for (int v = tid; v < BM * V; v += 512) {
+      const int r = v / V, c = v - r * V;
+      uint4 x = make_uint4(0, 0, 0, 0);
+      if (m0 + r < p.M) x = *reinterpret_cast<const uint4*>(A + (int64_t)(m0 + r) * p.lda + c * 8);
+      *reinterpret_cast<uint4*>(smn + r * PITCH + c * 16) = x;
+    }
+  }
+  // LayerNorm fold: (rstd, mean * rstd) of this lane's RF rows, once
+  float pre_ln[2 * RF];
+#pragma unroll
+  for (int b = 0; b < RF; ++b) {
+    pre_ln[2 * b] = 1.f; pre_ln[2 * b + 1] = 0.f;
+    if (p.flags & AVSD_GEMM_LNFUSE) ln_row_stats(p, min(m0 + 32 * b + (lane & 31), p.M - 1), 0, pre_ln[2 * b], pre_ln[2 * b + 1]);
+  }
+  __syncthreads();
+
+  // ---- this wave's fragments -------------------------------------------------------------------------------------------------
+  const int nfr_wg = (p.N / 32) / nsplit;           // fragments of this workgroup's N range (a multiple of 8)
+  const int T = nfr_wg / 8;
+  const int f0 = sp * nfr_wg + wave;
+  const u32x4n* wbase = reinterpret_cast<const u32x4n*>(p.W) + lane;
+  const unsigned char* arow = smn + (lane & 31) * PITCH + (lane >> 5) * 16;
+  const int hsel = (lane >> 5) * 4;
+  if (wave >= 4) __builtin_amdgcn_s_sleep(15);      // the SIMD's second wave starts ~1000 cycles late: one computes while the other drains
+
+  u32x4n wq[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) wq[d] = __builtin_nontemporal_load(wbase + ((int64_t)f0 * KS + d) * 64);
+  for (int t = 0; t < T; ++t) {
+    const int f = f0 + 8 * t;
+    const int fnext = t + 1 < T ? f + 8 : f;        // past the end: re-read this fragment (never consumed)
+    const u32x4n* wcur = wbase + (int64_t)f * KS * 64;
+    const u32x4n* wnxt = wbase + (int64_t)fnext * KS * 64;
+    f32x16 acc[1][RF];
+#pragma unroll
+    for (int b = 0; b < RF; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][b][r] = 0.f;
+    float4 cs4[4], bi4[4];
+    if constexpr (FAST) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        cs4[q] = *reinterpret_cast<const float4*>(p.ln_colsum + f * 32 + 8 * q + hsel);
+        bi4[q] = *reinterpret_cast<const float4*>(p.bias + f * 32 + 8 * q + hsel);
+      }
+    }
+    // A fragments are read one k-step ahead (two register sets); the scheduling barriers keep hipcc from hoisting all 3 KS fragment
+    // reads of the unrolled loop to its top (it did: 235 spilled registers)
+#ifndef NS_AD
+#define NS_AD 2
+#endif
+    constexpr int AD = NS_AD;                  // A fragments are read AD k-steps ahead (AD + 1 register sets)
+    h16x8 af[AD + 1][RF];
+#pragma unroll
+    for (int j = 0; j < AD; ++j)
+#pragma unroll
+      for (int b = 0; b < RF; ++b) af[j][b] = *reinterpret_cast<const h16x8*>(arow + b * 32 * PITCH + j * 32);
+    __builtin_amdgcn_s_setprio(1);         // the wave in its MFMA phase goes first; its partner's epilogue takes the slots in between
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      __builtin_amdgcn_sched_barrier(0);
+      const h16x8 wf = __builtin_bit_cast(h16x8, wq[ks % D]);
+      if (ks + AD < KS) {
+#pragma unroll
+        for (int b = 0; b < RF; ++b) af[(ks + AD) % (AD + 1)][b] = *reinterpret_cast<const h16x8*>(arow + b * 32 * PITCH + (ks + AD) * 32);
+      }
+#pragma unroll
+      for (int b = 0; b < RF; ++b) acc[0][b] = mfma32x32x16(wf, af[ks % (AD + 1)][b], acc[0][b], 0, 0, 0);
+#ifndef NS_NOW
+      wq[ks % D] = __builtin_nontemporal_load(ks + D < KS ? wcur + (ks + D) * 64 : wnxt + (ks + D - KS) * 64);
+#endif
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(0);
+    // (opaque copies: everything the epilogue derives from the band's rows is loop-invariant here, and hipcc hoists it all out of the
+    //  fragment loop — row pointers, frame divisions, 64-bit addresses of every optional operand — 231 registers spilled across the loop)
+#ifdef NS_NOEPI
+    if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[lane] = acc[0][0][0] + acc[0][1][1] + acc[0][2][2];
+#else
+    if constexpr (FAST) {
+#pragma unroll
+      for (int b = 0; b < RF; ++b) {
+        const int m = m0 + 32 * b + (lane & 31);
+        const float rstd = pre_ln[2 * b], mr = pre_ln[2 * b + 1];
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float c4[4] = {cs4[q].x, cs4[q].y, cs4[q].z, cs4[q].w}, b4[4] = {bi4[q].x, bi4[q].y, bi4[q].z, bi4[q].w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[4 * q + i] = fmaf(p.alpha * acc[0][b][4 * q + i] + 0.f, rstd, -mr * c4[i]) + b4[i];
+        }
+        // GEGLU: quads 0, 1 hold 8 values, quads 2, 3 their gates; lanes l / l ^ 32 swap halves so each stores 8 contiguous columns
+        unsigned e0[2], e1[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+#ifdef NS_NOERF
+#define NS_G(x) (x)
+#else
+#define NS_G(x) gelu_erf_f(x)
+#endif
+          const float g00 = v[2 * d] * NS_G(v[8 + 2 * d]), g01 = v[2 * d + 1] * NS_G(v[8 + 2 * d + 1]);
+          const float g10 = v[4 + 2 * d] * NS_G(v[12 + 2 * d]), g11 = v[4 + 2 * d + 1] * NS_G(v[12 + 2 * d + 1]);
+          const auto e = __builtin_amdgcn_permlane32_swap(pack2h(g00, g01), pack2h(g10, g11), false, false);
+          e0[d] = e[0]; e1[d] = e[1];
+        }
+#ifdef NS_NOSTORE
+        if (m < p.M && e0[0] == 0x12345678u)
+#else
+        if (m < p.M)
+#endif
+          *reinterpret_cast<uint4*>(reinterpret_cast<h16_t*>(p.out) + (int64_t)m * p.ldc + f * 16 + 2 * hsel) = make_uint4(e0[0], e0[1], e1[0], e1[1]);
+      }
+    } else {
+      // (opaque copies: everything the epilogue derives from the band's rows is loop-invariant here, and hipcc hoists it all out of the
+      //  fragment loop — row pointers, frame divisions, 64-bit addresses of every optional operand — 231 registers spilled across the loop)
+      int m0v = m0, lanev = lane;
+      asm volatile("" : "+s"(m0v), "+v"(lanev));
+      epilogue_each<1, RF>(p, acc, m0v, f * 32, lanev, 0, pre_ln, true);
+    }
+#endif
+  }
+}
+
+template <int K, int RF, bool FAST>
+int launch_nstream(const avsd_gemm_desc& d, hipStream_t s) {
+  constexpr int BM = 32 * RF;
+  constexpr size_t lds = (size_t)BM * (K * 2 + 16);
+  static_assert(lds <= 160 * 1024, "the A band does not fit the 160 KB of LDS");
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nstream_kernel<K, RF, FAST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      avsd_set_error("gemm/nstream: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+      return AVSD_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  const int nbands = (d.M + BM - 1) / BM;
+  // N splits: enough workgroups for the 256 CUs, every wave at least one fragment
+  const int nfr = d.N / 32;
+  int nsplit = 1;
+  while (nbands * nsplit < 256 && nfr % (nsplit * 2 * 8) == 0) nsplit *= 2;
+  hipLaunchKernelGGL((nstream_kernel<K, RF, FAST>), dim3((unsigned)(nbands * nsplit)), dim3(512), lds, s, d, nsplit);
+  AVSD_CHECK_LAUNCH("gemm/nstream launch");
+  return AVSD_OK;
+}
+
+}  // namespace
+
+int avsd_gemm_dispatch_nstream(const avsd_gemm_desc& d, hipStream_t s) {
+  AVSD_REQUIRE(d.mode == AVSD_GEMM_PLAIN && !d.A2 && d.batch == 1 && d.split_k <= 1 && !(d.flags & AVSD_GEMM_X2),
+               "gemm/nstream: PLAIN single-source descriptors, no batching, no split-K, no AVSD_GEMM_X2");
+  AVSD_REQUIRE(d.flags & AVSD_GEMM_W_FRAG, "gemm/nstream: W must be in MFMA-fragment order (AVSD_GEMM_W_FRAG)");
+  AVSD_REQUIRE((d.K == 320 || d.K == 640) && d.N % 256 == 0, "gemm/nstream: K = 320 or 640 and N %% 256 == 0 (got K %d, N %d)", d.K, d.N);
+  AVSD_REQUIRE(d.lda % 8 == 0 && !d.stats_pos && !d.ln_rowvec, "gemm/nstream: lda %% 8 == 0, no position tables");
+  // the GEGLU projection of a transformer block and nothing else in its epilogue: the written-out form
+  const bool fast = (d.flags & AVSD_GEMM_GEGLU) && (d.flags & AVSD_GEMM_LNFUSE) && d.bias && !d.rowvec && !d.res1 && !d.res2 && !d.out_master &&
+                    !(d.flags & (AVSD_GEMM_OUT_F32 | AVSD_GEMM_GELU | AVSD_GEMM_ROWSTATS)) && d.ldc % 8 == 0;
+  if (d.K == 320) return fast ? launch_nstream<320, 3, true>(d, s) : launch_nstream<320, 3, false>(d, s);
+  return fast ? launch_nstream<640, 3, true>(d, s) : launch_nstream<640, 3, false>(d, s);
+}

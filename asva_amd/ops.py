@@ -17,7 +17,7 @@ from . import precision as P
 from ._lib import GemmDesc, XAttnDesc, check
 
 PLAIN, TMIX, CONV3 = 0, 1, 2
-GEGLU, OUT_F32, GELU, XCD_N, ROWSTATS, LNFUSE, RES1_F32, RES2_F32, X2, KROT = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
+GEGLU, OUT_F32, GELU, XCD_N, ROWSTATS, LNFUSE, RES1_F32, RES2_F32, X2, KROT, W_FRAG = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024
 _XCD_MODE = "auto"     # auto | m | n  (which operand each XCD's L2 fetches once)
 F32 = torch.float32      # (16-bit storage dtype: P.ACT, asva_amd/precision.py)
 
@@ -145,6 +145,18 @@ _KROT_MAX_W = 16 << 20
 def set_krot(on: bool) -> None:
     global _KROT
     _KROT = bool(on)
+
+
+# A-resident, N-streaming tile (csrc/nstream.hip): the wide short-K projections whose weights the caller also holds in fragment order.
+# Chosen by rule, not by the table: it needs the second weight layout, which only the caller can provide (gemm(w_frag=...)).
+NSTREAM_TILE = 70
+_NSTREAM = os.environ.get("AVSD_NSTREAM", "1") != "0"
+
+
+def nstream_supported(M: int, N: int, K: int) -> bool:
+    """the shapes tile 70 is built for: all of A's K in LDS (K = 320 / 640), at least 8 N fragments per wave set, and N wide enough that
+    streaming it pays (N >= 4 K: the GEGLU projections; a square layer is better off on the tiled kernels)"""
+    return K in (320, 640) and N % 256 == 0 and N >= 4 * K and M >= 96
 
 
 _RASTER_G = 0       # probe knob: rows of the tile blocks an XCD walks (0 = the kernel's default)
@@ -513,6 +525,8 @@ def gemm(
     a_rest: Optional[torch.Tensor] = None,     # explicit rest planes of a / a2 / w: THIS product runs as three MFMA passes (AVSD_GEMM_X2)
     a2_rest: Optional[torch.Tensor] = None,    # whatever the process-wide mode (per-layer precision plan); f32 output and f32 residuals
     w_rest: Optional[torch.Tensor] = None,
+    w_frag: Optional[torch.Tensor] = None,     # the same weights in MFMA-fragment order (weights.pack_frag): lets the A-resident N-streaming
+                                               # tile (70, csrc/nstream.hip) take the product where it applies (nstream_supported)
 ) -> torch.Tensor:
     """out = epilogue(alpha * A' . W^T); see avsd_gemm_bf16 in include/avsd.h."""
     _req(a, P.ACT, "a")
@@ -653,6 +667,16 @@ def gemm(
         d.res1_lo = _lo(res1) if (res1 is not None and res1.dtype != F32) else 0
         d.res2_lo = _lo(res2) if (res2 is not None and res2.dtype != F32) else 0
 
+    if tile == NSTREAM_TILE or (tile == 0 and _NSTREAM and w_frag is not None):
+        ok = (w_frag is not None and not x2 and mode == PLAIN and a2 is None and split_k == 1 and nstream_supported(M, N, K)
+              and stats_pos is None and ln_pos is None and w_frag.dtype == P.ACT and w_frag.is_contiguous() and w_frag.numel() == N * K)
+        if ok:
+            tile = NSTREAM_TILE
+            d.W = _p(w_frag)
+            d.flags |= W_FRAG
+        elif tile == NSTREAM_TILE:
+            raise ValueError("gemm: tile 70 needs w_frag (weights.pack_frag) and a PLAIN single-source product with K = 320 / 640, N % 256 == 0")
+
     def _set(t, sk):
         nonlocal ws
         d.tile, d.split_k = t, sk
@@ -717,7 +741,7 @@ def gemm(
         fam = ("gemm_plain", "gemm_tmix", "gemm_conv3")[mode]
         dc = GemmDesc.from_buffer_copy(d)
         _TIMER.add_replay(fam, lambda dc=dc: check(_lib.lib().avsd_gemm_bf16(C.byref(dc), _stream()), "avsd_gemm_bf16"),
-                          (a, a2, w, out, bias, rowvec, res1, res2, ws, rowstats, ln, master, stats_pos, ln_pos, a_rest, a2_rest, w_rest))
+                          (a, a2, w, out, bias, rowvec, res1, res2, ws, rowstats, ln, master, stats_pos, ln_pos, a_rest, a2_rest, w_rest, w_frag))
         _TIMER.stop(ev, fam, 2.0 * M * N * K * (3 if x2 else 1), 2.0 * M * K * (1.0 / 9 if mode == CONV3 else 1.0 / 3 if mode == TMIX else 1.0)
                     + 2.0 * N * K + _nbytes(out, res1, res2))
     return out

@@ -24,7 +24,7 @@ from . import precision as P
 
 from . import ops
 from .conditioning import mask_to_key_index
-from .weights import from_act, is_twin, pack_conv1x1, pack_conv3x3, pack_geglu, pack_linear, rest_of, to_act, to_planes
+from .weights import from_act, is_twin, pack_conv1x1, pack_conv3x3, pack_frag, pack_geglu, pack_linear, rest_of, to_act, to_planes
 
 CONFIG_NAME = "config.json"
 SAFETENSORS_NAME = "diffusion_pytorch_model.safetensors"
@@ -421,6 +421,9 @@ class Packer:
                 pos1=self.lin(b.pos_embedding_temp.linear_1), pos2=self.lin(b.pos_embedding_temp.linear_2),
                 norm3=self.aff(b.norm3), w1=reg(w1), b1=reg(b1), ff2=self.lin(b.ff.net[2]),
                 dim=m.proj_in.weight.shape[0], audio=hasattr(b, "attn_audio"))
+        if w1_ln.shape[1] in (320, 640) and not is_twin(w1_ln):
+            # the same weights in MFMA-fragment order for the A-resident N-streaming tile (csrc/nstream.hip; ops.nstream_supported)
+            p.w1_ln_f = reg(pack_frag(w1_ln))
         if p.audio:
             p.norm_audio = self.aff(b.norm_audio)
             p.attn_audio = self.attn(b.attn_audio, False, b.norm_audio)
@@ -1199,7 +1202,12 @@ def _transformer(st, x: _Act, p, hw, heads, split: int = 1) -> _Act:
     h = stream(o, p.attn_temp.wo, p.attn_temp.bo, h)
     # 5. GEGLU feed-forward, activation fused in the first GEMM's epilogue (:361-371)
     if fused:
-        g = ops.gemm(h.lo, p.w1_ln, bias=p.b1_ln, geglu=True, ln=(ops.ln_fold(stats[si]) if _LN_PREFOLD else stats[si], p.s1_ln, eps))
+        wf = getattr(p, "w1_ln_f", None)
+        if wf is not None and ops._NSTREAM and not P.SPLIT and ops.nstream_supported(M, 8 * C, C):
+            # A-resident tile: every wave folds the statistics of its own rows once — no avsd_ln_fold launch
+            g = ops.gemm(h.lo, p.w1_ln, bias=p.b1_ln, geglu=True, ln=(stats[si], p.s1_ln, eps), w_frag=wf)
+        else:
+            g = ops.gemm(h.lo, p.w1_ln, bias=p.b1_ln, geglu=True, ln=(ops.ln_fold(stats[si]) if _LN_PREFOLD else stats[si], p.s1_ln, eps))
     else:
         g = ops.gemm(ops.layernorm(h.lo, p.norm3.g, p.norm3.b), p.w1, bias=p.b1, geglu=True)
     h = stream(g, p.ff2.w, p.ff2.b, h, want_stats=False)

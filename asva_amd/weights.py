@@ -100,6 +100,15 @@ def pack_geglu(w: torch.Tensor, b: torch.Tensor | None):
     return wp, bp
 
 
+def pack_frag(wp: torch.Tensor) -> torch.Tensor:
+    """packed 16-bit weights [N, K] -> MFMA-fragment order [N / 32, K / 16, 64, 8] (AVSD_GEMM_W_FRAG, include/avsd.h): element
+    (f, s, l, e) = W[32 f + (l & 31)][16 s + 8 (l >> 5) + e] — what lane l of a wave feeds the 32x32x16 MFMA of k-step s for the
+    32 columns of fragment f; one k-step of one fragment is 1 KB, contiguous (csrc/nstream.hip streams it straight into registers)"""
+    N, K = wp.shape
+    assert N % 32 == 0 and K % 16 == 0
+    return wp.reshape(N // 32, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().reshape(N // 32, K // 16, 64, 8)
+
+
 def pad_rows(w: torch.Tensor, mult: int = 4) -> torch.Tensor:
     n = w.shape[0]
     if n % mult == 0:

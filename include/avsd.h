@@ -80,11 +80,14 @@ int avsd_device_info(char* name_host, int len, int* num_cu_host);
  *                    summation order of a band then starts mid-K, so results differ from the unrotated walk in the last bits.
  *   AVSD_GEMM_XCD_N: scheduling hint, no effect on the result — tiles are dealt to the 8 XCDs in bands of N instead of
  *                    bands of M, so the weights (not the activations) are the operand each L2 fetches only once.
+ *   AVSD_GEMM_W_FRAG: W is stored in MFMA-fragment order instead of [N][ldw]: [N / 32][K / 16][64][8] 16-bit values with element
+ *                    (f, s, l, e) = W[32 f + (l & 31)][16 s + 8 (l >> 5) + e] (asva_amd/weights.py pack_frag) — one k-step of one 32-column
+ *                    fragment is 1 KB, contiguous.  Only tile AVSD_GEMM_TILE_NSTREAM reads it (and refuses anything else); ldw is ignored.
  * blockIdx.z batches: pointers advance by batch_stride_* elements (0 = shared).
  */
 enum { AVSD_GEMM_PLAIN = 0, AVSD_GEMM_TMIX = 1, AVSD_GEMM_CONV3 = 2 };
 enum { AVSD_GEMM_GEGLU = 1, AVSD_GEMM_OUT_F32 = 2, AVSD_GEMM_GELU = 4, AVSD_GEMM_XCD_N = 8, AVSD_GEMM_ROWSTATS = 16,
-       AVSD_GEMM_LNFUSE = 32, AVSD_GEMM_RES1_F32 = 64, AVSD_GEMM_RES2_F32 = 128, AVSD_GEMM_X2 = 256, AVSD_GEMM_KROT = 512 };
+       AVSD_GEMM_LNFUSE = 32, AVSD_GEMM_RES1_F32 = 64, AVSD_GEMM_RES2_F32 = 128, AVSD_GEMM_X2 = 256, AVSD_GEMM_KROT = 512, AVSD_GEMM_W_FRAG = 1024 };
 #define AVSD_GEMM_MAX_TILE 33
 #define AVSD_GEMM_MAX_TILE_X2 36   /* AVSD_GEMM_X2 also has tiles 34..36 (gemm.hip dispatch_tile_x2) */
 /* 256 x 160 LDS-direct tile, 8 MFMA + 4 loader waves (gemm.hip dispatch_tile; not with AVSD_GEMM_X2) */
@@ -98,6 +101,11 @@ enum { AVSD_GEMM_GEGLU = 1, AVSD_GEMM_OUT_F32 = 2, AVSD_GEMM_GELU = 4, AVSD_GEMM
  * 62 = 128 x 256, 63 = 128 x 128, 64 = 128 x 64, 65 = 64 x 128, 66 = 64 x 64, 67 = 128 x 320 (PLAIN / TMIX, no AVSD_GEMM_X2).  PLAIN single-source descriptors with K % 64 == 0, no AVSD_GEMM_X2; every epilogue flag; split_k. */
 #define AVSD_GEMM_TILE_ASM_FIRST 60
 #define AVSD_GEMM_TILE_ASM_LAST 67
+/* A-resident, N-streaming tile (nstream.hip): the workgroup keeps its 96-row band of A (all of K) in LDS and its 8 independent waves
+ * stream W fragments straight from memory into MFMA operands — for the wide short-K projections (the GEGLU projection of a transformer
+ * block: K = 320 / 640, N = 8 K).  PLAIN single-source descriptors with AVSD_GEMM_W_FRAG, K = 320 or 640, N % 256 == 0; every epilogue
+ * flag except the position tables; no split_k, no AVSD_GEMM_X2. */
+#define AVSD_GEMM_TILE_NSTREAM 70
 #define AVSD_GEMM_TILE_CONV3R_FIRST 40
 #define AVSD_GEMM_TILE_CONV3R_LAST 49
 /* the same convolution with RECTANGULAR resident tiles (TH image rows x 32 pixels + a one-pixel halo, positions outside the image

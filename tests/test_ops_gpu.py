@@ -847,6 +847,40 @@ def test_gemm_asm_tiles_plain(ops, tile, M, N, K, krot_off):
                                ops.gemm(h, w2, geglu=True, ln=(ops.ln_fold(st), cs, 1e-5), tile=9))
 
 
+@pytest.mark.parametrize("M,N,K", [(960, 2560, 320), (1000, 2560, 320), (96, 1280, 320), (2000, 5120, 640), (6144, 2560, 640), (200, 256 * 5, 320)])
+def test_gemm_nstream_tile(ops, M, N, K, krot_off):
+    """csrc/nstream.hip (tile 70): the A band resident in LDS, W streamed in fragment order by 8 independent waves.  Same products in the
+    same K order through the shared epilogue -> bit-identical to the LDS-direct tile 9: plain + residual, f32 output, GEGLU, GEGLU with
+    the LayerNorm fold from raw (K / 32 pairs) and pre-folded statistics; M tails; refused without the fragment-ordered weights."""
+    from asva_amd.weights import pack_frag, pack_geglu
+    assert ops.nstream_supported(M, N, K)
+    a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    bias, res = rndf(N, seed=3), rnd(M, N, seed=4)
+    wf = pack_frag(w)
+    out = ops.gemm(a, w, bias=bias, res1=res, tile=70, w_frag=wf)
+    assert rel_l2(out, a.float() @ w.float().T + bias + res.float()) < TOL_BF16
+    assert torch.equal(out, ops.gemm(a, w, bias=bias, res1=res, tile=9))
+    o32 = ops.gemm(a, w, bias=bias, out_f32=True, tile=70, w_frag=wf)
+    assert rel_l2(o32, a.float() @ w.float().T + bias) < TOL_F32 and torch.equal(o32, ops.gemm(a, w, bias=bias, out_f32=True, tile=9))
+    assert all(torch.equal(ops.gemm(a, w, bias=bias, out_f32=True, tile=70, w_frag=wf), o32) for _ in range(3))
+    # the GEGLU projection as the transformer block runs it: producer statistics -> LayerNorm fold -> value * gelu(gate)
+    wp, bp = pack_geglu(w.float(), bias)
+    wpf = pack_frag(wp)
+    st = torch.empty(M, K // 32, 2, device=dev())
+    h = ops.gemm(rnd(M, K, seed=6), rnd(K, K, seed=7, scale=K ** -0.5), rowstats=st, tile=9)
+    cs = wp.float().sum(1)
+    want = ops.gemm(h, wp, bias=bp, geglu=True, ln=(st, cs, 1e-5), tile=9)
+    assert torch.equal(ops.gemm(h, wp, bias=bp, geglu=True, ln=(st, cs, 1e-5), tile=70, w_frag=wpf), want)
+    assert torch.equal(ops.gemm(h, wp, bias=bp, geglu=True, ln=(ops.ln_fold(st), cs, 1e-5), tile=70, w_frag=wpf), want)
+    assert torch.equal(ops.gemm(h, wp, bias=bp, geglu=True, ln=(st, cs, 1e-5), w_frag=wpf), want)          # tile 0: chosen by rule
+    hf = h.float()
+    ln = (hf - hf.mean(1, keepdim=True)) * torch.rsqrt(hf.var(1, unbiased=False, keepdim=True) + 1e-5)
+    y = ln @ w.float().T + bias
+    assert rel_l2(want, y[:, :N // 2] * torch.nn.functional.gelu(y[:, N // 2:])) < TOL_BF16
+    with pytest.raises(ValueError, match="w_frag"):
+        ops.gemm(a, w, tile=70)
+
+
 @pytest.mark.parametrize("tile", [61, 62, 63, 64, 65, 66, 67])
 @pytest.mark.parametrize("B,hw,C,N", [(2, 64, 320, 320), (1, 32, 128, 132), (3, 96, 64, 64), (1, 16, 1280, 1280)])
 def test_gemm_asm_tiles_tmix(ops, tile, B, hw, C, N, krot_off):

@@ -21,29 +21,59 @@
 // PLAIN single-source descriptors, K = 320 or 640, N % 256 == 0 after the split, no split-K, no AVSD_GEMM_X2.
 #include "gemm_common.h"
 
+#ifdef NS_STAMPS     // probe build (tools/nstream_probe.py --stamps): cycle stamps of 4 workgroups x 8 waves x (start, per fragment: loop start / loop end / epilogue end)
+__device__ unsigned long long ns_stamps[4 * 8 * 64];
+extern "C" int avsd_nstream_debug_read(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ns_stamps), sizeof(ns_stamps)); }
+#define NS_STAMP(i) do { if (sb >= 0 && lane == 0) ns_stamps[(sb * 8 + wave) * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define NS_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 typedef unsigned u32x4n __attribute__((ext_vector_type(4)));
 
-// FAST: the GEGLU projection's own epilogue, written out (LayerNorm fold + bias + value * gelu(gate), 16-bit wide stores): the same f32
+// FAST: the GEGLU projection's own epilogue, written out (LayerNorm fold + bias + value * gelu(gate), 16-bit stores): the same f32
 // operations per element as epilogue_by_term, with the per-column operands (colsum, bias) requested BEFORE the fragment's K loop so the
 // epilogue waits for nothing.  Every other flag combination runs the shared epilogue one fragment at a time (the generic instantiation).
+// (Parking a wave's results in an LDS slab and writing whole 128-byte rows — runs of 4 adjacent fragments per wave — was built and measured
+// slower, 70.8 -> 75.2 us at C = 320: the extra LDS round trip costs more issue slots than the narrower stores)
 template <int K, int RF, bool FAST>
 __global__ __launch_bounds__(512, 1) void nstream_kernel(const avsd_gemm_desc p, const int nsplit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smn[];
   constexpr int KS = K / 16;                 // k-steps (one 32x32x16 MFMA per row fragment each)
-  constexpr int PITCH = K * 2 + 16;          // LDS row pitch: 164 / 324 dwords = 36 / 4 mod 64 -> ds_read_b128 conflict-free (K = 320) ...
+  constexpr int PITCH = K * 2 + 16;          // LDS row pitch: 164 / 324 dwords = 36 / 4 mod 64 -> ds_read_b128 conflict-free
   constexpr int BM = 32 * RF;
-#ifndef NS_D320
-#define NS_D320 10
-#endif
-  constexpr int D = K == 320 ? NS_D320 : 10;   // k-steps of W in flight per wave (divides KS = 20 / 40)
+  constexpr int D = 10;                      // k-steps of W in flight per wave (divides KS = 20 / 40)
+  constexpr int AD = 2;                      // A fragments are read AD k-steps ahead (AD + 1 register sets)
   static_assert(KS % D == 0, "the ring index must not depend on the fragment");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int band = blockIdx.x / nsplit, sp = blockIdx.x - band * nsplit;
   const int m0 = band * BM;
+#ifdef NS_STAMPS
+  const int sb = blockIdx.x == 0 ? 0 : blockIdx.x == 77 ? 1 : blockIdx.x == 150 ? 2 : blockIdx.x == 255 ? 3 : -1;
+#endif
+  NS_STAMP(0);
 
+  // LayerNorm fold, first half: the K / 32 (or 1) partial pairs of this lane's RF rows are requested together, ahead of the A band
+  // (ln_row_stats would take one round trip per row fragment, in series: 6000 of the prologue's 9000 cycles)
+  constexpr int NPAIR = K / 32;              // (even: 10 / 20 pairs = 5 / 10 16-byte vectors per row)
+  float4 lnq[RF][NPAIR / 2];
+  const bool lnfuse = (p.flags & AVSD_GEMM_LNFUSE) != 0, ln1 = p.ln_nblk == 1;
+  if (lnfuse) {
+#pragma unroll
+    for (int b = 0; b < RF; ++b) {
+      const float2* st = reinterpret_cast<const float2*>(p.ln_stats) + (int64_t)min(m0 + 32 * b + (lane & 31), p.M - 1) * p.ln_nblk;
+      if (ln1) {
+        const float2 t = st[0];
+        lnq[b][0] = make_float4(t.x, t.y, 0.f, 0.f);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NPAIR / 2; ++j) lnq[b][j] = reinterpret_cast<const float4*>(st)[j];
+      }
+    }
+  }
   // ---- A band -> LDS, once -------------------------------------------------------------------------------------------------
   {
     constexpr int V = K / 8;                 // 16-byte vectors per row
@@ -56,30 +86,44 @@ __global__ __launch_bounds__(512, 1) void nstream_kernel(const avsd_gemm_desc p,
       *reinterpret_cast<uint4*>(smn + r * PITCH + c * 16) = x;
     }
   }
-  // LayerNorm fold: (rstd, mean * rstd) of this lane's RF rows, once
+  // ... second half: (rstd, mean * rstd), the arithmetic of ln_row_stats (gemm_common.h) in the same order
   float pre_ln[2 * RF];
 #pragma unroll
   for (int b = 0; b < RF; ++b) {
     pre_ln[2 * b] = 1.f; pre_ln[2 * b + 1] = 0.f;
-    if (p.flags & AVSD_GEMM_LNFUSE) ln_row_stats(p, min(m0 + 32 * b + (lane & 31), p.M - 1), 0, pre_ln[2 * b], pre_ln[2 * b + 1]);
+    if (lnfuse) {
+      float sm = 0.f, sq = 0.f;
+      if (ln1) { sm += lnq[b][0].x; sq += lnq[b][0].y; }
+      else {
+#pragma unroll
+        for (int j = 0; j < NPAIR / 2; ++j) { sm += lnq[b][j].x; sq += lnq[b][j].y; sm += lnq[b][j].z; sq += lnq[b][j].w; }
+      }
+      const float inv_k = 1.0f / (float)p.K;
+      const float mean = sm * inv_k;
+      const float var = fmaxf(sq * inv_k - mean * mean, 0.f);
+      pre_ln[2 * b] = rsqrtf(var + p.ln_eps);
+      pre_ln[2 * b + 1] = mean * pre_ln[2 * b];
+    }
   }
   __syncthreads();
 
   // ---- this wave's fragments -------------------------------------------------------------------------------------------------
+  // wave w takes the 32-column fragments w, w + 8, ... of the workgroup's N range
   const int nfr_wg = (p.N / 32) / nsplit;           // fragments of this workgroup's N range (a multiple of 8)
   const int T = nfr_wg / 8;
-  const int f0 = sp * nfr_wg + wave;
+  const int fbase = sp * nfr_wg;
+  auto frag_of = [&](int t) -> int { return fbase + wave + 8 * t; };
   const u32x4n* wbase = reinterpret_cast<const u32x4n*>(p.W) + lane;
   const unsigned char* arow = smn + (lane & 31) * PITCH + (lane >> 5) * 16;
   const int hsel = (lane >> 5) * 4;
-  if (wave >= 4) __builtin_amdgcn_s_sleep(15);      // the SIMD's second wave starts ~1000 cycles late: one computes while the other drains
 
+  NS_STAMP(1);
   u32x4n wq[D];
 #pragma unroll
-  for (int d = 0; d < D; ++d) wq[d] = __builtin_nontemporal_load(wbase + ((int64_t)f0 * KS + d) * 64);
+  for (int d = 0; d < D; ++d) wq[d] = __builtin_nontemporal_load(wbase + ((int64_t)frag_of(0) * KS + d) * 64);
   for (int t = 0; t < T; ++t) {
-    const int f = f0 + 8 * t;
-    const int fnext = t + 1 < T ? f + 8 : f;        // past the end: re-read this fragment (never consumed)
+    const int f = frag_of(t);
+    const int fnext = t + 1 < T ? frag_of(t + 1) : f;        // past the end: re-read this fragment (never consumed)
     const u32x4n* wcur = wbase + (int64_t)f * KS * 64;
     const u32x4n* wnxt = wbase + (int64_t)fnext * KS * 64;
     f32x16 acc[1][RF];
@@ -95,18 +139,14 @@ __global__ __launch_bounds__(512, 1) void nstream_kernel(const avsd_gemm_desc p,
         bi4[q] = *reinterpret_cast<const float4*>(p.bias + f * 32 + 8 * q + hsel);
       }
     }
-    // A fragments are read one k-step ahead (two register sets); the scheduling barriers keep hipcc from hoisting all 3 KS fragment
-    // reads of the unrolled loop to its top (it did: 235 spilled registers)
-#ifndef NS_AD
-#define NS_AD 2
-#endif
-    constexpr int AD = NS_AD;                  // A fragments are read AD k-steps ahead (AD + 1 register sets)
+    // the scheduling barriers keep hipcc from hoisting all 3 KS fragment reads of the unrolled loop to its top (it did: 235 spilled registers)
     h16x8 af[AD + 1][RF];
 #pragma unroll
     for (int j = 0; j < AD; ++j)
 #pragma unroll
       for (int b = 0; b < RF; ++b) af[j][b] = *reinterpret_cast<const h16x8*>(arow + b * 32 * PITCH + j * 32);
-    __builtin_amdgcn_s_setprio(1);         // the wave in its MFMA phase goes first; its partner's epilogue takes the slots in between
+    NS_STAMP(2 + 3 * t);
+    __builtin_amdgcn_s_setprio(1);         // the wave in its MFMA phase goes first
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       __builtin_amdgcn_sched_barrier(0);
@@ -117,21 +157,15 @@ __global__ __launch_bounds__(512, 1) void nstream_kernel(const avsd_gemm_desc p,
       }
 #pragma unroll
       for (int b = 0; b < RF; ++b) acc[0][b] = mfma32x32x16(wf, af[ks % (AD + 1)][b], acc[0][b], 0, 0, 0);
-#ifndef NS_NOW
       wq[ks % D] = __builtin_nontemporal_load(ks + D < KS ? wcur + (ks + D) * 64 : wnxt + (ks + D - KS) * 64);
-#endif
     }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(0);
-    // (opaque copies: everything the epilogue derives from the band's rows is loop-invariant here, and hipcc hoists it all out of the
-    //  fragment loop — row pointers, frame divisions, 64-bit addresses of every optional operand — 231 registers spilled across the loop)
-#ifdef NS_NOEPI
-    if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[lane] = acc[0][0][0] + acc[0][1][1] + acc[0][2][2];
-#else
+    NS_STAMP(3 + 3 * t);
     if constexpr (FAST) {
 #pragma unroll
       for (int b = 0; b < RF; ++b) {
-        const int m = m0 + 32 * b + (lane & 31);
+        const int row = 32 * b + (lane & 31);
         const float rstd = pre_ln[2 * b], mr = pre_ln[2 * b + 1];
         float v[16];
 #pragma unroll
@@ -144,22 +178,13 @@ __global__ __launch_bounds__(512, 1) void nstream_kernel(const avsd_gemm_desc p,
         unsigned e0[2], e1[2];
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
-#ifdef NS_NOERF
-#define NS_G(x) (x)
-#else
-#define NS_G(x) gelu_erf_f(x)
-#endif
-          const float g00 = v[2 * d] * NS_G(v[8 + 2 * d]), g01 = v[2 * d + 1] * NS_G(v[8 + 2 * d + 1]);
-          const float g10 = v[4 + 2 * d] * NS_G(v[12 + 2 * d]), g11 = v[4 + 2 * d + 1] * NS_G(v[12 + 2 * d + 1]);
+          const float g00 = v[2 * d] * gelu_erf_f(v[8 + 2 * d]), g01 = v[2 * d + 1] * gelu_erf_f(v[8 + 2 * d + 1]);
+          const float g10 = v[4 + 2 * d] * gelu_erf_f(v[12 + 2 * d]), g11 = v[4 + 2 * d + 1] * gelu_erf_f(v[12 + 2 * d + 1]);
           const auto e = __builtin_amdgcn_permlane32_swap(pack2h(g00, g01), pack2h(g10, g11), false, false);
           e0[d] = e[0]; e1[d] = e[1];
         }
-#ifdef NS_NOSTORE
-        if (m < p.M && e0[0] == 0x12345678u)
-#else
-        if (m < p.M)
-#endif
-          *reinterpret_cast<uint4*>(reinterpret_cast<h16_t*>(p.out) + (int64_t)m * p.ldc + f * 16 + 2 * hsel) = make_uint4(e0[0], e0[1], e1[0], e1[1]);
+        const uint4 piece = make_uint4(e0[0], e0[1], e1[0], e1[1]);          // out columns 16 f + 2 hsel ... + 8
+        if (m0 + row < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<h16_t*>(p.out) + (int64_t)(m0 + row) * p.ldc + f * 16 + 2 * hsel) = piece;
       }
     } else {
       // (opaque copies: everything the epilogue derives from the band's rows is loop-invariant here, and hipcc hoists it all out of the
@@ -168,7 +193,7 @@ __global__ __launch_bounds__(512, 1) void nstream_kernel(const avsd_gemm_desc p,
       asm volatile("" : "+s"(m0v), "+v"(lanev));
       epilogue_each<1, RF>(p, acc, m0v, f * 32, lanev, 0, pre_ln, true);
     }
-#endif
+    NS_STAMP(4 + 3 * t);
   }
 }
 

@@ -6,6 +6,7 @@ import torch
 from asva_amd import ops
 from asva_amd.weights import pack_frag, pack_geglu
 
+STAMPS = "--stamps" in sys.argv        # AVSD_LIB_PATH = a library built with -DNS_STAMPS: per-wave timeline of 4 workgroups
 dev = torch.device("cuda", 0)
 g = torch.Generator().manual_seed(0)
 for M, C in [(24576, 320), (6144, 640), (12288, 320), (98304, 320), (24576, 640)]:
@@ -27,6 +28,26 @@ for M, C in [(24576, 320), (6144, 640), (12288, 320), (98304, 320), (24576, 640)
     got = ops.gemm(h, wp, bias=bp, geglu=True, ln=(stats, cs, 1e-5), out=out, w_frag=wf)
     same = torch.equal(got, ref)
     t_ns = ops._time_hot(lambda *_: ops.gemm(h, wp, bias=bp, geglu=True, ln=(stats, cs, 1e-5), out=out, w_frag=wf), ()) * 1e3
+    if STAMPS and M == 24576 and C == 320:
+        import ctypes, numpy as np
+        from asva_amd import _lib
+        torch.cuda.synchronize()
+        for _ in range(3):
+            ops.gemm(h, wp, bias=bp, geglu=True, ln=(stats, cs, 1e-5), out=out, w_frag=wf)
+        torch.cuda.synchronize()
+        buf = np.zeros(4 * 8 * 64, dtype=np.uint64)
+        lib = ctypes.CDLL(os.environ["AVSD_LIB_PATH"])
+        lib.avsd_nstream_debug_read(ctypes.c_void_p(buf.ctypes.data))
+        d = buf.reshape(4, 8, 64).astype(np.int64)
+        t0 = d[:, :, 0].min()
+        for wg in range(4):
+            print(f"workgroup {wg}: start {d[wg, :, 0].min() - t0} cycles after the first")
+            for wv in range(8):
+                r = d[wg, wv]
+                T = 10
+                loops = [int(r[3 + 3 * t] - r[2 + 3 * t]) for t in range(T)]
+                epis = [int(r[4 + 3 * t] - r[3 + 3 * t]) for t in range(T)]
+                print(f"  wave {wv}: prologue {int(r[1] - r[0]):6d}  K loops {loops}  epilogues {epis}  total {int(r[4 + 3 * (T - 1)] - r[0])}")
     a_l, w_l = torch.randn(M, C, device=dev).bfloat16(), torch.randn(8 * C, C, device=dev).bfloat16()
     o_l = torch.empty(M, 8 * C, dtype=torch.bfloat16, device=dev)
     torch.matmul(a_l, w_l.t(), out=o_l)

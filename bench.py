@@ -356,7 +356,7 @@ def main():
         fam_ms = {k: (timer.replay_ms((k,)) if not a.no_graph else v["ms"]) for k, v in fam.items()}
         ms = timer.replay_ms(gemm_fams) if not a.no_graph else ms_events
         ach = fl / (ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "GEMM family: gemm4_kernel (hand-scheduled tiles) / gemm2_kernel<BM,BN,...,MODE> (linear / temporal-mix / strided conv3x3 implicit GEMM) + conv3r_kernel (conv3x3, input tile resident in LDS), split-K reduce launches included",
+        roof = {"bound": "mfma", "kernel": "GEMM family: gemm4_kernel (hand-scheduled tiles) / gemm2_kernel<BM,BN,...,MODE> (linear / temporal-mix / strided conv3x3 implicit GEMM) + conv3r_kernel (conv3x3, input tile resident in LDS) + nstream_kernel (GEGLU projections, A band resident), split-K reduce launches included",
                 "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                 "traffic": None, "launches_per_step": launches // clips, "clips_per_forward": clips, "ms_per_step": round(ms / clips, 4),
                 "ms_per_forward": round(ms, 4), "ms_per_step_event_pairs": round(ms_events / clips, 4),

@@ -33,7 +33,7 @@ extern "C" {
 #define AVSD_ELAUNCH (-2)  /* hipLaunch / runtime error                          */
 #define AVSD_ENODEV (-3)   /* no gfx950 device / wrong architecture              */
 
-#define AVSD_ABI_VERSION 8
+#define AVSD_ABI_VERSION 9   /* v9: tile ids 67 (128 x 320 asm tile) and 70 (A-resident N-streaming tile), AVSD_GEMM_W_FRAG */
 
 /* ---- library ------------------------------------------------------------------------ */
 int avsd_abi_version(void);

@@ -19,7 +19,7 @@ from prof_summary import short  # noqa: E402
 
 def fam(n):
     k = short(n)
-    for key, name in (("gemm4", "gemm"), ("gemm2", "gemm"), ("gemm1", "gemm"), ("conv3r", "gemm"), ("splitk_reduce", "splitk_reduce"), ("xattn", "fused_cross_attention"),
+    for key, name in (("gemm4", "gemm"), ("gemm2", "gemm"), ("gemm1", "gemm"), ("conv3r", "gemm"), ("nstream", "gemm"), ("splitk_reduce", "splitk_reduce"), ("xattn", "fused_cross_attention"),
                       ("mlp_", "fused_mlp"), ("attn_kernel", "attention"), ("attn_f8", "attention"), ("tattn", "temporal_attention"), ("gn_", "groupnorm"),
                       ("layernorm", "layernorm"), ("linear_small", "small"), ("guided", "small"), ("ncfhw", "small"),
                       ("rows_to", "small"), ("timestep", "small"), ("copy_rep", "small")):

@@ -17,7 +17,7 @@ def per_dispatch(db_path, counter):
 
 fetch, names_f = per_dispatch(sys.argv[1], "FETCH_SIZE")
 write, names_w = per_dispatch(sys.argv[2], "WRITE_SIZE")
-isg = lambda n: ("gemm_kernel" in n or "gemm2_kernel" in n or "gemm4_kernel" in n or "conv3r_kernel" in n or "conv3r2d_kernel" in n)
+isg = lambda n: ("gemm_kernel" in n or "gemm2_kernel" in n or "gemm4_kernel" in n or "conv3r_kernel" in n or "conv3r2d_kernel" in n or "nstream_kernel" in n)
 gf = [v for d, v in fetch.items() if isg(names_f[d])]
 gw = [v for d, v in write.items() if isg(names_w[d])]
 assert gf and len(gf) == len(gw), (len(gf), len(gw))

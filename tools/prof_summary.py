@@ -7,10 +7,11 @@ import sys
 
 
 def short(name: str) -> str:
-    m = re.search(r"gemm2_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?>", name)
+    m = re.search(r"gemm2_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?(?:, (\w+))?>", name)
     if m:
-        bm, bn, wm, wn, st, mode, lw = m.groups()
-        return f"gemm2<{bm}x{bn},{wm}x{wn}w{'+' + lw + 'L' if lw and lw != '0' else ''},{st}st,{('plain','tmix','conv3')[int(mode)]}>"
+        bm, bn, wm, wn, st, mode, lw, x2 = m.groups()
+        return (f"gemm2<{bm}x{bn},{wm}x{wn}w{'+' + lw + 'L' if lw and lw != '0' else ''},{st}st,{('plain','tmix','conv3')[int(mode)]}"
+                f"{',x2' if x2 in ('true', '1') else ''}>")
     m = re.search(r"conv3r_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\w+))?>", name)
     if m:
         bm, bn, wm, wn, st, lw, gn = m.groups()
@@ -19,6 +20,10 @@ def short(name: str) -> str:
     if m:
         fm, fn, mode, x2 = m.groups()
         return f"gemm4<{64 * int(fm)}x{64 * int(fn)},asm,{('plain','tmix','conv3')[int(mode)]}{',x2' if x2 in ('true', '1') else ''}>"
+    m = re.search(r"nstream_kernel<(\d+), (\d+), (\w+)>", name)
+    if m:
+        k, rf, fast = m.groups()
+        return f"nstream<A-resident 96 rows x K={k}, W streamed{',geglu' if fast in ('true', '1') else ''}>"
     m = re.search(r"gemm_kernel<(\d+), (\d+), (\d+)>", name)
     if m:
         bm, bn, mode = m.groups()

@@ -74,16 +74,35 @@ __global__ __launch_bounds__(512, 1) void nstream_kernel(const avsd_gemm_desc p,
       }
     }
   }
+  // ---- this wave's fragments -------------------------------------------------------------------------------------------------
+  // wave w takes the 32-column fragments w, w + 8, ... of the workgroup's N range
+  const int nfr_wg = (p.N / 32) / nsplit;           // fragments of this workgroup's N range (a multiple of 8)
+  const int T = nfr_wg / 8;
+  const int fbase = sp * nfr_wg;
+  auto frag_of = [&](int t) -> int { return fbase + wave + 8 * t; };
+  const u32x4n* wbase = reinterpret_cast<const u32x4n*>(p.W) + lane;
+  const unsigned char* arow = smn + (lane & 31) * PITCH + (lane >> 5) * 16;
+  const int hsel = (lane >> 5) * 4;
+
+  // the first D k-steps of W are requested before the A band: they land while it is staged
+  u32x4n wq[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) wq[d] = __builtin_nontemporal_load(wbase + ((int64_t)frag_of(0) * KS + d) * 64);
   // ---- A band -> LDS, once -------------------------------------------------------------------------------------------------
   {
     constexpr int V = K / 8;                 // 16-byte vectors per row
     const h16_t* A = reinterpret_cast<const h16_t*>(p.A);
-#pragma unroll 4
-    for (int v = tid; v < BM * V; v += 512) {
-      const int r = v / V, c = v - r * V;
-      uint4 x = make_uint4(0, 0, 0, 0);
-      if (m0 + r < p.M) x = *reinterpret_cast<const uint4*>(A + (int64_t)(m0 + r) * p.lda + c * 8);
-      *reinterpret_cast<uint4*>(smn + r * PITCH + c * 16) = x;
+    constexpr int NV = (BM * V + 511) / 512;  // vectors per thread: all requested before the first is written (one round trip)
+    uint4 x[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = min(tid + i * 512, BM * V - 1), r = v / V, c = v - r * V;
+      x[i] = *reinterpret_cast<const uint4*>(A + (int64_t)min(m0 + r, p.M - 1) * p.lda + c * 8);      // (rows past M: a copy of the last row, never stored)
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = tid + i * 512, r = v / V, c = v - r * V;
+      if (v < BM * V) *reinterpret_cast<uint4*>(smn + r * PITCH + c * 16) = x[i];
     }
   }
   // ... second half: (rstd, mean * rstd), the arithmetic of ln_row_stats (gemm_common.h) in the same order
@@ -106,21 +125,8 @@ __global__ __launch_bounds__(512, 1) void nstream_kernel(const avsd_gemm_desc p,
     }
   }
   __syncthreads();
-
-  // ---- this wave's fragments -------------------------------------------------------------------------------------------------
-  // wave w takes the 32-column fragments w, w + 8, ... of the workgroup's N range
-  const int nfr_wg = (p.N / 32) / nsplit;           // fragments of this workgroup's N range (a multiple of 8)
-  const int T = nfr_wg / 8;
-  const int fbase = sp * nfr_wg;
-  auto frag_of = [&](int t) -> int { return fbase + wave + 8 * t; };
-  const u32x4n* wbase = reinterpret_cast<const u32x4n*>(p.W) + lane;
-  const unsigned char* arow = smn + (lane & 31) * PITCH + (lane >> 5) * 16;
-  const int hsel = (lane >> 5) * 4;
-
   NS_STAMP(1);
-  u32x4n wq[D];
-#pragma unroll
-  for (int d = 0; d < D; ++d) wq[d] = __builtin_nontemporal_load(wbase + ((int64_t)frag_of(0) * KS + d) * 64);
+
   for (int t = 0; t < T; ++t) {
     const int f = frag_of(t);
     const int fnext = t + 1 < T ? frag_of(t + 1) : f;        // past the end: re-read this fragment (never consumed)

@@ -1082,7 +1082,8 @@ def _ffconv(st, x: _Act, p, hw, stride=1, ups=0, temb=None, res: Optional[_Act] 
 def _resblock(st, x: _Act, skip: Optional[_Act], p, hw) -> _Act:
     rows_b = st.F * hw[0] * hw[1]
     if p.shortcut is not None:
-        s = _ffconv(st, x, p.shortcut, hw, x2=skip)
+        # (a three-pass shortcut feeds the block's last residual add only: its f32 result is all that is needed — no plane split behind it)
+        s = _ffconv(st, x, p.shortcut, hw, x2=skip, out_f32=getattr(p.shortcut, "wt_r", None) is not None)
     else:
         assert skip is None
         s = x

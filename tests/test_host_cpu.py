@@ -497,3 +497,20 @@ def test_product_filler_matches_the_reference_side_filler():
                         ("up_blocks.3.resnets.2.conv1.conv_temp.weight", (320, 960))):
         assert torch.equal(prod.fill_tensor(name, shape), ref.fill_tensor(name, shape)), name
     assert torch.equal(prod.seeded_randn(7, 3, 5), ref.seeded_randn(7, 3, 5))
+
+
+def test_pack_frag_layout_matches_the_header():
+    """include/avsd.h AVSD_GEMM_W_FRAG: element (f, s, l, e) = W[32 f + (l & 31)][16 s + 8 (l >> 5) + e] (what csrc/nstream.hip streams);
+    the nstream rule admits exactly the GEGLU projections of the 320- / 640-channel levels"""
+    from asva_amd.weights import pack_frag
+    from asva_amd import ops
+    N, K = 96, 64
+    w = torch.arange(N * K, dtype=torch.float32).reshape(N, K).to(torch.bfloat16)       # (values repeat after rounding: compare indices instead)
+    idx = torch.arange(N * K, dtype=torch.int32).reshape(N, K)
+    pf = pack_frag(idx)
+    assert pf.shape == (N // 32, K // 16, 64, 8) and pf.is_contiguous()
+    for f, s, l, e in [(0, 0, 0, 0), (1, 2, 5, 3), (2, 3, 63, 7), (0, 1, 32, 0), (2, 0, 31, 4)]:
+        assert pf[f, s, l, e].item() == idx[32 * f + (l & 31), 16 * s + 8 * (l >> 5) + e].item()
+    assert pack_frag(w).dtype == torch.bfloat16
+    assert ops.nstream_supported(24576, 2560, 320) and ops.nstream_supported(6144, 5120, 640) and ops.nstream_supported(96, 1280, 320)
+    assert not ops.nstream_supported(1536, 10240, 1280) and not ops.nstream_supported(24576, 960, 320) and not ops.nstream_supported(24576, 320, 320)

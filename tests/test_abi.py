@@ -107,3 +107,13 @@ def test_every_recordable_entry_point_is_replayable():
     recordable -= {n for n in recordable if n.startswith("avsd_sizeof_") or n.endswith("_supported")}
     missing = {n for n in recordable if n not in table}
     assert not missing - {"avsd_gemm_f32"}, sorted(missing)
+
+
+def test_graft_entry_build_runs():
+    """the driver's "does it build" check, as the driver calls it (the libraries are built incrementally: seconds when nothing changed)"""
+    import importlib
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    ge = importlib.import_module("__graft_entry__")
+    ge.build()

@@ -18,7 +18,7 @@
 // The epilogue is the shared one (gemm_common.h): same terms, same f32 order per element as every other tile; K is summed in
 // ascending order, so results are bit-identical to the LDS-direct tiles.  The LayerNorm statistics of a wave's rows are folded once
 // per launch (the rows never change), from the producer's K / 32 partial pairs — no avsd_ln_fold launch in front of it.
-// PLAIN single-source descriptors, K = 320 or 640, N % 256 == 0 after the split, no split-K, no AVSD_GEMM_X2.
+// PLAIN single-source descriptors, K = 320 or 640, N % 32 == 0, no split-K, no AVSD_GEMM_X2.
 #include "gemm_common.h"
 
 #ifdef NS_STAMPS     // probe build (tools/nstream_probe.py --stamps): cycle stamps of 4 workgroups x 8 waves x (start, per fragment: loop start / loop end / epilogue end)
@@ -76,10 +76,10 @@ __global__ __launch_bounds__(512, 1) void nstream_kernel(const avsd_gemm_desc p,
   }
   // ---- this wave's fragments -------------------------------------------------------------------------------------------------
   // wave w takes the 32-column fragments w, w + 8, ... of the workgroup's N range
-  const int nfr_wg = (p.N / 32) / nsplit;           // fragments of this workgroup's N range (a multiple of 8)
-  const int T = nfr_wg / 8;
+  const int nfr_wg = (p.N / 32) / nsplit;           // fragments of this workgroup's N range
+  const int T = wave < nfr_wg ? (nfr_wg - wave + 7) / 8 : 0;       // ... of this wave (a range that is no multiple of 8 leaves the last waves one short)
   const int fbase = sp * nfr_wg;
-  auto frag_of = [&](int t) -> int { return fbase + wave + 8 * t; };
+  auto frag_of = [&](int t) -> int { return fbase + min(wave + 8 * t, nfr_wg - 1); };
   const u32x4n* wbase = reinterpret_cast<const u32x4n*>(p.W) + lane;
   const unsigned char* arow = smn + (lane & 31) * PITCH + (lane >> 5) * 16;
   const int hsel = (lane >> 5) * 4;
@@ -221,7 +221,11 @@ int launch_nstream(const avsd_gemm_desc& d, hipStream_t s) {
   // N splits: enough workgroups for the 256 CUs, every wave at least one fragment
   const int nfr = d.N / 32;
   int nsplit = 1;
-  while (nbands * nsplit < 256 && nfr % (nsplit * 2 * 8) == 0) nsplit *= 2;
+  for (int c : {1, 2, 3, 4, 5, 6, 8, 10}) {          // the smallest split of N that fills the 256 CUs and leaves every wave of a workgroup a fragment
+    if (nfr % c != 0 || nfr / c < 8) continue;
+    nsplit = c;
+    if (nbands * c >= 256) break;
+  }
   hipLaunchKernelGGL((nstream_kernel<K, RF, FAST>), dim3((unsigned)(nbands * nsplit)), dim3(512), lds, s, d, nsplit);
   AVSD_CHECK_LAUNCH("gemm/nstream launch");
   return AVSD_OK;
@@ -233,7 +237,7 @@ int avsd_gemm_dispatch_nstream(const avsd_gemm_desc& d, hipStream_t s) {
   AVSD_REQUIRE(d.mode == AVSD_GEMM_PLAIN && !d.A2 && d.batch == 1 && d.split_k <= 1 && !(d.flags & AVSD_GEMM_X2),
                "gemm/nstream: PLAIN single-source descriptors, no batching, no split-K, no AVSD_GEMM_X2");
   AVSD_REQUIRE(d.flags & AVSD_GEMM_W_FRAG, "gemm/nstream: W must be in MFMA-fragment order (AVSD_GEMM_W_FRAG)");
-  AVSD_REQUIRE((d.K == 320 || d.K == 640) && d.N % 256 == 0, "gemm/nstream: K = 320 or 640 and N %% 256 == 0 (got K %d, N %d)", d.K, d.N);
+  AVSD_REQUIRE((d.K == 320 || d.K == 640) && d.N % 32 == 0, "gemm/nstream: K = 320 or 640 and N %% 32 == 0 (got K %d, N %d)", d.K, d.N);
   AVSD_REQUIRE(d.lda % 8 == 0 && !d.stats_pos && !d.ln_rowvec, "gemm/nstream: lda %% 8 == 0, no position tables");
   // the GEGLU projection of a transformer block and nothing else in its epilogue: the written-out form
   const bool fast = (d.flags & AVSD_GEMM_GEGLU) && (d.flags & AVSD_GEMM_LNFUSE) && d.bias && !d.rowvec && !d.res1 && !d.res2 && !d.out_master &&

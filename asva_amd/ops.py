@@ -668,14 +668,15 @@ def gemm(
         d.res2_lo = _lo(res2) if (res2 is not None and res2.dtype != F32) else 0
 
     if tile == NSTREAM_TILE or (tile == 0 and _NSTREAM and w_frag is not None):
-        ok = (w_frag is not None and not x2 and mode == PLAIN and a2 is None and split_k == 1 and nstream_supported(M, N, K)
+        ok = (w_frag is not None and not x2 and mode == PLAIN and a2 is None and split_k == 1 and K in (320, 640) and N % 32 == 0
+              and (tile == NSTREAM_TILE or nstream_supported(M, N, K))
               and stats_pos is None and ln_pos is None and w_frag.dtype == P.ACT and w_frag.is_contiguous() and w_frag.numel() == N * K)
         if ok:
             tile = NSTREAM_TILE
             d.W = _p(w_frag)
             d.flags |= W_FRAG
         elif tile == NSTREAM_TILE:
-            raise ValueError("gemm: tile 70 needs w_frag (weights.pack_frag) and a PLAIN single-source product with K = 320 / 640, N % 256 == 0")
+            raise ValueError("gemm: tile 70 needs w_frag (weights.pack_frag) and a PLAIN single-source product with K = 320 / 640, N % 32 == 0")
 
     def _set(t, sk):
         nonlocal ws

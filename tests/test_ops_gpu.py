@@ -847,13 +847,14 @@ def test_gemm_asm_tiles_plain(ops, tile, M, N, K, krot_off):
                                ops.gemm(h, w2, geglu=True, ln=(ops.ln_fold(st), cs, 1e-5), tile=9))
 
 
-@pytest.mark.parametrize("M,N,K", [(960, 2560, 320), (1000, 2560, 320), (96, 1280, 320), (2000, 5120, 640), (6144, 2560, 640), (200, 256 * 5, 320)])
+@pytest.mark.parametrize("M,N,K", [(960, 2560, 320), (1000, 2560, 320), (96, 1280, 320), (2000, 5120, 640), (6144, 2560, 640), (200, 256 * 5, 320),
+                                   (500, 320, 320), (3000, 960, 320), (700, 1920, 640), (130, 64, 640)])
 def test_gemm_nstream_tile(ops, M, N, K, krot_off):
     """csrc/nstream.hip (tile 70): the A band resident in LDS, W streamed in fragment order by 8 independent waves.  Same products in the
     same K order through the shared epilogue -> bit-identical to the LDS-direct tile 9: plain + residual, f32 output, GEGLU, GEGLU with
     the LayerNorm fold from raw (K / 32 pairs) and pre-folded statistics; M tails; refused without the fragment-ordered weights."""
     from asva_amd.weights import pack_frag, pack_geglu
-    assert ops.nstream_supported(M, N, K)
+    by_rule = ops.nstream_supported(M, N, K)          # (the other shapes: explicit tile 70 — fragment counts that are no multiple of 8, few fragments)
     a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
     bias, res = rndf(N, seed=3), rnd(M, N, seed=4)
     wf = pack_frag(w)
@@ -872,7 +873,8 @@ def test_gemm_nstream_tile(ops, M, N, K, krot_off):
     want = ops.gemm(h, wp, bias=bp, geglu=True, ln=(st, cs, 1e-5), tile=9)
     assert torch.equal(ops.gemm(h, wp, bias=bp, geglu=True, ln=(st, cs, 1e-5), tile=70, w_frag=wpf), want)
     assert torch.equal(ops.gemm(h, wp, bias=bp, geglu=True, ln=(ops.ln_fold(st), cs, 1e-5), tile=70, w_frag=wpf), want)
-    assert torch.equal(ops.gemm(h, wp, bias=bp, geglu=True, ln=(st, cs, 1e-5), w_frag=wpf), want)          # tile 0: chosen by rule
+    if by_rule:
+        assert torch.equal(ops.gemm(h, wp, bias=bp, geglu=True, ln=(st, cs, 1e-5), w_frag=wpf), want)          # tile 0: chosen by rule
     hf = h.float()
     ln = (hf - hf.mean(1, keepdim=True)) * torch.rsqrt(hf.var(1, unbiased=False, keepdim=True) + 1e-5)
     y = ln @ w.float().T + bias

@@ -39,17 +39,21 @@ def main():
     cur = db.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
-    rows = cur.execute(f"select {name_col}, start, end from kernels").fetchall()
+    by_grid = "--by-grid" in sys.argv          # one row per (kernel, grid): the grid tells the shapes of one kernel apart
+    gcols = [c for c in ("grid_x", "grid_y", "grid_z", "grid_size_x", "grid_size_y", "grid_size_z") if c in cols] if by_grid else []
+    if by_grid and not gcols:
+        print("columns of `kernels`:", cols, file=sys.stderr)
+    rows = cur.execute(f"select {name_col}, start, end" + "".join(", " + c for c in gcols) + " from kernels").fetchall()
     agg = {}
-    for name, s, e in rows:
-        k = short(name)
+    for name, s, e, *g in rows:
+        k = short(name) + (" grid " + "x".join(str(v) for v in g) if g else "")
         a = agg.setdefault(k, [0, 0.0])
         a[0] += 1
         a[1] += (e - s) / 1e3
     total = sum(v[1] for v in agg.values())
     print(f"| kernel | launches | total us | avg us | share |")
     print(f"|---|---:|---:|---:|---:|")
-    for k, (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+    for k, (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:(120 if by_grid else 40)]:
         print(f"| `{k}` | {n} | {us:.0f} | {us / n:.2f} | {100 * us / total:.1f}% |")
     print(f"\ntotal kernel time {total / 1e3:.2f} ms over {sum(v[0] for v in agg.values())} launches" +
           (f"; {total / 1e3 / steps:.3f} ms per step over {steps} steps (all kernels incl. warm-up/autotune)" if steps else ""))

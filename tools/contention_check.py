@@ -37,10 +37,20 @@ def main():
             x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
             w = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(dev)
             gold = x.float() @ w.float().T
-            for tile in (60, 61, 62, 63, 64, 65, 66, 11, 20, 30):
+            for tile in (60, 61, 62, 63, 64, 65, 66, 67, 11, 20, 30):
                 bad = sum(float((ops.gemm(x, w, out_f32=True, tile=tile) - gold).abs().max()) > 0.05 for _ in range(a.reps))
                 total += bad
                 print(f"{M}x{N}x{K} tile {tile}: {bad}/{a.reps} launches wrong", flush=True)
+        # the A-resident N-streaming tile (70): eight independent waves per workgroup, W straight from memory into MFMA operands
+        from asva_amd.weights import pack_frag
+        for M, N, K in ((3000, 2560, 320), (1536, 5120, 640)):
+            x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+            w = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(dev)
+            wf = pack_frag(w)
+            gold = x.float() @ w.float().T
+            bad = sum(float((ops.gemm(x, w, out_f32=True, tile=70, w_frag=wf) - gold).abs().max()) > 0.05 for _ in range(a.reps))
+            total += bad
+            print(f"{M}x{N}x{K} tile 70: {bad}/{a.reps} launches wrong", flush=True)
         unet = bench.build_unet(dev, 0, 1)
         lat, text, audio, null_audio = bench.synthetic_clip(dev, 1000)
         xin = torch.cat([lat, lat])

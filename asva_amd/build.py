@@ -19,7 +19,7 @@ VARIANTS = {"bf16": ("", LIB, []), "fp16": ("_f16", os.path.join(HERE, "libavsd_
 SOURCES = ["lib.hip", "attention.hip", "attention_x2.hip", "gemm_f32.hip", "gemm4.hip", "nstream.hip", "conv3r.hip", "norm.hip", "groupnorm_fused.hip", "elementwise.hip", "audio.hip", "xattn.hip", "attention_fp8.hip", "plan.hip"]
 # gemm.hip instantiates ~290 kernels: compiled as six translation units (one per A-loader mode, the entry point, and two for
 # the split-precision tiles)
-GEMM_UNITS = 6
+GEMM_UNITS = 7
 HEADERS = [os.path.join(CSRC, "avsd_common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "gemm4_loops.inc"),
            os.path.join(HERE, "..", "include", "avsd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

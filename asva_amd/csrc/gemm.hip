@@ -84,7 +84,7 @@ __device__ __forceinline__ uint4 load_a(const avsd_gemm_desc& p, const h16_t* A,
   return *reinterpret_cast<const uint4*>(ptr);
 }
 
-template <int BM, int BN, int MODE>
+template <int BM, int BN, int MODE, int EX = EPI_PLAIN>
 __global__ __launch_bounds__(256) void gemm_kernel(const avsd_gemm_desc p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   h16_t* sA = reinterpret_cast<h16_t*>(smem);      // [2][BM][LDS_STRIDE]
@@ -196,15 +196,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const avsd_gemm_desc p) {
   }
 
   const float no_pre[2 * FM] = {};
-  epilogue<FN, FM>(p, acc, tm * BM + wm * (BM / 2), tn * BN + wn * (BN / 2), lane, bz, no_pre, false);
+  epilogue<FN, FM, false, EX>(p, acc, tm * BM + wm * (BM / 2), tn * BN + wn * (BN / 2), lane, bz, no_pre, false);
 }
 
-template <int BM, int BN, int MODE>
+template <int BM, int BN, int MODE, int EX = EPI_PLAIN>
 int launch(const avsd_gemm_desc& d, hipStream_t s) {
   constexpr size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(h16_t);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, MODE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, MODE, EX>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       avsd_set_error("gemm: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
@@ -214,7 +214,7 @@ int launch(const avsd_gemm_desc& d, hipStream_t s) {
   }
   const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
   dim3 grid((unsigned)(ntm * ntn), 1, (unsigned)d.batch);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE>), grid, dim3(256), lds, s, d);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE, EX>), grid, dim3(256), lds, s, d);
   AVSD_CHECK_LAUNCH("gemm launch");
   return AVSD_OK;
 }
@@ -307,7 +307,11 @@ constexpr int gemm2_min_waves(int bm, int bn, int stages, bool x2, int waves) {
   const int w = (wgs * waves + 3) / 4;
   return w > 3 ? 3 : w;
 }
-template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int LW = 0, bool X2 = false>
+// MODE_SUBPIX: the sub-pixel form of nearest-2x upsample + 3x3 convolution (AVSD_GEMM_CONV3 descriptors with ups = 2, include/avsd.h) — an
+// A-loader mode of its own, so that the CONV3 kernels keep the code (and the registers) they had.
+// EX (gemm_common.h): EPI_REST = this kernel also stores the rest plane of its 16-bit output (AVSD_GEMM_OUT_REST; IEEE-half build only).
+constexpr int MODE_SUBPIX = 3;
+template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int LW = 0, bool X2 = false, int EX = EPI_PLAIN>
 __global__ __launch_bounds__(64 * (WM * WN + LW), gemm2_min_waves(BM, BN, STAGES, X2, WM * WN + LW)) void gemm2_kernel(const avsd_gemm_desc p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem2[];
   constexpr int NC = WM * WN;               // MFMA waves
@@ -402,12 +406,20 @@ __global__ __launch_bounds__(64 * (WM * WN + LW), gemm2_min_waves(BM, BN, STAGES
   // source (`rebase`, a wave-uniform branch), so the per-tile address work is one add per load.
   // Fast path needs every K tile inside one tap / segment (cin % 64 == 0, cseg % 64 == 0).
   const bool fast = (MODE == AVSD_GEMM_PLAIN) || (MODE == AVSD_GEMM_TMIX && p.cseg % BK == 0) ||
-                    (MODE == AVSD_GEMM_CONV3 && p.cin % BK == 0);
+                    ((MODE == AVSD_GEMM_CONV3 || MODE == MODE_SUBPIX) && p.cin % BK == 0);
   // Rotated K walk (AVSD_GEMM_KROT, see gemm4.hip): row bands (tm) that share a column band of W start at different K tiles of
   // the slice and wrap — the weights of the low-resolution layers stream from HBM inside a step, and a lockstep walk is one chain
   // of round trips.  Deterministic; only the f32 summation order of a band rotates.
   const int nk_slice = max(kt1 - kt0, 0);
   const int krot = ((p.flags & AVSD_GEMM_KROT) && nk_slice > 1 && ntm > 1) ? (int)(((long long)tm * nk_slice) / ntm) : 0;
+  // MODE_SUBPIX: a 2 x 2 kernel on the ORIGINAL image per output-pixel parity (dy, dx); this column tile lies inside one parity
+  // (cout % BN == 0, checked by launch2), whose input window starts at (y + dy - 1, x + dx - 1): the gather of a 2 x 2 convolution
+  // with padding (1 - dy, 1 - dx)
+  constexpr bool subpix = MODE == MODE_SUBPIX;
+  constexpr int KS = subpix ? 2 : 3;                  // kernel rows / columns walked by the tap decode
+  const int ush = subpix ? 0 : p.ups;
+  const int sub_par = subpix ? (tn * BN) / (p.N >> 2) : 0;
+  const int sub_dy = sub_par >> 1, sub_dx = sub_par & 1;
   int i_kbase = 0;          // first k of the tile
   int i_c0 = 0;             // PLAIN: = kbase; CONV3: channel offset inside the tap; TMIX: offset inside the segment
   int i_kh = 0, i_kw = 0, i_seg = 0;
@@ -423,12 +435,12 @@ __global__ __launch_bounds__(64 * (WM * WN + LW), gemm2_min_waves(BM, BN, STAGES
     } else {
       const int tap = i_kbase / p.cin;
       i_c0 = i_kbase - tap * p.cin;
-      i_kh = tap / 3;
-      i_kw = tap - i_kh * 3;
+      i_kh = tap / KS;
+      i_kw = tap - i_kh * KS;
     }
   };
   seek((kt0 + krot) * BK);
-  const int hin = p.hs << p.ups, win = p.ws << p.ups;
+  const int hin = p.hs << ush, win = p.ws << ush;
   int abase[PA];
   bool aok[PA];
 
@@ -443,10 +455,10 @@ __global__ __launch_bounds__(64 * (WM * WN + LW), gemm2_min_waves(BM, BN, STAGES
         abase[j] = o + kca[j];
         aok[j] = rvalid[j] && i_seg < 3;
       } else {
-        const int hi = rhb[j] + i_kh;
-        const int wi = rwb[j] + i_kw;
-        aok[j] = rvalid[j] && i_kh < 3 && (unsigned)hi < (unsigned)hin && (unsigned)wi < (unsigned)win;
-        abase[j] = ((ro0[j] * p.hs + (hi >> p.ups)) * p.ws + (wi >> p.ups)) * p.lda + kca[j];
+        const int hi = rhb[j] + i_kh + sub_dy;
+        const int wi = rwb[j] + i_kw + sub_dx;
+        aok[j] = rvalid[j] && i_kh < KS && (unsigned)hi < (unsigned)hin && (unsigned)wi < (unsigned)win;
+        abase[j] = ((ro0[j] * p.hs + (hi >> ush)) * p.ws + (wi >> ush)) * p.lda + kca[j];
       }
     }
   };
@@ -501,7 +513,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW), gemm2_min_waves(BM, BN, STAGES
       i_c0 += BK;
       if (i_c0 >= p.cin) {
         i_c0 = 0;
-        if (++i_kw == 3) { i_kw = 0; ++i_kh; }
+        if (++i_kw == KS) { i_kw = 0; ++i_kh; }
         rebase();
       }
     }
@@ -658,7 +670,12 @@ __global__ __launch_bounds__(64 * (WM * WN + LW), gemm2_min_waves(BM, BN, STAGES
       }
     }
   }
-  if constexpr (X2) epilogue_x2<FN, FM>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
+  if constexpr (subpix) {     // the same epilogue with the per-pixel output scatter compiled in (gemm_common.h EPI_SHUF)
+    if constexpr (X2) epilogue_x2<FN, FM, true>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
+    else epilogue_each<FN, FM, (64 * (WM * WN + LW) > 512), EPI_SHUF>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
+  } else if constexpr (X2) epilogue_x2<FN, FM>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
+  else if constexpr (EX == EPI_REST)     // (a fragment at a time: the rest-plane words need one fragment of temporaries more)
+    epilogue_each<FN, FM, (64 * (WM * WN + LW) > 512), EPI_REST>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
   else if constexpr (FN * FM >= 10)      // 64 x 160 wave tiles (tile 19): the 10-fragment epilogue is not unrolled -> accumulators in scratch (gemm_common.h)
     epilogue_each<FN, FM, (64 * (WM * WN + LW) > 512)>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
   else epilogue<FN, FM, (64 * (WM * WN + LW) > 512)>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
@@ -667,13 +684,16 @@ __global__ __launch_bounds__(64 * (WM * WN + LW), gemm2_min_waves(BM, BN, STAGES
 // out = epilogue(sum_s ws[s]) for split-K launches: one thread per 4 consecutive columns.  S = the slice count (2 / 4 / 8:
 // all slab loads of a thread are issued before the first add — the kernel is one memory round trip deep instead of S;
 // 7.4 -> ~4 us per launch, 73 launches per step) or 0 (any count, one load at a time).  The sum runs in slice order.
-template <int S>
+// EXTRA: the rest plane of a one-pass output (AVSD_GEMM_OUT_REST) and the per-pixel output scatter of AVSD_GEMM_CONV3 with ups = 2
+// (gemm_common.h) — run-time options of a SEPARATE instantiation, so that the reduce of every other split-K launch keeps its registers
+template <int S, bool EXTRA = false>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const avsd_gemm_desc p) {
   const int nq = p.N / 4;
   const int64_t total = (int64_t)p.M * nq;
   const h16_t* R1 = reinterpret_cast<const h16_t*>(p.res1);
   const h16_t* R2 = reinterpret_cast<const h16_t*>(p.res2);
   const bool x2 = (p.flags & AVSD_GEMM_X2) != 0;
+  const bool out_rest = EXTRA && (p.flags & AVSD_GEMM_OUT_REST) != 0;     // one-pass product, rest plane of the output wanted (not part of the row statistics)
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int m = (int)(i / nq);
     const int n = (int)(i - (int64_t)m * nq) * 4;
@@ -748,8 +768,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const avsd_gemm_desc
         if (x2) { v[0] += lo2f(pre_r2lo.x); v[1] += hi2f(pre_r2lo.x); v[2] += lo2f(pre_r2lo.y); v[3] += hi2f(pre_r2lo.y); }
       }
     }
-    if (p.out_master) *reinterpret_cast<float4*>(p.out_master + (int64_t)m * p.ldm + n) = make_float4(v[0], v[1], v[2], v[3]);
-    const int64_t o = (int64_t)m * p.ldc + n;
+    int64_t mo = m;
+    int no = n;
+    if (EXTRA && p.mode == AVSD_GEMM_CONV3 && p.ups == 2) {      // (input pixel, parity x channel) -> (output pixel, channel), gemm_common.h EPI_SHUF
+      int radd;
+      shuf_col(p, n, radd, no);
+      mo = shuf_row(p, m) + radd;
+    }
+    if (p.out_master) *reinterpret_cast<float4*>(p.out_master + mo * p.ldm + no) = make_float4(v[0], v[1], v[2], v[3]);
+    const int64_t o = mo * p.ldc + no;
     if (p.flags & AVSD_GEMM_OUT_F32) {
       *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) = make_float4(v[0], v[1], v[2], v[3]);
     } else {
@@ -758,12 +785,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const avsd_gemm_desc
       st.y = pack2h(v[2], v[3]);
       *reinterpret_cast<uint2*>(reinterpret_cast<h16_t*>(p.out) + o) = st;
       float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;     // x2: what the rest plane adds to the stored value
-      if (x2) {
+      if (x2 || out_rest) {
         uint2 sr;
         sr.x = pack2h(v[0] - lo2f(st.x), v[1] - hi2f(st.x));
         sr.y = pack2h(v[2] - lo2f(st.y), v[3] - hi2f(st.y));
         *reinterpret_cast<uint2*>(reinterpret_cast<h16_t*>(p.out) + p.out_lo + o) = sr;
-        e0 = lo2f(sr.x); e1 = hi2f(sr.x); e2 = lo2f(sr.y); e3 = hi2f(sr.y);
+        if (x2) { e0 = lo2f(sr.x); e1 = hi2f(sr.x); e2 = lo2f(sr.y); e3 = hi2f(sr.y); }
       }
       if (p.flags & AVSD_GEMM_ROWSTATS) {
         // 8 consecutive threads hold one 32-column block of row m (N % 32 == 0, 256 % 8 == 0): fold in a fixed order
@@ -787,13 +814,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const avsd_gemm_desc
   }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int LW = 0, bool X2 = false>
+template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int LW = 0, bool X2 = false, int EX = EPI_PLAIN>
 int launch2(const avsd_gemm_desc& d, hipStream_t s) {
   constexpr size_t lds = (size_t)STAGES * (BM + BN) * 128 * (X2 ? 2 : 1);
   static_assert(lds <= 160 * 1024, "tile does not fit the 160 KB of LDS");
+  if (MODE == MODE_SUBPIX && (d.N / 4) % BN != 0) {
+    avsd_set_error("gemm/conv3: ups = 2 needs whole column tiles per output-pixel parity: cout (%d) %% %d != 0 for this tile", d.N / 4, BN);
+    return AVSD_EINVAL;
+  }
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<BM, BN, WM, WN, STAGES, MODE, LW, X2>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<BM, BN, WM, WN, STAGES, MODE, LW, X2, EX>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       avsd_set_error("gemm2: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
@@ -804,12 +835,15 @@ int launch2(const avsd_gemm_desc& d, hipStream_t s) {
   const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
   const int nsplit = d.split_k > 1 ? d.split_k : 1;
   dim3 grid((unsigned)(ntm * ntn), (unsigned)nsplit, (unsigned)d.batch);
-  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM, WN, STAGES, MODE, LW, X2>), grid, dim3(64 * (WM * WN + LW)), lds, s, d);
+  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM, WN, STAGES, MODE, LW, X2, EX>), grid, dim3(64 * (WM * WN + LW)), lds, s, d);
   AVSD_CHECK_LAUNCH("gemm2 launch");
   if (nsplit > 1) {
     const int64_t total = (int64_t)d.M * (d.N / 4);
     int64_t g = (total + 255) / 256;
     if (g > 2048) g = 2048;
+    if (MODE == MODE_SUBPIX || (d.flags & AVSD_GEMM_OUT_REST)) {      // the reduce with the rest-plane store / output scatter (any slice count)
+      hipLaunchKernelGGL((splitk_reduce_kernel<0, true>), dim3((unsigned)g), dim3(256), 0, s, d);
+    } else
     switch (nsplit) {
       case 2: hipLaunchKernelGGL(splitk_reduce_kernel<2>, dim3((unsigned)g), dim3(256), 0, s, d); break;
       case 4: hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((unsigned)g), dim3(256), 0, s, d); break;
@@ -823,36 +857,36 @@ int launch2(const avsd_gemm_desc& d, hipStream_t s) {
   return AVSD_OK;
 }
 
-template <int MODE>
+template <int MODE, int EX = EPI_PLAIN>
 int dispatch_tile(const avsd_gemm_desc& d, int tile, hipStream_t s) {
   switch (tile) {
-    case 1: return launch<128, 128, MODE>(d, s);
-    case 2: return launch<128, 64, MODE>(d, s);
-    case 3: return launch<64, 64, MODE>(d, s);
+    case 1: return launch<128, 128, MODE, EX>(d, s);
+    case 2: return launch<128, 64, MODE, EX>(d, s);
+    case 3: return launch<64, 64, MODE, EX>(d, s);
     // v2 (LDS-direct ring): BM, BN, waves M x N, stages
-    case 4: return launch2<128, 64, 2, 2, 3, MODE>(d, s);
-    case 6: return launch2<128, 128, 2, 4, 3, MODE>(d, s);
-    case 7: return launch2<64, 64, 2, 2, 4, MODE>(d, s);
-    case 9: return launch2<256, 128, 4, 2, 3, MODE>(d, s);
-    case 11: return launch2<128, 128, 2, 2, 2, MODE>(d, s);   // 64 KB: two 4-wave blocks per CU, 64x64 wave tiles
-    case 12: return launch2<128, 64, 2, 2, 2, MODE>(d, s);    // 48 KB: three blocks per CU
-    case 13: return launch2<64, 64, 2, 2, 2, MODE>(d, s);     // 32 KB: five blocks per CU (short-K GEMMs)
-    case 14: return launch2<256, 128, 4, 2, 2, MODE>(d, s);   // 96 KB
+    case 4: return launch2<128, 64, 2, 2, 3, MODE, 0, false, EX>(d, s);
+    case 6: return launch2<128, 128, 2, 4, 3, MODE, 0, false, EX>(d, s);
+    case 7: return launch2<64, 64, 2, 2, 4, MODE, 0, false, EX>(d, s);
+    case 9: return launch2<256, 128, 4, 2, 3, MODE, 0, false, EX>(d, s);
+    case 11: return launch2<128, 128, 2, 2, 2, MODE, 0, false, EX>(d, s);   // 64 KB: two 4-wave blocks per CU, 64x64 wave tiles
+    case 12: return launch2<128, 64, 2, 2, 2, MODE, 0, false, EX>(d, s);    // 48 KB: three blocks per CU
+    case 13: return launch2<64, 64, 2, 2, 2, MODE, 0, false, EX>(d, s);     // 32 KB: five blocks per CU (short-K GEMMs)
+    case 14: return launch2<256, 128, 4, 2, 2, MODE, 0, false, EX>(d, s);   // 96 KB
     // full-row tiles for N = 320 / 640 / 1280 layers: the activation tile is fetched from L2 once per block
-    case 17: return launch2<128, 320, 4, 2, 2, MODE>(d, s);   // 112 KB, 8 waves, 32x160 wave tiles
+    case 17: return launch2<128, 320, 4, 2, 2, MODE, 0, false, EX>(d, s);   // 112 KB, 8 waves, 32x160 wave tiles
     // 256-row tiles for the widest layers: (BM + BN) / (BM * BN) global->LDS bytes per MFMA is what the texture path pays
-    case 19: return launch2<256, 320, 4, 2, 2, MODE>(d, s);   // 144 KB, 8 waves, 64x160 wave tiles
+    case 19: return launch2<256, 320, 4, 2, 2, MODE, 0, false, EX>(d, s);   // 144 KB, 8 waves, 64x160 wave tiles
     // the same tiles with 2 extra loader waves (LW): the MFMA waves issue no loads
-    case 20: return launch2<256, 128, 4, 2, 3, MODE, 4>(d, s);
-    case 24: return launch2<128, 64, 2, 2, 3, MODE, 2>(d, s);
-    case 25: return launch2<64, 64, 2, 2, 4, MODE, 2>(d, s);
+    case 20: return launch2<256, 128, 4, 2, 3, MODE, 4, false, EX>(d, s);
+    case 24: return launch2<128, 64, 2, 2, 3, MODE, 2, false, EX>(d, s);
+    case 25: return launch2<64, 64, 2, 2, 4, MODE, 2, false, EX>(d, s);
     // deep rings for the weight-streaming low-resolution layers (M = 384 / 1536, K up to 23040): what bounds them is the
     // bytes in flight per CU against the ~2 us HBM round trip, so the ring takes all of LDS
-    case 30: return launch2<128, 128, 2, 4, 4, MODE>(d, s);     // 128 KB
-    case 31: return launch2<128, 256, 2, 4, 3, MODE>(d, s);     // 144 KB, weight-heavy tile
+    case 30: return launch2<128, 128, 2, 4, 4, MODE, 0, false, EX>(d, s);     // 128 KB
+    case 31: return launch2<128, 256, 2, 4, 3, MODE, 0, false, EX>(d, s);     // 144 KB, weight-heavy tile
     // 256 x 160: the geometry the resident convolution does best with on the N = 320 layers (conv3r.hip tile 43) — N = 320 /
     // 640 / 960 / 1280 in whole column tiles, 98 FLOP per staged byte (128 x 128: 64)
-    case AVSD_GEMM_TILE_256x160_8W: return launch2<256, 160, 8, 1, 3, MODE, 4>(d, s);   // 156 KB, 32x160 wave tiles, 8 MFMA + 4 loader waves
+    case AVSD_GEMM_TILE_256x160_8W: return launch2<256, 160, 8, 1, 3, MODE, 4, false, EX>(d, s);   // 156 KB, 32x160 wave tiles, 8 MFMA + 4 loader waves
     // (built, measured and dropped — never the tuner's pick on MI355X: 128x128 x 3 on 4 waves (5), 128x64 x 4 (10), the 128x320 / 64x320
     //  4-wave full-row tiles (15, 16), 256x256 (18), 128x128 / 256x64 / 64x320 with loader waves (26-28), the 5-deep 128x128 ring (29),
     //  96x320 x 2 (33), 256x160 on 4 MFMA waves (39); round 4, <= 2 table entries each once the asm tiles existed: 256x64 (8), the
@@ -915,14 +949,58 @@ int pick_tile(int M, int N, int batch) {
 int avsd_gemm_dispatch_plain(const avsd_gemm_desc& d, int tile, hipStream_t s);
 int avsd_gemm_dispatch_tmix(const avsd_gemm_desc& d, int tile, hipStream_t s);
 int avsd_gemm_dispatch_conv3(const avsd_gemm_desc& d, int tile, hipStream_t s);
+// (IEEE-half build: a launch with AVSD_GEMM_OUT_REST runs the EPI_REST instantiation of its tile — separate kernels, so the ones every
+//  other launch runs keep their registers; profiles/r6_epilogue_ab.txt)
+#ifdef AVSD_F16
+#define AVSD_DISPATCH_TILE(MODE) ((d.flags & AVSD_GEMM_OUT_REST) ? dispatch_tile<MODE, EPI_REST>(d, tile, s) : dispatch_tile<MODE>(d, tile, s))
+#else
+#define AVSD_DISPATCH_TILE(MODE) dispatch_tile<MODE>(d, tile, s)
+#endif
 #if !defined(AVSD_GEMM_TU) || AVSD_GEMM_TU == 0
-int avsd_gemm_dispatch_plain(const avsd_gemm_desc& d, int tile, hipStream_t s) { return dispatch_tile<AVSD_GEMM_PLAIN>(d, tile, s); }
+int avsd_gemm_dispatch_plain(const avsd_gemm_desc& d, int tile, hipStream_t s) { return AVSD_DISPATCH_TILE(AVSD_GEMM_PLAIN); }
 #endif
 #if !defined(AVSD_GEMM_TU) || AVSD_GEMM_TU == 1
-int avsd_gemm_dispatch_tmix(const avsd_gemm_desc& d, int tile, hipStream_t s) { return dispatch_tile<AVSD_GEMM_TMIX>(d, tile, s); }
+int avsd_gemm_dispatch_tmix(const avsd_gemm_desc& d, int tile, hipStream_t s) { return AVSD_DISPATCH_TILE(AVSD_GEMM_TMIX); }
 #endif
 #if !defined(AVSD_GEMM_TU) || AVSD_GEMM_TU == 2
-int avsd_gemm_dispatch_conv3(const avsd_gemm_desc& d, int tile, hipStream_t s) { return dispatch_tile<AVSD_GEMM_CONV3>(d, tile, s); }
+int avsd_gemm_dispatch_conv3(const avsd_gemm_desc& d, int tile, hipStream_t s) { return AVSD_DISPATCH_TILE(AVSD_GEMM_CONV3); }
+#endif
+// sub-pixel upsample convolution (CONV3 descriptors with ups = 2): its own A-loader mode, one-pass and split-precision tiles
+int avsd_gemm_dispatch_subpix(const avsd_gemm_desc& d, int tile, hipStream_t s);
+int avsd_gemm_dispatch_x2_subpix(const avsd_gemm_desc& d, int tile, hipStream_t s);
+#if !defined(AVSD_GEMM_TU) || AVSD_GEMM_TU == 6
+int avsd_gemm_dispatch_subpix(const avsd_gemm_desc& d, int tile, hipStream_t s) {
+  switch (tile) {       // (the tiles the tuner is offered for these layers, asva_amd/ops.py SUBPIX_TILES)
+    case 4: return launch2<128, 64, 2, 2, 3, MODE_SUBPIX>(d, s);
+    case 6: return launch2<128, 128, 2, 4, 3, MODE_SUBPIX>(d, s);
+    case 9: return launch2<256, 128, 4, 2, 3, MODE_SUBPIX>(d, s);
+    case 11: return launch2<128, 128, 2, 2, 2, MODE_SUBPIX>(d, s);
+    case 13: return launch2<64, 64, 2, 2, 2, MODE_SUBPIX>(d, s);
+    case 17: return launch2<128, 320, 4, 2, 2, MODE_SUBPIX>(d, s);
+    case 20: return launch2<256, 128, 4, 2, 3, MODE_SUBPIX, 4>(d, s);
+    case 24: return launch2<128, 64, 2, 2, 3, MODE_SUBPIX, 2>(d, s);
+    case 25: return launch2<64, 64, 2, 2, 4, MODE_SUBPIX, 2>(d, s);
+    case 30: return launch2<128, 128, 2, 4, 4, MODE_SUBPIX>(d, s);
+    case AVSD_GEMM_TILE_256x160_8W: return launch2<256, 160, 8, 1, 3, MODE_SUBPIX, 4>(d, s);
+    default:
+      avsd_set_error("gemm/conv3: ups = 2 runs on tiles 4, 6, 9, 11, 13, 17, 20, 24, 25, 30, 38 (got %d)", tile);
+      return AVSD_EINVAL;
+  }
+}
+int avsd_gemm_dispatch_x2_subpix(const avsd_gemm_desc& d, int tile, hipStream_t s) {
+  switch (tile) {
+    case 7: return launch2<64, 64, 2, 2, 4, MODE_SUBPIX, 0, true>(d, s);
+    case 11: return launch2<128, 128, 2, 2, 2, MODE_SUBPIX, 0, true>(d, s);
+    case 13: return launch2<64, 64, 2, 2, 2, MODE_SUBPIX, 0, true>(d, s);
+    case 24: return launch2<128, 64, 2, 2, 3, MODE_SUBPIX, 2, true>(d, s);
+    case 25: return launch2<64, 64, 2, 2, 4, MODE_SUBPIX, 2, true>(d, s);
+    case 34: return launch2<128, 160, 4, 1, 2, MODE_SUBPIX, 0, true>(d, s);
+    case 35: return launch2<256, 64, 4, 2, 2, MODE_SUBPIX, 0, true>(d, s);
+    default:
+      avsd_set_error("gemm/conv3: ups = 2 with AVSD_GEMM_X2 runs on tiles 7, 11, 13, 24, 25, 34, 35 (got %d)", tile);
+      return AVSD_EINVAL;
+  }
+}
 #endif
 
 int avsd_gemm_dispatch_x2_plain(const avsd_gemm_desc& d, int tile, hipStream_t s);
@@ -946,6 +1024,9 @@ int avsd_gemm_splitk_reduce(const avsd_gemm_desc& d, hipStream_t s) {
   const int64_t total = (int64_t)d.M * (d.N / 4);
   int64_t g = (total + 255) / 256;
   if (g > 2048) g = 2048;
+  if (d.flags & AVSD_GEMM_OUT_REST) {
+    hipLaunchKernelGGL((splitk_reduce_kernel<0, true>), dim3((unsigned)g), dim3(256), 0, s, d);
+  } else
   switch (d.split_k) {
     case 2: hipLaunchKernelGGL(splitk_reduce_kernel<2>, dim3((unsigned)g), dim3(256), 0, s, d); break;
     case 4: hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((unsigned)g), dim3(256), 0, s, d); break;
@@ -996,6 +1077,14 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
   if (d.out_master) AVSD_REQUIRE(d.ldm % 4 == 0 && d.ldm >= d.N && !(d.flags & AVSD_GEMM_GEGLU),
                                  "gemm: out_master needs ldm %% 4 == 0, ldm >= N and no GEGLU");
   if (d.rowvec) AVSD_REQUIRE(d.rows_per_vec > 0 && d.ldv % 4 == 0, "gemm: rowvec needs rows_per_vec > 0 and ldv %% 4 == 0");
+  if (d.flags & AVSD_GEMM_OUT_REST) {
+#ifndef AVSD_F16
+    AVSD_REQUIRE(false, "gemm: OUT_REST is compiled into the IEEE-half build only (libavsd_hip_f16.so: the per-layer precision plan is fp16 storage)");
+#endif
+    AVSD_REQUIRE(!(d.flags & (AVSD_GEMM_X2 | AVSD_GEMM_OUT_F32 | AVSD_GEMM_GEGLU)) && d.out_lo != 0 && (d.out_lo & 7) == 0 && d.batch == 1 &&
+                     d.tile != AVSD_GEMM_TILE_NSTREAM && !(d.tile >= AVSD_GEMM_TILE_CONV3R_FIRST && d.tile <= AVSD_GEMM_TILE_CONV3R2D_LAST),
+                 "gemm: OUT_REST is for one-pass 16-bit outputs (no X2 / OUT_F32 / GEGLU / batch, not on tiles 40..54 / 70) and needs out_lo %% 8 == 0, != 0");
+  }
   if (d.mode == AVSD_GEMM_PLAIN) {
     if (!d.A2) d.k_split = d.K;
     AVSD_REQUIRE(d.k_split % 8 == 0 && d.k_split <= d.K, "gemm: k_split (%d) must be a multiple of 8 and <= K", d.k_split);
@@ -1004,13 +1093,25 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
     AVSD_REQUIRE(d.cseg > 0 && d.cseg % 8 == 0 && d.K == 3 * d.cseg, "gemm/tmix: K (%d) must equal 3*cseg (%d)", d.K, d.cseg);
     AVSD_REQUIRE(d.hw > 0 && d.frames > 0 && d.M % (d.hw * d.frames) == 0, "gemm/tmix: M (%d) must be a multiple of frames*hw (%d*%d)", d.M, d.frames, d.hw);
   } else if (d.mode == AVSD_GEMM_CONV3) {
-    AVSD_REQUIRE(d.cin > 0 && d.cin % 8 == 0 && d.K == 9 * d.cin, "gemm/conv3: K (%d) must equal 9*cin (%d), cin %% 8 == 0", d.K, d.cin);
     AVSD_REQUIRE(d.stride == 1 || d.stride == 2, "gemm/conv3: stride must be 1 or 2");
-    AVSD_REQUIRE(d.ups == 0 || d.ups == 1, "gemm/conv3: ups must be 0 or 1");
+    if (d.ups == 2) {      // sub-pixel upsample convolution: rows = input pixels, columns = (parity, cout), K = 4 taps x cin
+      AVSD_REQUIRE(d.cin > 0 && d.cin % 64 == 0 && d.K == 4 * d.cin, "gemm/conv3: ups = 2 needs K (%d) == 4*cin (%d), cin %% 64 == 0", d.K, d.cin);
+      AVSD_REQUIRE(d.stride == 1 && d.pad == 1 && d.hs > 0 && d.ws > 0 && d.ho == d.hs && d.wo == d.ws && d.M % (d.hs * d.ws) == 0,
+                   "gemm/conv3: ups = 2 needs stride 1, pad 1, (ho, wo) = (hs, ws) and whole images");
+      AVSD_REQUIRE(d.N % 4 == 0 && (d.N / 4) % 64 == 0 && d.ldc >= d.N / 4, "gemm/conv3: ups = 2 needs N = 4 * cout, cout %% 64 == 0, ldc >= cout");
+      AVSD_REQUIRE(!d.A2 && !d.res1 && !d.res2 && !d.rowvec && !(d.flags & (AVSD_GEMM_GEGLU | AVSD_GEMM_GELU | AVSD_GEMM_ROWSTATS | AVSD_GEMM_LNFUSE)) && d.batch == 1,
+                   "gemm/conv3: ups = 2 takes bias / out_master / the rest plane only");
+      AVSD_REQUIRE((double)d.M * 4.0 * d.ldc < 2147483648.0, "gemm/conv3: ups = 2 output too large");
+      AVSD_REQUIRE(d.tile >= 4 && !(d.tile >= AVSD_GEMM_TILE_CONV3R_FIRST && d.tile <= AVSD_GEMM_TILE_CONV3R2D_LAST) && !(d.tile >= AVSD_GEMM_TILE_ASM_FIRST),
+                   "gemm/conv3: ups = 2 runs on the LDS-direct tiles (4..38), got %d", d.tile);
+    } else {
+    AVSD_REQUIRE(d.cin > 0 && d.cin % 8 == 0 && d.K == 9 * d.cin, "gemm/conv3: K (%d) must equal 9*cin (%d), cin %% 8 == 0", d.K, d.cin);
+    AVSD_REQUIRE(d.ups == 0 || d.ups == 1, "gemm/conv3: ups must be 0, 1 or 2");
     AVSD_REQUIRE(d.pad == 0 || d.pad == 1, "gemm/conv3: pad must be 0 or 1");
     AVSD_REQUIRE(d.hs > 0 && d.ws > 0 && d.ho > 0 && d.wo > 0 && d.M % (d.ho * d.wo) == 0, "gemm/conv3: bad image geometry");
     const int hin = d.hs << d.ups, win = d.ws << d.ups;
     AVSD_REQUIRE(d.ho == (hin + 2 - 3) / d.stride + 1 && d.wo == (win + 2 - 3) / d.stride + 1, "gemm/conv3: (ho,wo)=(%d,%d) inconsistent with input (%d,%d) stride %d", d.ho, d.wo, hin, win, d.stride);
+    }
   } else {
     AVSD_REQUIRE(false, "gemm: unknown mode %d", d.mode);
   }
@@ -1038,7 +1139,6 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
     AVSD_REQUIRE(!d.res1 || (d.flags & AVSD_GEMM_RES1_F32) || d.res1_lo != 0, "gemm/x2: a 16-bit res1 needs res1_lo");
     AVSD_REQUIRE(!d.res2 || (d.flags & AVSD_GEMM_RES2_F32) || d.res2_lo != 0, "gemm/x2: a 16-bit res2 needs res2_lo");
     AVSD_REQUIRE(((d.a_lo | d.a2_lo | d.w_lo | d.out_lo | d.res1_lo | d.res2_lo) & 7) == 0, "gemm/x2: plane offsets must be multiples of 8 elements");
-    AVSD_REQUIRE(!d.out_master, "gemm/x2: no f32 master (the planes carry 16 bits)");
     AVSD_REQUIRE(d.mode != AVSD_GEMM_PLAIN || !d.A2 || d.k_split % 64 == 0, "gemm/x2: a two-source A needs k_split %% 64 == 0 (got %d)", d.k_split);
     const double a_rows = d.mode == AVSD_GEMM_CONV3 ? (double)(d.M / (d.ho * d.wo)) * d.hs * d.ws : (double)d.M;
     AVSD_REQUIRE(a_rows * d.lda * 2.0 < 2147483648.0 && (double)d.N * d.ldw * 2.0 < 2147483648.0, "gemm/x2: operands must be < 2 GiB per plane");
@@ -1047,7 +1147,7 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
     switch (d.mode) {
       case AVSD_GEMM_PLAIN: return avsd_gemm_dispatch_x2_plain(d, d.tile, sx);
       case AVSD_GEMM_TMIX: return avsd_gemm_dispatch_x2_tmix(d, d.tile, sx);
-      default: return avsd_gemm_dispatch_x2_conv3(d, d.tile, sx);
+      default: return d.ups == 2 ? avsd_gemm_dispatch_x2_subpix(d, d.tile, sx) : avsd_gemm_dispatch_x2_conv3(d, d.tile, sx);
     }
   }
   int tile = d.tile;
@@ -1056,6 +1156,7 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
     const double a_rows = d.mode == AVSD_GEMM_CONV3 ? (double)(d.M / (d.ho * d.wo)) * d.hs * d.ws : (double)d.M;
     const bool big = a_rows * d.lda * 2.0 >= 2147483648.0 || (double)d.N * d.ldw * 2.0 >= 2147483648.0 ||
                      (d.A2 && (double)d.M * d.lda2 * 2.0 >= 2147483648.0);
+    AVSD_REQUIRE(!(big && d.mode == AVSD_GEMM_CONV3 && d.ups == 2), "gemm/conv3: ups = 2 needs operands < 2 GiB");
     if (big && (tile < 1 || tile > 3)) tile = (d.N > 64 && d.M > 2048) ? 1 : 3;
     // the LDS-direct loader picks the source buffer (A or A2) per 64-wide K tile: a split point inside a tile
     // needs the per-vector select of the register-staged kernel
@@ -1069,7 +1170,7 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
   switch (d.mode) {
     case AVSD_GEMM_PLAIN: return avsd_gemm_dispatch_plain(d, tile, s);
     case AVSD_GEMM_TMIX: return avsd_gemm_dispatch_tmix(d, tile, s);
-    default: return avsd_gemm_dispatch_conv3(d, tile, s);
+    default: return d.ups == 2 ? avsd_gemm_dispatch_subpix(d, tile, s) : avsd_gemm_dispatch_conv3(d, tile, s);
   }
 }
 #endif  // AVSD_GEMM_TU

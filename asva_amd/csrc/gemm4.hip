@@ -64,7 +64,8 @@ __device__ __forceinline__ f32x16 from_agpr(const f32x16& a) {
 // X2 (AVSD_GEMM_X2, split precision): every operand a (main, rest) pair of planes — an LDS stage holds [A | W | A rest | W rest], the rest
 // planes come through second buffer descriptors with the same offsets, every fragment pair takes three MFMAs (Wr.A, W.Ar, W.A).
 // NS = K tiles of global loads in flight per workgroup (staging register sets of the generated loop): 2 in every shipped tile
-template <int FM, int FN, int MODE, bool X2 = false, int NS = 2>
+// EX (gemm_common.h): EPI_REST = this kernel also stores the rest plane of its 16-bit output (AVSD_GEMM_OUT_REST; IEEE-half build only)
+template <int FM, int FN, int MODE, bool X2 = false, int NS = 2, int EX = EPI_PLAIN>
 __global__ __launch_bounds__(256, 1) void gemm4_kernel(const avsd_gemm_desc p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem4[];
   constexpr int BM = 64 * FM, BN = 64 * FN;
@@ -220,19 +221,19 @@ __global__ __launch_bounds__(256, 1) void gemm4_kernel(const avsd_gemm_desc p) {
       pre_ln[1] = mean * pre_ln[0];
     }
     if constexpr (X2) epilogue_x2<FN, 1>(p, band, m_base + 32 * B, n_base, lane, 0, pre_ln, ln_pre);
-    else if constexpr (FN == 5) epilogue_by_term<FN, 1>(p, band, m_base + 32 * B, n_base, lane, 0, pre_ln, ln_pre);   // (as the fused cross-attention tile)
-    else epilogue<FN, 1>(p, band, m_base + 32 * B, n_base, lane, 0, pre_ln, ln_pre);
+    else if constexpr (FN == 5) epilogue_by_term<FN, 1, EX>(p, band, m_base + 32 * B, n_base, lane, 0, pre_ln, ln_pre);   // (as the fused cross-attention tile)
+    else epilogue<FN, 1, false, EX>(p, band, m_base + 32 * B, n_base, lane, 0, pre_ln, ln_pre);
   });
 }
 
-template <int FM, int FN, int MODE, bool X2 = false, int NS = 2>
-int launch4(const avsd_gemm_desc& d, hipStream_t s) {
+template <int FM, int FN, int MODE, bool X2 = false, int NS = 2, int EX = EPI_PLAIN>
+int launch4_ex(const avsd_gemm_desc& d, hipStream_t s) {
   constexpr int BM = 64 * FM, BN = 64 * FN;
   constexpr size_t lds = (size_t)2 * (BM + BN) * ROWB * (X2 ? 2 : 1);
   static_assert(lds <= 160 * 1024, "tile does not fit the 160 KB of LDS");
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<FM, FN, MODE, X2, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<FM, FN, MODE, X2, NS, EX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       avsd_set_error("gemm4: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
       return AVSD_ELAUNCH;
@@ -242,10 +243,20 @@ int launch4(const avsd_gemm_desc& d, hipStream_t s) {
   const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
   const int nsplit = d.split_k > 1 ? d.split_k : 1;
   dim3 grid((unsigned)(ntm * ntn), (unsigned)nsplit, 1);
-  hipLaunchKernelGGL((gemm4_kernel<FM, FN, MODE, X2, NS>), grid, dim3(256), lds, s, d);
+  hipLaunchKernelGGL((gemm4_kernel<FM, FN, MODE, X2, NS, EX>), grid, dim3(256), lds, s, d);
   AVSD_CHECK_LAUNCH("gemm4 launch");
   if (nsplit > 1) return avsd_gemm_splitk_reduce(d, s);
   return AVSD_OK;
+}
+// (IEEE-half build: a one-pass launch with AVSD_GEMM_OUT_REST runs the EPI_REST instantiation of its tile — separate kernels)
+template <int FM, int FN, int MODE, bool X2 = false, int NS = 2>
+int launch4(const avsd_gemm_desc& d, hipStream_t s) {
+#ifdef AVSD_F16
+  if constexpr (!X2) {
+    if (d.flags & AVSD_GEMM_OUT_REST) return launch4_ex<FM, FN, MODE, X2, NS, EPI_REST>(d, s);
+  }
+#endif
+  return launch4_ex<FM, FN, MODE, X2, NS>(d, s);
 }
 
 }  // namespace

@@ -71,6 +71,33 @@ __device__ __forceinline__ void rowstats16(const unsigned (&w8)[8], const float*
   }
 }
 
+// ---- compile-time extras of the shared epilogue (template parameter EX) -------------------------------------------------------------
+// Round 6 first added both as run-time flags of the one epilogue: the bf16 step lost 1.6 %, the VAE decode 4.5 % against the round-5
+// tree on the same box (profiles/r6_epilogue_ab.txt) and the 768-thread tiles spilled 10-87 registers (tools/resource_usage.py) — the
+// shared epilogue is compiled into ~290 kernels that sit at their register budgets.  EX = 0 is the round-5 code, untouched.
+//   EPI_REST  AVSD_GEMM_OUT_REST (include/avsd.h): the 16-bit output also gets its rest plane round16(v - main) at out + out_lo — the
+//             (main, rest) pair a three-pass product reads, made by the producer instead of by an avsd_split_f32 pass over the f32
+//             master (68 launches per step in round 5).  Instantiated in the IEEE-half build only (the per-layer precision plan is
+//             fp16 storage, asva_amd/precision.py) by the kernels that produce residual-stream tensors: gemm2_kernel, gemm4_kernel.
+//   EPI_SHUF  AVSD_GEMM_CONV3 with ups = 2: GEMM row m = input pixel (img, y, x), GEMM column n = (parity dy dx, channel co) is element
+//             co of OUTPUT pixel (img, 2y + dy, 2x + dx) of the [n_img * 2 hs * 2 ws][ld] result (shuf_row: the output row of parity
+//             (0, 0); shuf_col: a column — a whole 32-column fragment lies inside one parity — as (rows to add, channel)); the rest
+//             plane is a run-time option there.  Instantiated by the CONV3 form of gemm2_kernel only.
+constexpr int EPI_PLAIN = 0, EPI_REST = 1, EPI_SHUF = 2;
+__device__ __forceinline__ unsigned rest2h(float v0, float v1, unsigned mainw) { return pack2h(v0 - lo2f(mainw), v1 - hi2f(mainw)); }
+__device__ __forceinline__ int64_t shuf_row(const avsd_gemm_desc& p, int m) { return 4 * (int64_t)m - 2 * (m % p.ws); }
+__device__ __forceinline__ void shuf_col(const avsd_gemm_desc& p, int n, int& radd, int& col) {
+  const int cout = p.N >> 2, par = n / cout;
+  col = n - par * cout;
+  radd = (par >> 1) * 2 * p.ws + (par & 1);
+}
+template <int EX>
+__device__ __forceinline__ bool epi_rest(const avsd_gemm_desc& p) {
+  if constexpr (EX == EPI_REST) return true;
+  else if constexpr (EX == EPI_SHUF) return (p.flags & AVSD_GEMM_OUT_REST) != 0;
+  else return false;
+}
+
 // Big tiles hold 128-160 accumulator registers: letting the compiler batch the loads of ALL fragments of a term would spill.
 // A scheduling fence after each fragment caps the batch at one fragment's loads (4-8 in flight), still one wait per fragment
 // instead of one per vector.
@@ -142,7 +169,7 @@ __device__ __forceinline__ void epilogue_add_residual(const avsd_gemm_desc& p, f
 // uniform branches and possibly-aliasing stores (it was 40-60 dependent round trips per workgroup; rocprof:
 // SQ_WAIT_ANY 60-67 % of the wave cycles of the short-K GEMMs).  Loads are made unconditional by clamping their row /
 // column to the last valid one; only the stores are guarded.  The f32 operation order per element is unchanged.
-template <int FN, int FM>
+template <int FN, int FM, int EX = EPI_PLAIN>
 __device__ __forceinline__ void epilogue_by_term(const avsd_gemm_desc& p, f32x16 (&acc)[FN][FM], int m_base, int n_base,
                                                  int lane, int64_t bz, const float (&pre_ln)[2 * FM], bool have_pre, int mstride = 32) {
   const int frow = lane & 31;
@@ -252,12 +279,19 @@ __device__ __forceinline__ void epilogue_by_term(const avsd_gemm_desc& p, f32x16
     const int m = mrow[b];
     if (m >= p.M) continue;
     float2* rs_out = rowstats ? reinterpret_cast<float2*>(p.rowstats) + ((int64_t)bz * p.M + m) * (p.N >> 5) : nullptr;
-    const int64_t orow = bo + (int64_t)m * p.ldc;
+    int64_t orow = bo + (int64_t)m * p.ldc;
     float* mrow_p = p.out_master ? p.out_master + bo + (int64_t)m * p.ldm : nullptr;
 #pragma unroll
     for (int a = 0; a < FN; ++a) {
       const int nb = n_base + a * 32;  // first packed column of this fragment
       if (nb >= p.N) continue;
+      if constexpr (EX == EPI_SHUF) {       // this fragment's parity moves it `radd` output rows down and to channel `ob` of its pixel
+        int radd, ob;
+        shuf_col(p, nb, radd, ob);
+        const int64_t mo = shuf_row(p, m) + radd;
+        orow = bo + mo * p.ldc + (ob - nb);
+        mrow_p = p.out_master ? p.out_master + bo + mo * p.ldm + (ob - nb) : nullptr;
+      }
       if (geglu) {
         // GEGLU: packed 32-row block = [16 value rows | 16 gate rows]; quads 0,1 hold values, 2,3 their gates.
         float g[2][4];
@@ -310,6 +344,22 @@ __device__ __forceinline__ void epilogue_by_term(const avsd_gemm_desc& p, f32x16
         h16_t* op = reinterpret_cast<h16_t*>(p.out) + orow + nb + 4 * hsel;
         *reinterpret_cast<uint4*>(op) = make_uint4(x[0][0], x[0][1], x[1][0], x[1][1]);
         *reinterpret_cast<uint4*>(op + 8) = make_uint4(y[0][0], y[0][1], y[1][0], y[1][1]);
+        if constexpr (EX != EPI_PLAIN) {
+          if (epi_rest<EX>(p)) {       // the rest plane of the same 32 bytes: round16(v - main), traded between the two lanes like the main words
+            unsigned xr[2][2], yr[2][2];
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+              const unsigned m0 = pack2h(acc[a][b][0 + 2 * d], acc[a][b][1 + 2 * d]), m2 = pack2h(acc[a][b][8 + 2 * d], acc[a][b][9 + 2 * d]);
+              const unsigned m1 = pack2h(acc[a][b][4 + 2 * d], acc[a][b][5 + 2 * d]), m3 = pack2h(acc[a][b][12 + 2 * d], acc[a][b][13 + 2 * d]);
+              const auto e = __builtin_amdgcn_permlane32_swap(rest2h(acc[a][b][0 + 2 * d], acc[a][b][1 + 2 * d], m0), rest2h(acc[a][b][8 + 2 * d], acc[a][b][9 + 2 * d], m2), false, false);
+              const auto o = __builtin_amdgcn_permlane32_swap(rest2h(acc[a][b][4 + 2 * d], acc[a][b][5 + 2 * d], m1), rest2h(acc[a][b][12 + 2 * d], acc[a][b][13 + 2 * d], m3), false, false);
+              xr[0][d] = e[0]; xr[1][d] = e[1];
+              yr[0][d] = o[0]; yr[1][d] = o[1];
+            }
+            *reinterpret_cast<uint4*>(op + p.out_lo) = make_uint4(xr[0][0], xr[0][1], xr[1][0], xr[1][1]);
+            *reinterpret_cast<uint4*>(op + p.out_lo + 8) = make_uint4(yr[0][0], yr[0][1], yr[1][0], yr[1][1]);
+          }
+        }
         if (rs_out) {
           // (sum, sum of squares) of the 16 rounded values this lane just stored (+ stats_pos), plus the partner lane's 16
           float sm, sq;
@@ -333,6 +383,14 @@ __device__ __forceinline__ void epilogue_by_term(const avsd_gemm_desc& p, f32x16
             st.x = pack2h(acc[a][b][4 * q], acc[a][b][4 * q + 1]);
             st.y = pack2h(acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]);
             *reinterpret_cast<uint2*>(reinterpret_cast<h16_t*>(p.out) + orow + n) = st;
+            if constexpr (EX != EPI_PLAIN) {
+              if (epi_rest<EX>(p)) {
+                uint2 sr;
+                sr.x = rest2h(acc[a][b][4 * q], acc[a][b][4 * q + 1], st.x);
+                sr.y = rest2h(acc[a][b][4 * q + 2], acc[a][b][4 * q + 3], st.y);
+                *reinterpret_cast<uint2*>(reinterpret_cast<h16_t*>(p.out) + p.out_lo + orow + n) = sr;
+              }
+            }
           }
         }
       }
@@ -344,7 +402,7 @@ __device__ __forceinline__ void epilogue_by_term(const avsd_gemm_desc& p, f32x16
 // n = n_base + 32*a + 8q + 4*(lane>>5) + {0..3} of fragment a (see header of this file) ----------------
 // Residuals are 16-bit, or f32 under AVSD_GEMM_RES1_F32 / RES2_F32 (the f32 residual stream); with `out_master` the
 // un-rounded f32 result is stored next to the 16-bit one.
-template <int FN, int FM>
+template <int FN, int FM, int EX = EPI_PLAIN>
 __device__ __forceinline__ void epilogue_by_fragment(const avsd_gemm_desc& p, f32x16 (&acc)[FN][FM], int m_base, int n_base,
                                          int lane, int64_t bz, const float (&pre_ln)[2 * FM], bool have_pre, int mstride = 32) {
   const int frow = lane & 31;
@@ -372,7 +430,7 @@ __device__ __forceinline__ void epilogue_by_fragment(const avsd_gemm_desc& p, f3
       else ln_row_stats(p, m, bz, ln_rstd, ln_mr);
     }
     float2* rs_out = rowstats ? reinterpret_cast<float2*>(p.rowstats) + ((int64_t)bz * p.M + m) * (p.N >> 5) : nullptr;
-    const int64_t orow = bz * p.batch_stride_out + (int64_t)m * p.ldc;
+    int64_t orow = bz * p.batch_stride_out + (int64_t)m * p.ldc;
     float* mrow = p.out_master ? p.out_master + bz * p.batch_stride_out + (int64_t)m * p.ldm : nullptr;
     // alpha * acc (+ LayerNorm fold) + bias + rowvec (+ GELU) for quad q of fragment (a, b) -> v[0..3]
     auto head = [&](int a, int q, int n, float (&v)[4]) {
@@ -404,6 +462,13 @@ __device__ __forceinline__ void epilogue_by_fragment(const avsd_gemm_desc& p, f3
     for (int a = 0; a < FN; ++a) {
       const int nb = n_base + a * 32;  // first packed column of this fragment
       if (nb >= p.N) continue;
+      if constexpr (EX == EPI_SHUF) {       // this fragment's parity moves it `radd` output rows down and to channel `ob` of its pixel
+        int radd, ob;
+        shuf_col(p, nb, radd, ob);
+        const int64_t mo = shuf_row(p, m) + radd;
+        orow = bz * p.batch_stride_out + mo * p.ldc + (ob - nb);
+        mrow = p.out_master ? p.out_master + bz * p.batch_stride_out + mo * p.ldm + (ob - nb) : nullptr;
+      }
       // 16-bit output, fragment fully inside N, 16-byte-aligned rows: the two lanes that share a row (l, l ^ 32) trade
       // halves with v_permlane32_swap so each stores (and reads 16-bit residuals as) 32 contiguous bytes — two dwordx4
       // per fragment instead of four dwordx2 scattered 8 bytes apart (store issue, not bandwidth, bounds this tail).
@@ -463,6 +528,22 @@ __device__ __forceinline__ void epilogue_by_fragment(const avsd_gemm_desc& p, f3
         h16_t* op = reinterpret_cast<h16_t*>(p.out) + orow + ncol;
         *reinterpret_cast<uint4*>(op) = make_uint4(x[0][0], x[0][1], x[1][0], x[1][1]);
         *reinterpret_cast<uint4*>(op + 8) = make_uint4(y[0][0], y[0][1], y[1][0], y[1][1]);
+        if constexpr (EX != EPI_PLAIN) {
+          if (epi_rest<EX>(p)) {       // the rest plane of the same 32 bytes: round16(v - main), traded between the two lanes like the main words
+            unsigned xr[2][2], yr[2][2];
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+              const auto e = __builtin_amdgcn_permlane32_swap(rest2h(v[0][2 * d], v[0][2 * d + 1], pack2h(v[0][2 * d], v[0][2 * d + 1])),
+                                                              rest2h(v[2][2 * d], v[2][2 * d + 1], pack2h(v[2][2 * d], v[2][2 * d + 1])), false, false);
+              const auto o = __builtin_amdgcn_permlane32_swap(rest2h(v[1][2 * d], v[1][2 * d + 1], pack2h(v[1][2 * d], v[1][2 * d + 1])),
+                                                              rest2h(v[3][2 * d], v[3][2 * d + 1], pack2h(v[3][2 * d], v[3][2 * d + 1])), false, false);
+              xr[0][d] = e[0]; xr[1][d] = e[1];
+              yr[0][d] = o[0]; yr[1][d] = o[1];
+            }
+            *reinterpret_cast<uint4*>(op + p.out_lo) = make_uint4(xr[0][0], xr[0][1], xr[1][0], xr[1][1]);
+            *reinterpret_cast<uint4*>(op + p.out_lo + 8) = make_uint4(yr[0][0], yr[0][1], yr[1][0], yr[1][1]);
+          }
+        }
         if (rs_out) {
           // (sum, sum of squares) of the 16 rounded values this lane just stored (+ stats_pos), plus the partner lane's 16
           float sm, sq;
@@ -507,6 +588,14 @@ __device__ __forceinline__ void epilogue_by_fragment(const avsd_gemm_desc& p, f3
             st.x = pack2h(v[0], v[1]);
             st.y = pack2h(v[2], v[3]);
             *reinterpret_cast<uint2*>(reinterpret_cast<h16_t*>(p.out) + orow + n) = st;
+            if constexpr (EX != EPI_PLAIN) {
+              if (epi_rest<EX>(p)) {
+                uint2 sr;
+                sr.x = rest2h(v[0], v[1], st.x);
+                sr.y = rest2h(v[2], v[3], st.y);
+                *reinterpret_cast<uint2*>(reinterpret_cast<h16_t*>(p.out) + p.out_lo + orow + n) = sr;
+              }
+            }
           }
         }
       } else {
@@ -556,11 +645,11 @@ __device__ __forceinline__ void epilogue_by_fragment(const avsd_gemm_desc& p, f3
 // (TIGHT: the kernel runs under a reduced register budget — the loader-wave tiles of 768 threads get 168 registers.)
 // mstride: rows between the row fragments of a wave (32: consecutive rows; the 2-D convolution tiles pass the image width —
 // fragment b is the tile's b-th image row).
-template <int FN, int FM, bool TIGHT = false>
+template <int FN, int FM, bool TIGHT = false, int EX = EPI_PLAIN>
 __device__ __forceinline__ void epilogue(const avsd_gemm_desc& p, f32x16 (&acc)[FN][FM], int m_base, int n_base,
                                          int lane, int64_t bz, const float (&pre_ln)[2 * FM], bool have_pre, int mstride = 32) {
-  if constexpr (FN * FM <= (TIGHT ? 2 : 4)) epilogue_by_term<FN, FM>(p, acc, m_base, n_base, lane, bz, pre_ln, have_pre, mstride);
-  else epilogue_by_fragment<FN, FM>(p, acc, m_base, n_base, lane, bz, pre_ln, have_pre, mstride);
+  if constexpr (FN * FM <= (TIGHT ? 2 : 4)) epilogue_by_term<FN, FM, EX>(p, acc, m_base, n_base, lane, bz, pre_ln, have_pre, mstride);
+  else epilogue_by_fragment<FN, FM, EX>(p, acc, m_base, n_base, lane, bz, pre_ln, have_pre, mstride);
 }
 
 // Wave tiles of 8+ fragments whose epilogue the compiler does NOT unroll (hipcc 7.2: "loop not unrolled" on the 5 x 2 and 4 x 2
@@ -569,7 +658,7 @@ __device__ __forceinline__ void epilogue(const avsd_gemm_desc& p, f32x16 (&acc)[
 // resident-convolution tile (tools/resource_usage.py; profiles/r5_resource_usage.txt).  This form hands the shared epilogue ONE fragment
 // at a time with compile-time indices, so every accumulator is consumed from the register it was computed in.  Same terms in the same
 // order per element; the LayerNorm-fold row statistics are folded once per row band and handed to the fragments.
-template <int FN, int FM, bool TIGHT = false>
+template <int FN, int FM, bool TIGHT = false, int EX = EPI_PLAIN>
 __device__ __forceinline__ void epilogue_each(const avsd_gemm_desc& p, f32x16 (&acc)[FN][FM], int m_base, int n_base, int lane, int64_t bz,
                                               const float (&pre_ln)[2 * FM], bool have_pre, int mstride = 32) {
   const bool lnfuse = (p.flags & AVSD_GEMM_LNFUSE) != 0;
@@ -588,15 +677,16 @@ __device__ __forceinline__ void epilogue_each(const avsd_gemm_desc& p, f32x16 (&
       __builtin_amdgcn_sched_barrier(0);          // fragments are independent: keep each one's loads and stores together
       f32x16 one[1][1];
       one[0][0] = acc[A][B];
-      epilogue<1, 1, TIGHT>(p, one, m_base + B * mstride, n_base + 32 * A, lane, bz, pl, lnfuse, mstride);
+      epilogue<1, 1, TIGHT, EX>(p, one, m_base + B * mstride, n_base + 32 * A, lane, bz, pl, lnfuse, mstride);
     });
   });
 }
 
 // ---- AVSD_GEMM_X2 epilogue: same terms and f32 order as above; 16-bit residuals are read as main + rest, the result is
-// written as main = round16(v), rest = round16(v - main); LayerNorm row statistics are taken from main + rest (what the
-// consumer reconstructs).  Fragment-at-a-time, 8-byte stores (the precise tier trades the wide-store form for one code path).
-template <int FN, int FM>
+// written as main = round16(v), rest = round16(v - main) (+ the un-rounded f32 value to `out_master`: the three-pass products of
+// the per-layer precision plan feed a residual add AND another three-pass product); LayerNorm row statistics are taken from
+// main + rest (what the consumer reconstructs).  SHUF: the per-pixel output scatter of AVSD_GEMM_CONV3 with ups = 2 (see EPI_SHUF).  Fragment-at-a-time, 8-byte stores (the precise tier trades the wide-store form for one code path).
+template <int FN, int FM, bool SHUF = false>
 __device__ __forceinline__ void epilogue_x2(const avsd_gemm_desc& p, f32x16 (&acc)[FN][FM], int m_base, int n_base,
                                             int lane, int64_t bz, const float (&pre_ln)[2 * FM], bool have_pre) {
   const int frow = lane & 31;
@@ -622,7 +712,8 @@ __device__ __forceinline__ void epilogue_x2(const avsd_gemm_desc& p, f32x16 (&ac
       else ln_row_stats(p, m, bz, ln_rstd, ln_mr);
     }
     float2* rs_out = rowstats ? reinterpret_cast<float2*>(p.rowstats) + ((int64_t)bz * p.M + m) * (p.N >> 5) : nullptr;
-    const int64_t orow = bo + (int64_t)m * p.ldc;
+    int64_t orow = bo + (int64_t)m * p.ldc;
+    float* mrow = p.out_master ? p.out_master + bo + (int64_t)m * p.ldm : nullptr;
     auto head = [&](int a, int q, int n, float (&v)[4]) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] = p.alpha * acc[a][b][4 * q + i];
@@ -667,6 +758,13 @@ __device__ __forceinline__ void epilogue_x2(const avsd_gemm_desc& p, f32x16 (&ac
     for (int a = 0; a < FN; ++a) {
       const int nb = n_base + a * 32;
       if (nb >= p.N) continue;
+      if constexpr (SHUF) {
+        int radd, ob;
+        shuf_col(p, nb, radd, ob);
+        const int64_t mo = shuf_row(p, m) + radd;
+        orow = bo + mo * p.ldc + (ob - nb);
+        mrow = p.out_master ? p.out_master + bo + mo * p.ldm + (ob - nb) : nullptr;
+      }
       if (!geglu) {
         float sm = 0.f, sq = 0.f;
 #pragma unroll
@@ -681,6 +779,7 @@ __device__ __forceinline__ void epilogue_x2(const avsd_gemm_desc& p, f32x16 (&ac
           }
           if (R1) add_res(R1, p.res1_lo, p.ldr1, r1f, n, v);
           if (R2) add_res(R2, p.res2_lo, p.ldr2, r2f, n, v);
+          if (mrow) *reinterpret_cast<float4*>(mrow + n) = make_float4(v[0], v[1], v[2], v[3]);
           if (out_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow + n) = make_float4(v[0], v[1], v[2], v[3]);
           else store4(orow + n, v, sm, sq);
         }

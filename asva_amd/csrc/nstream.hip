@@ -12,13 +12,15 @@
 //   * W never touches LDS: it is stored in MFMA-fragment order (AVSD_GEMM_W_FRAG: [N / 32][K / 16][64 lanes][8 values], packed once
 //     with the weights), so a wave's operand of one k-step is ONE coalesced 1-KB load straight into the registers the MFMA reads,
 //     prefetched D k-steps ahead through a register ring that runs on across fragment boundaries — no prologue per fragment;
-//   * two waves share a SIMD and drift half a fragment apart (the second four start late on purpose): while one drains its
+//   * two waves share a SIMD and drift apart on their own (nothing staggers them): while one drains its
 //     accumulators through the epilogue (LayerNorm fold, bias, GEGLU's erf, 16-bit stores — VALU and memory), the other owns the
 //     MFMA pipe.  No barrier, no LDS traffic besides the A fragment reads (3 ds_read_b128 per 3 MFMAs per wave).
 // The epilogue is the shared one (gemm_common.h): same terms, same f32 order per element as every other tile; K is summed in
-// ascending order, so results are bit-identical to the LDS-direct tiles.  The LayerNorm statistics of a wave's rows are folded once
+// ascending order, so results are bit-identical to the LDS-direct tiles on their UNROTATED walk (this tile ignores AVSD_GEMM_KROT).  The LayerNorm statistics of a wave's rows are folded once
 // per launch (the rows never change), from the producer's K / 32 partial pairs — no avsd_ln_fold launch in front of it.
-// PLAIN single-source descriptors, K = 320 or 640, N % 32 == 0, no split-K, no AVSD_GEMM_X2.
+// PLAIN single-source descriptors, K = 320 or 640, N % 32 == 0, no split-K, no AVSD_GEMM_X2.  Wave w owns fragments w, w + 8, ...: with
+// fewer than 8 fragments (N < 256) or N / 32 not a multiple of 8 some waves simply run fewer (or no) fragments — correct, just not what the
+// tile is for; the host rule (ops.nstream_supported) only picks it at N >= 4 K, N % 256 == 0.
 #include "gemm_common.h"
 
 #ifdef NS_STAMPS     // probe build (tools/nstream_probe.py --stamps): cycle stamps of 4 workgroups x 8 waves x (start, per fragment: loop start / loop end / epilogue end)

@@ -54,16 +54,20 @@ def set_precision(name: str) -> None:
 # three-pass split products: their A operand is split into (main, rest) planes from the f32 master of the stream, their weights are
 # packed as two planes, their result is written in f32.
 PLAN = None
+_BEFORE_PLAN = None       # (NAME, SPLIT) at the time the plan was switched on: what set_plan(False) returns to
 PLAN_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "precision_plan.json")
 
 
 def set_plan(on=True, path=None) -> None:
     """switches the per-layer precision plan on (fp16 storage + f32 residual stream + the plan's three-pass products) or off
-    (back to bf16); models are repacked on next use"""
-    global PLAN
+    (back to the storage mode that was active before it); models are repacked on next use"""
+    global PLAN, _BEFORE_PLAN
     if not on:
+        if PLAN is not None and _BEFORE_PLAN is not None:      # back to the storage mode that was active when the plan was switched on
+            set_precision(_BEFORE_PLAN[0])
+            set_split(_BEFORE_PLAN[1])
         PLAN = None
-        set_precision("bf16")
+        _BEFORE_PLAN = None
         return
     import json
 
@@ -75,6 +79,8 @@ def set_plan(on=True, path=None) -> None:
     unknown = {e.split("@")[0] for e in plan["three_pass"]} - {"conv_in", "conv_out", "shortcut", "shortcut_temp", "sampler", "sampler_temp"}
     if unknown:
         raise ValueError(f"precision plan: three-pass kinds {sorted(unknown)} are not built (asva_amd/unet.py _ffconv)")
+    if PLAN is None:
+        _BEFORE_PLAN = (NAME, SPLIT)
     set_split(False)
     set_precision("fp16")
     PLAN = {"three_pass": frozenset(plan["three_pass"]), "name": plan.get("name", "plan")}

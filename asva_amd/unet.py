@@ -24,7 +24,7 @@ from . import precision as P
 
 from . import ops
 from .conditioning import mask_to_key_index
-from .weights import from_act, is_twin, pack_conv1x1, pack_conv3x3, pack_frag, pack_geglu, pack_linear, rest_of, to_act, to_planes
+from .weights import from_act, is_twin, pack_conv1x1, pack_conv3x3, pack_frag, pack_geglu, pack_linear, rest_of, subpixel_conv3x3, to_act, to_planes
 
 CONFIG_NAME = "config.json"
 SAFETENSORS_NAME = "diffusion_pytorch_model.safetensors"
@@ -55,11 +55,15 @@ _LN_PREFOLD = True
 # per branch on its torch.cat'ed batch).  14 launches run on half (a third) of the rows.
 _SHARE_PREFIX = True
 _F32_CONV_Y = True      # with the f32 residual stream: also the conv output inside FFInflatedConv3d
+# nearest-2x upsample + 3x3 convolution (FFSpatioTempResUpsample3D) as four 2x2 convolutions on the original image, one per output-pixel
+# parity (weights.subpixel_conv3x3): the same function with 4/9 of the multiplies — 0.41 of the step's 5.4 TFLOP become 0.18
+_SUBPIXEL_UPS = os.environ.get("AVSD_SUBPIXEL_UPS", "1") != "0"
 
 
 def _replicate(a: "_Act", r: int) -> "_Act":
     """rows of all branches = r copies of the shared rows, branch-major like torch.cat([latents] * r) (pure data movement)"""
-    return _Act(ops.copy(a.lo, rep=r), None if a.hi is None else ops.copy(a.hi, rep=r))     # (ops.copy moves both planes of a split tensor)
+    return _Act(ops.copy(a.lo, rep=r), None if a.hi is None else ops.copy(a.hi, rep=r),     # (ops.copy moves both planes of a split tensor)
+                None if a.rest is None else ops.copy(a.rest, rep=r))
 
 
 def _xa_fill(kv: torch.Tensor, n_kv: int, rows: int, C: int, idx: Optional[torch.Tensor], old=None):
@@ -321,7 +325,7 @@ class Packer:
     def aff(self, m: _Affine):
         return _Pk(g=self.reg(m.weight.detach().float()), b=self.reg(m.bias.detach().float()))
 
-    def ffconv(self, m: _FFConv, kind: Optional[str] = None, where: Optional[str] = None):
+    def ffconv(self, m: _FFConv, kind: Optional[str] = None, where: Optional[str] = None, subpixel: bool = False):
         """kind: "conv_in" / "conv_out" / "shortcut" / "sampler" (None: the 3x3 convolutions inside a ResBlock) — under the per-layer
         precision plan (precision.py) the spatial convolution of a listed kind and / or its temporal mix ("<kind>_temp"; conv_in and
         conv_out as a whole) also get the REST planes of their weights: w_r / wt_r, the second operand plane of a three-pass product"""
@@ -333,10 +337,12 @@ class Packer:
         whole = kind in ("conv_in", "conv_out")
         x3 = kind is not None and P.three_pass(kind, where)
         x3t = kind is not None and P.three_pass(kind if whole else kind + "_temp", where)
+        subpixel = subpixel and m.kernel == 3 and cip % 64 == 0 and cop % 64 == 0       # (the kernel wants whole 64-channel K tiles per tap and whole column tiles per parity)
         if m.kernel == 3:
             wf = torch.zeros((cop, 3, 3, cip), dtype=torch.float32, device=w.device)
             wf[:cout, :, :, :cin] = w.permute(0, 2, 3, 1)
-            wf = wf.reshape(cop, 9 * cip)
+            # an upsampler's convolution: [4 cop, 4 cip], one 2x2 kernel per output-pixel parity (the bias repeats per parity below)
+            wf = subpixel_conv3x3(wf) if subpixel else wf.reshape(cop, 9 * cip)
         else:
             wf = torch.zeros(cop, cip, device=w.device)
             wf[:cout, :cin] = w.reshape(cout, cin)
@@ -347,7 +353,7 @@ class Packer:
         wt = wt.reshape(cop, 3 * cop)
         bt = torch.zeros(cop, device=w.device)
         bt[:cout] = m.conv_temp.bias.detach().float()
-        p = _Pk(b=reg(b), bt=reg(bt), cout=cop, cin=cip, k=m.kernel, w_r=None, wt_r=None)
+        p = _Pk(b=reg(b.repeat(4) if subpixel else b), bt=reg(bt), cout=cop, cin=cip, k=m.kernel, w_r=None, wt_r=None, subpixel=subpixel)
         if x3:
             wm, wr = to_planes(wf)
             p.w, p.w_r = reg(wm), reg(wr)
@@ -421,8 +427,10 @@ class Packer:
                 pos1=self.lin(b.pos_embedding_temp.linear_1), pos2=self.lin(b.pos_embedding_temp.linear_2),
                 norm3=self.aff(b.norm3), w1=reg(w1), b1=reg(b1), ff2=self.lin(b.ff.net[2]),
                 dim=m.proj_in.weight.shape[0], audio=hasattr(b, "attn_audio"))
-        if w1_ln.shape[1] in (320, 640) and not is_twin(w1_ln):
-            # the same weights in MFMA-fragment order for the A-resident N-streaming tile (csrc/nstream.hip; ops.nstream_supported)
+        if w1_ln.shape[1] in (320, 640) and not P.SPLIT:
+            # the same weights in MFMA-fragment order for the A-resident N-streaming tile (csrc/nstream.hip; ops.nstream_supported).
+            # Decided by the MODE, not by the tensor: a layout-only (meta) replica must register the same items as the rank that holds
+            # the weights, or the two blobs differ in size and offsets (asva_amd.dist.broadcast_blob)
             p.w1_ln_f = reg(pack_frag(w1_ln))
         if p.audio:
             p.norm_audio = self.aff(b.norm_audio)
@@ -434,7 +442,7 @@ class Packer:
         return _Pk(resnets=[self.res(r, where) for r in m.resnets],
                    attentions=[self.tr(a) for a in m.attentions] if hasattr(m, "attentions") else None,
                    down=self.ffconv(m.downsamplers[0].conv, "sampler", where) if hasattr(m, "downsamplers") else None,
-                   up=self.ffconv(m.upsamplers[0].conv, "sampler", where) if hasattr(m, "upsamplers") else None)
+                   up=self.ffconv(m.upsamplers[0].conv, "sampler", where, subpixel=_SUBPIXEL_UPS) if hasattr(m, "upsamplers") else None)
 
     def finish(self, pk: _Pk, device, meta: bool = False) -> _Pk:
         """Adds the concatenated time_emb_proj matrix of every ResBlock registered so far, lays all items out in one
@@ -479,6 +487,7 @@ class Packer:
         pk.act_dtype = P.ACT
         pk.split = P.SPLIT
         pk.plan = P.plan_key()
+        pk.subpixel = _SUBPIXEL_UPS
         return pk
 
 
@@ -752,7 +761,8 @@ class AudioUNet3DConditionModel(nn.Module):
             if device.type == "cuda" and device.index is None:
                 device = torch.device("cuda", torch.cuda.current_device())
         if (self._packed is not None and self._packed.act_dtype == P.ACT and getattr(self._packed, "split", False) == P.SPLIT
-                and getattr(self._packed, "plan", None) == P.plan_key() and (device is None or self._packed.blob.device == device)):
+                and getattr(self._packed, "plan", None) == P.plan_key() and getattr(self._packed, "subpixel", None) == _SUBPIXEL_UPS
+                and (device is None or self._packed.blob.device == device)):
             return self._packed
         device = device if device is not None else self.device
         if device.type == "meta":
@@ -985,32 +995,35 @@ class AudioUNet3DConditionModel(nn.Module):
         else:
             h = _Act(ops.ncfhw_to_rows(x32, cpad=pk.conv_in.cin, rep=rep // pre))
         hw = (H, W)
-        h = _ffconv(st, h, pk.conv_in, hw)
+        # per-layer precision plan: the tensors a three-pass product reads as (main, rest) planes — every skip and every input of a ResBlock
+        # with a shortcut convolution, of a sampler and of conv_norm_out / conv_out — get their rest plane from the epilogue that produces them
+        pr = P.PLAN is not None
+        h = _ffconv(st, h, pk.conv_in, hw, rest=pr)
         skips = [h]
         for i, blk in enumerate(pk.down):
             for j, r in enumerate(blk.resnets):
-                h = _resblock(st, h, None, r, hw)
+                h = _resblock(st, h, None, r, hw, rest=pr and not blk.attentions)
                 if blk.attentions:
-                    h = _transformer(st, h, blk.attentions[j], hw, st.heads[i], split=pre)
+                    h = _transformer(st, h, blk.attentions[j], hw, st.heads[i], split=pre, rest=pr)
                     if pre > 1:                    # the transformer left st.B at the full batch; the shared skip follows
                         skips[0] = _replicate(skips[0], pre)
                         pre = 1
                 skips.append(h)
             if blk.down is not None:
-                h = _ffconv(st, h, blk.down, hw, stride=2)
+                h = _ffconv(st, h, blk.down, hw, stride=2, rest=pr)
                 hw = (hw[0] // 2, hw[1] // 2)
                 skips.append(h)
         h = _resblock(st, h, None, pk.mid.resnets[0], hw)
         h = _transformer(st, h, pk.mid.attentions[0], hw, st.heads[-1])
-        h = _resblock(st, h, None, pk.mid.resnets[1], hw)
+        h = _resblock(st, h, None, pk.mid.resnets[1], hw, rest=pr)
         rheads = st.heads[::-1]
         for i, blk in enumerate(pk.up):
             for j, r in enumerate(blk.resnets):
-                h = _resblock(st, h, skips.pop(), r, hw)
+                h = _resblock(st, h, skips.pop(), r, hw, rest=pr and not blk.attentions)
                 if blk.attentions:
-                    h = _transformer(st, h, blk.attentions[j], hw, rheads[i])
+                    h = _transformer(st, h, blk.attentions[j], hw, rheads[i], rest=pr)
             if blk.up is not None:
-                h = _ffconv(st, h, blk.up, hw, ups=1)
+                h = _ffconv(st, h, blk.up, hw, ups=1, rest=pr)
                 hw = (hw[0] * 2, hw[1] * 2)
         rows_b = Fr * hw[0] * hw[1]
         if pk.conv_out.w_r is not None:      # precision plan: conv_norm_out -> conv_out on two planes
@@ -1029,7 +1042,9 @@ def _master(st, like: torch.Tensor, cols: int):
 # FFInflatedConv3d (utils.py:34-57): conv GEMM, then the temporal-mix GEMM whose epilogue also adds the
 # time embedding (resnet :173) and the residual / shortcut (resnet :189)
 def _ffconv(st, x: _Act, p, hw, stride=1, ups=0, temb=None, res: Optional[_Act] = None, out_f32=False,
-            x2: Optional[_Act] = None, master=True) -> _Act:
+            x2: Optional[_Act] = None, master=True, rest=False) -> _Act:
+    """rest: (per-layer precision plan) the result feeds a three-pass product — its producer writes the rest plane of the 16-bit copy
+    too (AVSD_GEMM_OUT_REST), so no avsd_split_f32 pass over the f32 master is needed later"""
     n_img = st.B * st.F
     if p.k == 3:
         ho = ((hw[0] << ups) + 2 - 3) // stride + 1
@@ -1038,48 +1053,57 @@ def _ffconv(st, x: _Act, p, hw, stride=1, ups=0, temb=None, res: Optional[_Act] 
     else:
         ho, wo = hw
         rows = x.lo.shape[0]
+    dev = x.lo.device
     # f32 residual stream: the conv output y is itself a residual term (out = y + conv_temp(...), utils.py:53) — keep its
     # un-rounded copy for that addition; the 16-bit copy feeds the temporal-mix product
     x3, x3t = getattr(p, "w_r", None) is not None, getattr(p, "wt_r", None) is not None     # three-pass products of the precision plan
-    ym = torch.empty((rows, p.cout), dtype=torch.float32, device=x.lo.device) if (st.f32_stream and _F32_CONV_Y and not x3) else None
+    if ups and getattr(p, "subpixel", False):
+        ups = 2           # the packed weights are the four per-parity 2x2 kernels (weights.subpixel_conv3x3): AVSD_GEMM_CONV3 with ups = 2
+    ym = torch.empty((rows, p.cout), dtype=torch.float32, device=dev) if (st.f32_stream and _F32_CONV_Y) or x3 or x3t else None
     yr = None
     if x3:
-        # three MFMA passes on (main, rest) planes of the input and of the weights, f32 result; its planes feed the temporal mix
+        # three MFMA passes on (main, rest) planes of the input and of the weights; ONE launch writes the f32 result (a residual term of the
+        # temporal mix) and its (main, rest) planes (the temporal mix's A operand)
         xm, xr = x.planes()
+        y, yr = ops.alloc_planes((rows, p.cout), dev)
         if p.k == 3:
-            ym = ops.gemm(xm, p.w, bias=p.b, mode=ops.CONV3, conv=(n_img, hw[0], hw[1], stride, ups), out_f32=True, a_rest=xr, w_rest=p.w_r)
+            ops.gemm(xm, p.w, bias=p.b, mode=ops.CONV3, conv=(n_img, hw[0], hw[1], stride, ups), out=y, out_rest=yr, master=ym, a_rest=xr, w_rest=p.w_r)
         else:
             x2m, x2r = (None, None) if x2 is None else x2.planes()
-            ym = ops.gemm(xm, p.w, a2=x2m, bias=p.b, out_f32=True, a_rest=xr, a2_rest=x2r, w_rest=p.w_r)
-        y, yr = ops.split_planes(ym)
-    elif p.k == 3:
-        y = ops.gemm(x.lo, p.w, bias=p.b, mode=ops.CONV3, conv=(n_img, hw[0], hw[1], stride, ups), master=ym)
+            ops.gemm(xm, p.w, a2=x2m, bias=p.b, out=y, out_rest=yr, master=ym, a_rest=xr, a2_rest=x2r, w_rest=p.w_r)
     else:
-        y = ops.gemm(x.lo, p.w, a2=None if x2 is None else x2.lo, bias=p.b, master=ym)
+        if x3t:           # one-pass convolution in front of a three-pass temporal mix: the rest plane of y comes out of the same epilogue
+            y, yr = ops.alloc_planes((rows, p.cout), dev)
+        else:
+            y = None
+        if p.k == 3:
+            y = ops.gemm(x.lo, p.w, bias=p.b, mode=ops.CONV3, conv=(n_img, hw[0], hw[1], stride, ups), master=ym, out=y, out_rest=yr)
+        else:
+            y = ops.gemm(x.lo, p.w, a2=None if x2 is None else x2.lo, bias=p.b, master=ym, out=y, out_rest=yr)
     if x3t:
-        if ym is None:
-            raise RuntimeError("a three-pass temporal mix needs the f32 copy of the convolution output (f32 residual stream)")
-        if yr is None:
-            y, yr = ops.split_planes(ym)
         if res is not None and res.hi is None:
             raise RuntimeError("a three-pass temporal mix adds f32 residuals only")
-        outm = ops.gemm(y, p.wt, bias=p.bt, res1=ym, res2=None if res is None else res.hi, rowvec=temb,
-                        rows_per_vec=(st.temb_rows * ho * wo) if temb is not None else 0,
-                        mode=ops.TMIX, tmix=(ho * wo, st.F), out_f32=True, a_rest=yr, w_rest=p.wt_r)
+        kw = dict(bias=p.bt, res1=ym, res2=None if res is None else res.hi, rowvec=temb, rows_per_vec=(st.temb_rows * ho * wo) if temb is not None else 0,
+                  mode=ops.TMIX, tmix=(ho * wo, st.F), a_rest=yr, w_rest=p.wt_r)
         if out_f32:
-            return _Act(outm)
-        o16, o16r = ops.split_planes(outm)
-        return _Act(o16, outm if master else None, o16r)
+            return _Act(ops.gemm(y, p.wt, out_f32=True, **kw))
+        o16, o16r = ops.alloc_planes((rows, p.cout), dev)
+        outm = torch.empty((rows, p.cout), dtype=torch.float32, device=dev) if master else None
+        ops.gemm(y, p.wt, out=o16, out_rest=o16r, master=outm, **kw)
+        return _Act(o16, outm, o16r)
     m = _master(st, y, p.cout) if (master and not out_f32) else None
+    o16 = o16r = None
+    if rest and m is not None:
+        o16, o16r = ops.alloc_planes((rows, p.cout), dev)
     out = ops.gemm(y, p.wt, bias=p.bt, res1=y if ym is None else ym, res2=None if res is None else res.res, rowvec=temb,
                    rows_per_vec=(st.temb_rows * ho * wo) if temb is not None else 0,
-                   mode=ops.TMIX, tmix=(ho * wo, st.F), out_f32=out_f32, master=m)
-    return _Act(out, m)
+                   mode=ops.TMIX, tmix=(ho * wo, st.F), out_f32=out_f32, master=m, out=o16, out_rest=o16r)
+    return _Act(out, m, o16r)
 
 
 # FFSpatioTempResnetBlock3D.forward (ff_spatio_temp_resnet_3d.py:161-191); `skip` is the UNet skip tensor
 # that the reference torch.cat's onto x (unet_3d_blocks.py:358,1038) — never materialised here
-def _resblock(st, x: _Act, skip: Optional[_Act], p, hw) -> _Act:
+def _resblock(st, x: _Act, skip: Optional[_Act], p, hw, rest=False) -> _Act:
     rows_b = st.F * hw[0] * hw[1]
     if p.shortcut is not None:
         # (a three-pass shortcut feeds the block's last residual add only: its f32 result is all that is needed — no plane split behind it)
@@ -1091,12 +1115,12 @@ def _resblock(st, x: _Act, skip: Optional[_Act], p, hw) -> _Act:
     a = ops.groupnorm(x.lo, None if skip is None else skip.lo, st.B, rows_b, st.groups, p.norm1.g, p.norm1.b, st.eps, True)
     h = _ffconv(st, _Act(a), p.conv1, hw, temb=tv, master=False)         # feeds GroupNorm only
     a2 = ops.groupnorm(h.lo, None, st.B, rows_b, st.groups, p.norm2.g, p.norm2.b, st.eps, True)
-    return _ffconv(st, _Act(a2), p.conv2, hw, res=s)
+    return _ffconv(st, _Act(a2), p.conv2, hw, res=s, rest=rest)
 
 
 # FFSpatioAudioTempTransformer3DModel.forward + BasicTransformerBlock.forward
 # (ff_spatio_audio_temp_transformer_3d.py:94-158, :278-373)
-def _transformer(st, x: _Act, p, hw, heads, split: int = 1) -> _Act:
+def _transformer(st, x: _Act, p, hw, heads, split: int = 1, rest=False) -> _Act:
     """split > 1: the rows hold ONE copy of `split` still-identical guidance branches (st.B = shared batch); everything up to
     and including the first-frame attention runs on them, then the stream is replicated and st.B becomes the full batch."""
     B, Fr = st.B, st.F
@@ -1115,15 +1139,18 @@ def _transformer(st, x: _Act, p, hw, heads, split: int = 1) -> _Act:
     stats = [torch.empty((M, C // 32, 2), dtype=torch.float32, device=n.device) for _ in range(2)] if fused else None
     si = 0
 
-    def stream(a, w, bias, res, want_stats=True, stats_pos=None):
+    def stream(a, w, bias, res, want_stats=True, stats_pos=None, rest=False):
         """h' = a . w^T + bias (+ res): a residual-stream update (16-bit copy + optional f32 master + LayerNorm statistics;
-        stats_pos: the statistics are those of h' + pos[frame], for norm_temp)"""
+        stats_pos: the statistics are those of h' + pos[frame], for norm_temp; rest: also the rest plane of the 16-bit copy, _ffconv)"""
         nonlocal si
         m = _master(st, a, w.shape[0])
         if fused and want_stats:
             si ^= 1
             return _Act(ops.gemm(a, w, bias=bias, res1=None if res is None else res.res, rowstats=stats[si], master=m, stats_pos=stats_pos), m)
-        return _Act(ops.gemm(a, w, bias=bias, res1=None if res is None else res.res, master=m), m)
+        o16 = o16r = None
+        if rest and m is not None:
+            o16, o16r = ops.alloc_planes((a.shape[0], w.shape[0]), a.device)
+        return _Act(ops.gemm(a, w, bias=bias, res1=None if res is None else res.res, master=m, out=o16, out_rest=o16r), m, o16r)
 
     def cross(h, a, norm, xa, want_stats, unfused, stats_pos=None):
         """h + to_out(attention(LN(h) Wq, cached K, V)): one launch where the fused kernel is built, else q-proj + attention
@@ -1212,7 +1239,7 @@ def _transformer(st, x: _Act, p, hw, heads, split: int = 1) -> _Act:
     else:
         g = ops.gemm(ops.layernorm(h.lo, p.norm3.g, p.norm3.b), p.w1, bias=p.b1, geglu=True)
     h = stream(g, p.ff2.w, p.ff2.b, h, want_stats=False)
-    return stream(h.lo, p.proj_out.w, p.proj_out.b, x, want_stats=False)
+    return stream(h.lo, p.proj_out.w, p.proj_out.b, x, want_stats=False, rest=rest)
 
 
 # the verdict / tests address the block functions through the model class

@@ -84,6 +84,28 @@ def pack_conv3x3(w: torch.Tensor, cin_pad: int | None = None, cout_pad: int | No
     return to_act(p.reshape(cout_pad, 9 * cin_pad))
 
 
+def subpixel_conv3x3(wf: torch.Tensor) -> torch.Tensor:
+    """3x3 pad-1 convolution behind a nearest 2x upsample (FFSpatioTempResUpsample3D, ff_spatio_temp_resnet_3d.py:48-55) as FOUR 2x2
+    convolutions on the ORIGINAL image, one per output-pixel parity (dy, dx): output pixel (2y + dy, 2x + dx) of the upsampled
+    convolution sees input rows y + dy - 1 and y + dy (columns likewise), because upsampled row 2y + dy + ky - 1 is input row
+    y + ((dy + ky - 1) >> 1) — so the 3 kernel rows fold onto 2 input rows with summed weights: dy = 0: {w0 | w1 + w2}, dy = 1:
+    {w0 + w1 | w2}.  Exactly the same function (the sums are formed in f32 before the one rounding to storage), 4/9 of the multiplies.
+    wf [cout, 3, 3, cin] f32 (kernel layout, channels last) -> [4 * cout, 2 * 2 * cin]: row (2 dy + dx) * cout + co, column
+    (2 i + j) * cin + ci = the weight of input pixel (y + dy - 1 + i, x + dx - 1 + j) (AVSD_GEMM_CONV3 with ups = 2, include/avsd.h)."""
+    cout, kh, kw, cin = wf.shape
+    assert kh == 3 and kw == 3
+    sets = (((0,), (1, 2)), ((0, 1), (2,)))            # sets[d][i]: kernel rows (columns) that land on input row (column) offset d - 1 + i
+    out = torch.zeros((2, 2, cout, 2, 2, cin), dtype=torch.float32, device=wf.device)
+    for dy in range(2):
+        for dx in range(2):
+            for i in range(2):
+                for j in range(2):
+                    for ky in sets[dy][i]:
+                        for kx in sets[dx][j]:
+                            out[dy, dx, :, i, j, :] += wf[:, ky, kx, :]
+    return out.reshape(4 * cout, 4 * cin)
+
+
 def geglu_row_order(nh: int) -> torch.Tensor:
     """Packed row r of a GEGLU projection with nh output features reads source row order[r]."""
     assert nh % 16 == 0, "GEGLU packing needs the inner dim to be a multiple of 16"

@@ -309,7 +309,7 @@ def main():
     ms_per_step = max_wall / a.steps * 1e3
     out = {
         "metric": "UNet denoising steps/sec, 12x256x256 bf16, CFG on",
-        "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "world_size_rccl": world_observed,
+        "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "world_size": world_observed,
         "dist_backend": (tdist.get_backend() if tdist.is_initialized() else None), "ranks_share_one_gpu": bool(adist.same_device() and world > 1),
         "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -338,30 +338,39 @@ def main():
                              "workload": f"SD1.5 AutoencoderKL decoder, {12 * cpg} x (4,32,32) latents -> uint8 256x256 frames, "
                                          f"{vae_reps} reps, random-init weights; 7.47 TFLOP and >= 6.4 GB per 12-frame clip (SURVEY 8d)"}
 
-    def roofline_of(latents_, clips):
+    def roofline_of(latents_, clips, model=None, n_branch=2):
         """instrumented eager forward (one forward = `clips` steps) -> (roofline dict of the GEMM family, per-family table).
         Every family's time is the GPU time of its launches of that forward re-issued back to back from ONE captured graph —
         the clock of a rocprofv3 trace of the graph-replayed step; the per-launch event pairs of the eager pass (each carries
-        ~4 us of command-processor time) are kept beside it as `ms_event_pairs`."""
+        ~4 us of command-processor time) are kept beside it as `ms_event_pairs`.
+        `achieved` counts the multiply-adds the launches EXECUTE at one pass per product (2 M N K of each launch: the sub-pixel
+        upsample convolutions at their 4 taps, a three-pass product of the precision plan once) — the MFMA work a one-pass bf16
+        reference of the same algorithm would need; `achieved_reference_algorithm` prices the same launches as the reference states
+        them (3x3 taps on the upsampled image), `achieved_mfma_issued` counts every MFMA pass issued (three-pass products x 3)."""
         timer = ops.KernelTimer()
         ops.set_timer(timer)
-        unet.denoise_forward(latents_, torch.full((1,), 501.0, device=device), rep=2)
+        (model or unet).denoise_forward(latents_, torch.full((1,), 501.0, device=device), rep=n_branch)
         ops.set_timer(None)
         fam = timer.summary()
         gemm_fams = tuple(k for k in ("gemm_plain", "gemm_tmix", "gemm_conv3") if k in fam)
         mm = [fam[k] for k in gemm_fams]
         ms_events = sum(f["ms"] for f in mm)
-        fl = sum(f["flops"] for f in mm)
+        fl_issued = sum(f["flops"] for f in mm)
+        fl_ref = sum(f["flops_ref"] for f in mm)
+        fl = sum(f.get("flops_once", f["flops"]) for f in mm)
         launches = sum(f["launches"] for f in mm)
         fam_ms = {k: (timer.replay_ms((k,)) if not a.no_graph else v["ms"]) for k, v in fam.items()}
         ms = timer.replay_ms(gemm_fams) if not a.no_graph else ms_events
         ach = fl / (ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "GEMM family: gemm4_kernel (hand-scheduled tiles) / gemm2_kernel<BM,BN,...,MODE> (linear / temporal-mix / strided conv3x3 implicit GEMM) + conv3r_kernel (conv3x3, input tile resident in LDS) + nstream_kernel (GEGLU projections, A band resident), split-K reduce launches included",
+        roof = {"bound": "mfma", "kernel": "GEMM family: gemm4_kernel (hand-scheduled tiles) / gemm2_kernel<BM,BN,...,MODE> (linear / temporal-mix / strided and sub-pixel-upsample conv3x3 implicit GEMM) + conv3r_kernel (conv3x3, input tile resident in LDS) + nstream_kernel (GEGLU projections, A band resident), split-K reduce launches included",
                 "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                "achieved_reference_algorithm": round(fl_ref / (ms * 1e-3) / 1e12, 2), "frac_reference_algorithm": round(fl_ref / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                "achieved_mfma_issued": round(fl_issued / (ms * 1e-3) / 1e12, 2), "frac_mfma_issued": round(fl_issued / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                 "traffic": None, "launches_per_step": launches // clips, "clips_per_forward": clips, "ms_per_step": round(ms / clips, 4),
                 "ms_per_forward": round(ms, 4), "ms_per_step_event_pairs": round(ms_events / clips, 4),
                 "family_ms_sum": round(sum(fam_ms[k] for k in gemm_fams) / clips, 4),
                 "avg_launch_us": round(ms * 1e3 / launches, 2), "tflop_per_step": round(fl / clips / 1e12, 4),
+                "tflop_per_step_reference_algorithm": round(fl_ref / clips / 1e12, 4), "tflop_per_step_mfma_issued": round(fl_issued / clips / 1e12, 4),
                 "algorithmic_bytes_per_launch": round(sum(f["bytes"] for f in mm) / launches)}
         table = {k: {"launches": v["launches"], "ms": round(fam_ms[k], 4), "ms_event_pairs": round(v["ms"], 4),
                      "tflops": round(v["flops"] / (fam_ms[k] * 1e-3) / 1e12, 2) if v["flops"] else None,
@@ -427,7 +436,7 @@ def main():
         #   precise_split  every tensor two bf16 planes, every product three MFMA passes (round 3's mode): 40x inside the tolerance
         from asva_amd import precision as P
 
-        def precise_leg(enter, leave, mode, passes):
+        def precise_leg(enter, leave, mode, passes, roofline=False, mode_id=""):
             enter()
             try:
                 unet._invalidate()
@@ -445,13 +454,18 @@ def main():
                 torch.cuda.synchronize()
                 tp = time.perf_counter() - tp
                 rel = precise_rel_l2(device)
-                row = {"mode": mode, "value": round(kp / tp, 3), "unit": "steps/s", "ms_per_step": round(tp / kp * 1e3, 4), "steps": kp,
+                row = {"mode_id": mode_id, "mode": mode, "value": round(kp / tp, 3), "unit": "steps/s", "ms_per_step": round(tp / kp * 1e3, 4), "steps": kp,
                        "all_finite": bool(torch.isfinite(lp).all()),
                        "rel_l2": rel, "rel_l2_tolerance": 1e-3, "rel_l2_ok": bool(rel < 1e-3),
                        "rel_l2_of": "one CFG forward (2,4,12,32,32), filler weights, vs the REFERENCE's fp32 output "
                                     "(tests/golden/unet_sd15_forward.pt), measured in this run"}
                 if passes:
                     row["mfma_frac_of_3x_work"] = round(passes * ALGORITHMIC_TFLOP_PER_STEP / (tp / kp) / PEAK_BF16_TFLOPS, 4)
+                row["step_tflops"] = round(ALGORITHMIC_TFLOP_PER_STEP / (tp / kp), 2)
+                row["step_mfma_frac"] = round(ALGORITHMIC_TFLOP_PER_STEP / (tp / kp) / PEAK_BF16_TFLOPS, 4)
+                if roofline and not a.no_roofline:
+                    # the same instrumented forward as the headline's, in THIS mode (graph-replay clock per family)
+                    row["roofline"], row["kernel_families"] = roofline_of(lp, 1)
                 del eng_p
                 return row
             finally:
@@ -459,11 +473,14 @@ def main():
                 unet._invalidate()
                 torch.cuda.empty_cache()
 
+        # (`precise` has been the per-layer plan since round 5 — rounds 3-4 printed split precision under that key; `mode_id` says which)
         out["precise"] = precise_leg(lambda: P.set_plan(True), lambda: P.set_plan(False),
                                      "per-layer precision plan: fp16 storage + f32 residual stream, three-pass split products for "
-                                     + ", ".join(sorted(json.load(open(P.PLAN_PATH))["three_pass"])), 0)
+                                     + ", ".join(sorted(json.load(open(P.PLAN_PATH))["three_pass"])), 0, roofline=True, mode_id="plan")
+        if not out["precise"]["rel_l2_ok"]:
+            out["precise"]["note"] = "OUTSIDE the stated tolerance: not a valid in-tolerance throughput number"
         out["precise_split"] = precise_leg(lambda: P.set_split(True), lambda: P.set_split(False),
-                                           "bf16x2 split precision (main + rest planes, 3-pass MFMA)", 3)
+                                           "bf16x2 split precision (main + rest planes, 3-pass MFMA)", 3, mode_id="split")
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(unet, clip)
         out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)

@@ -33,7 +33,7 @@ extern "C" {
 #define AVSD_ELAUNCH (-2)  /* hipLaunch / runtime error                          */
 #define AVSD_ENODEV (-3)   /* no gfx950 device / wrong architecture              */
 
-#define AVSD_ABI_VERSION 9   /* v9: tile ids 67 (128 x 320 asm tile) and 70 (A-resident N-streaming tile), AVSD_GEMM_W_FRAG */
+#define AVSD_ABI_VERSION 10  /* v10: AVSD_GEMM_OUT_REST, AVSD_GEMM_X2 with out_master; v9: tile ids 67 (128 x 320 asm tile) and 70 (A-resident N-streaming tile), AVSD_GEMM_W_FRAG */
 
 /* ---- library ------------------------------------------------------------------------ */
 int avsd_abi_version(void);
@@ -62,6 +62,16 @@ int avsd_device_info(char* name_host, int len, int* num_cu_host);
  *                    (utils.py:37-38 -> nn.Conv2d): K = 9*cin (tap-major, cin-minor),
  *                    row m = (n, ho, wo); stride 1 or 2; `ups`=1 reads the input through a
  *                    nearest x2 upsample (ff_spatio_temp_resnet_3d.py:48); `pad` = top/left padding.
+ *                    `ups`=2 (v10) is the SUB-PIXEL form of the same upsample + convolution: output pixel (2y + dy, 2x + dx) of the
+ *                    upsampled 3x3 convolution only sees input rows y + dy - 1, y + dy and columns x + dx - 1, x + dx, so it is a 2x2
+ *                    convolution on the ORIGINAL image with the kernel rows / columns that land on the same input pixel summed
+ *                    (asva_amd/weights.py subpixel_conv3x3): the same function with 4/9 of the multiplies.  Descriptor: rows
+ *                    m = (img, y, x) over the INPUT image (ho = hs, wo = ws), K = 4*cin (tap (i, j)-major: input pixel
+ *                    (y + dy - 1 + i, x + dx - 1 + j)), N = 4*cout with column n = (2 dy + dx) * cout + co and W [4*cout][4*cin] likewise
+ *                    (bias [4*cout] = the layer's bias four times); the epilogue stores element (m, n) to channel co of OUTPUT pixel
+ *                    (img, 2y + dy, 2x + dx) of out [n_img*2hs*2ws][ldc] (out_master / the rest plane likewise).  stride 1, pad 1,
+ *                    cin % 64 == 0, cout % 64 == 0 and cout a multiple of the tile's column width; bias only (no residual, row vector,
+ *                    activation, statistics); LDS-direct tiles (4..38), AVSD_GEMM_X2 included.
  *
  * epilogue, in f32:  v = act(alpha*acc + bias[n] + rowvec[(m / rows_per_vec)*ldv + n])
  *                                   + res1[m*ldr1 + n] + res2[m*ldr2 + n]
@@ -83,11 +93,18 @@ int avsd_device_info(char* name_host, int len, int* num_cu_host);
  *   AVSD_GEMM_W_FRAG: W is stored in MFMA-fragment order instead of [N][ldw]: [N / 32][K / 16][64][8] 16-bit values with element
  *                    (f, s, l, e) = W[32 f + (l & 31)][16 s + 8 (l >> 5) + e] (asva_amd/weights.py pack_frag) — one k-step of one 32-column
  *                    fragment is 1 KB, contiguous.  Only tile AVSD_GEMM_TILE_NSTREAM reads it (and refuses anything else); ldw is ignored.
+ *   AVSD_GEMM_OUT_REST: a ONE-pass product whose 16-bit output also gets its rest plane: besides main = round16(v) at `out`, the epilogue
+ *                    stores rest = round16(v - main) at `out + out_lo` elements (same strides) — the (main, rest) pair a three-pass product
+ *                    (AVSD_GEMM_X2) reads as its A operand, written by the producer of the tensor instead of by a separate avsd_split_f32 pass
+ *                    over its f32 master (per-layer precision plan: the ResBlock / transformer outputs that feed the three-pass shortcut and
+ *                    sampler convolutions, ff_spatio_temp_resnet_3d.py:30-62,88-96,159).  16-bit output only, not with GEGLU; LayerNorm row
+ *                    statistics (ROWSTATS) stay those of the main plane, which is what the one-pass consumers read.
  * blockIdx.z batches: pointers advance by batch_stride_* elements (0 = shared).
  */
 enum { AVSD_GEMM_PLAIN = 0, AVSD_GEMM_TMIX = 1, AVSD_GEMM_CONV3 = 2 };
 enum { AVSD_GEMM_GEGLU = 1, AVSD_GEMM_OUT_F32 = 2, AVSD_GEMM_GELU = 4, AVSD_GEMM_XCD_N = 8, AVSD_GEMM_ROWSTATS = 16,
-       AVSD_GEMM_LNFUSE = 32, AVSD_GEMM_RES1_F32 = 64, AVSD_GEMM_RES2_F32 = 128, AVSD_GEMM_X2 = 256, AVSD_GEMM_KROT = 512, AVSD_GEMM_W_FRAG = 1024 };
+       AVSD_GEMM_LNFUSE = 32, AVSD_GEMM_RES1_F32 = 64, AVSD_GEMM_RES2_F32 = 128, AVSD_GEMM_X2 = 256, AVSD_GEMM_KROT = 512, AVSD_GEMM_W_FRAG = 1024,
+       AVSD_GEMM_OUT_REST = 2048 };
 #define AVSD_GEMM_MAX_TILE 33
 #define AVSD_GEMM_MAX_TILE_X2 36   /* AVSD_GEMM_X2 also has tiles 34..36 (gemm.hip dispatch_tile_x2) */
 /* 256 x 160 LDS-direct tile, 8 MFMA + 4 loader waves (gemm.hip dispatch_tile; not with AVSD_GEMM_X2) */
@@ -103,7 +120,7 @@ enum { AVSD_GEMM_GEGLU = 1, AVSD_GEMM_OUT_F32 = 2, AVSD_GEMM_GELU = 4, AVSD_GEMM
 #define AVSD_GEMM_TILE_ASM_LAST 67
 /* A-resident, N-streaming tile (nstream.hip): the workgroup keeps its 96-row band of A (all of K) in LDS and its 8 independent waves
  * stream W fragments straight from memory into MFMA operands — for the wide short-K projections (the GEGLU projection of a transformer
- * block: K = 320 / 640, N = 8 K).  PLAIN single-source descriptors with AVSD_GEMM_W_FRAG, K = 320 or 640, N % 256 == 0; every epilogue
+ * block: K = 320 / 640, N = 8 K).  PLAIN single-source descriptors with AVSD_GEMM_W_FRAG, K = 320 or 640, N % 32 == 0 (built for N % 256 == 0: 8 waves x whole fragments); every epilogue
  * flag except the position tables; no split_k, no AVSD_GEMM_X2. */
 #define AVSD_GEMM_TILE_NSTREAM 70
 #define AVSD_GEMM_TILE_CONV3R_FIRST 40
@@ -165,7 +182,8 @@ typedef struct avsd_gemm_desc {
   /* AVSD_GEMM_X2 (split precision, see "split-precision storage" below): every 16-bit operand is a pair of planes; these are
    * the ELEMENT offsets from each main plane to its rest plane (same strides).  The product is accumulated as
    * W.A + Wr.A + W.Ar (three MFMA passes into one f32 accumulator); 16-bit residuals are read as main + rest and the output
-   * is written as main = round16(v), rest = round16(v - main).  LDS-direct tiles 7, 11, 13, 24, 25, 34, 35, 36 only. */
+   * is written as main = round16(v), rest = round16(v - main) — and, with `out_master`, the un-rounded f32 value as well (v10).
+   * LDS-direct tiles 7, 11, 13, 24, 25, 34, 35, 36 and the asm tiles.  `out_lo` is also the rest-plane offset of AVSD_GEMM_OUT_REST. */
   int64_t a_lo, a2_lo, w_lo, out_lo, res1_lo, res2_lo;
   /* LayerNorm(x + pos[frame]) folded like the plain LayerNorm above (ff_spatio_audio_temp_transformer_3d.py:346-356: norm_temp of
    * h + the temporal position embedding feeds the q|k|v projection of the temporal attention).  Row m belongs to frame

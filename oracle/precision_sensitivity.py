@@ -15,6 +15,11 @@ chosen set as a whole.
 
     python -m oracle.precision_sensitivity --out profiles/r5_precision_sensitivity.json          # ~15 min on 8 cores
     python -m oracle.precision_sensitivity --verify asva_amd/precision_plan.json
+
+Round 6, per OPERAND (`--operand a` / `--operand w`): only the activation operand or only the weight of the group's products is rounded.
+A two-pass product (main.main + rest.main, or main.main + main.rest) removes the rounding of ONE operand for two thirds of the three-pass
+cost; whether that is enough for a group is read off these rows (profiles/r6_precision_sensitivity_operands.json).  `--verify` plans may
+carry "round_a_only" / "round_w_only" lists beside "one_pass" (the operand that stays rounded).
 """
 from __future__ import annotations
 
@@ -86,9 +91,15 @@ class Rounder:
             g = group_of(k)
             if g is not None:
                 self.names[id(v)] = (k, g)
-        self.active: set = set()
+        self.active = set()          # groups whose products see rounded operands: a set (both operands) or {group: "both" | "a" | "w"}
         self.sdpa_level = None
         self.count = {}
+
+    def mode(self, g):
+        """None (exact), or which operand(s) of group g's products are rounded"""
+        if isinstance(self.active, dict):
+            return self.active.get(g)
+        return "both" if g in self.active else None
 
     @staticmethod
     def r16(t):
@@ -111,21 +122,23 @@ class Rounder:
                 if name.endswith("to_q.weight"):          # remember which attention / level the next SDPA belongs to
                     kind = {"attn1_q": "attn1", "audio_q": "audio", "text_q": "text", "temp_qkv": "temp"}[g.split("@")[0]]
                     me.sdpa_level = f"{kind}_sdpa@{g.split('@')[1]}"
-                if g in me.active:
+                md = me.mode(g)
+                if md is not None:
                     me.count[g] = me.count.get(g, 0) + 1
-                    return lin(me.r16(x), me.r16(w), b)
+                    return lin(me.r16(x) if md != "w" else x, me.r16(w) if md != "a" else w, b)
             return lin(x, w, b)
 
         def conv2d(x, w, b=None, **kw):
             hit = me.names.get(id(w))
-            if hit is not None and hit[1] in me.active:
+            md = None if hit is None else me.mode(hit[1])
+            if md is not None:
                 me.count[hit[1]] = me.count.get(hit[1], 0) + 1
-                return conv(me.r16(x), me.r16(w), b, **kw)
+                return conv(me.r16(x) if md != "w" else x, me.r16(w) if md != "a" else w, b, **kw)
             return conv(x, w, b, **kw)
 
         def attention(q, k, v, attn_mask=None):
             g = me.sdpa_level
-            if g in me.active:
+            if me.mode(g) is not None:
                 me.count[g] = me.count.get(g, 0) + 1
                 q, k, v = me.r16(q), me.r16(k), me.r16(v)
                 s = (q @ k.transpose(-1, -2)) * (q.shape[-1] ** -0.5)
@@ -174,6 +187,7 @@ def main():
     ap.add_argument("--verify", default="", help="a plan JSON ({'one_pass': [groups]}): run the whole set at once")
     ap.add_argument("--threads", type=int, default=max(1, (os.cpu_count() or 2) - 2))
     ap.add_argument("--only", default="", help="comma-separated group names (default: all)")
+    ap.add_argument("--operand", default="both", choices=("both", "a", "w"), help="which operand of the group's products is rounded")
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
     sd, cfg, inp, golden = build_inputs()
@@ -186,7 +200,9 @@ def main():
         if a.verify:
             with open(a.verify) as f:
                 plan = json.load(f)
-            rd.active = set(plan["one_pass"])
+            rd.active = {g: "both" for g in plan["one_pass"]}
+            rd.active.update({g: "a" for g in plan.get("round_a_only", ())})
+            rd.active.update({g: "w" for g in plan.get("round_w_only", ())})
             out = unet_ref.unet_forward(sd, cfg, *inp)
             print(json.dumps({"one_pass_groups": len(rd.active), "rel_l2_vs_fp32_oracle": rel(out, ref),
                               "rel_l2_vs_reference_golden": rel(out, golden)}))
@@ -194,14 +210,14 @@ def main():
         groups = rd.groups() if not a.only else a.only.split(",")
         res = {}
         for gname in groups:
-            rd.active, rd.count = {gname}, {}
+            rd.active, rd.count = {gname: a.operand}, {}
             t0 = time.time()
             out = unet_ref.unet_forward(sd, cfg, *inp)
             if not rd.count:
                 continue                     # the model has no product in this group
             res[gname] = {"rel_l2": rel(out, ref), "products": rd.count.get(gname, 0)}
             print(f"{gname:18s} {res[gname]['rel_l2']:.3e}  ({res[gname]['products']} products, {time.time() - t0:.0f} s)", flush=True)
-        rd.active = set(res)
+        rd.active = {g: a.operand for g in res}
         out = unet_ref.unet_forward(sd, cfg, *inp)
         tot = rel(out, ref)
         quad = sum(v["rel_l2"] ** 2 for v in res.values()) ** 0.5
@@ -209,7 +225,7 @@ def main():
         if a.out:
             with open(a.out, "w") as f:
                 json.dump({"what": "rel-L2 of the cfg-2 UNet forward vs the fp32 oracle when ONLY this group's products see fp16-rounded operands "
-                                   "(oracle/precision_sensitivity.py)", "groups": res, "all_groups_one_pass": tot, "quadrature_sum": quad}, f, indent=1)
+                                   "(oracle/precision_sensitivity.py)", "operand": a.operand, "groups": res, "all_groups_one_pass": tot, "quadrature_sum": quad}, f, indent=1)
 
 
 if __name__ == "__main__":

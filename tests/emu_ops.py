@@ -20,9 +20,21 @@ F32 = torch.float32
 
 def gemm(a, w, *, n=None, k=None, a2=None, bias=None, rowvec=None, rows_per_vec=0, res1=None, res2=None, alpha=1.0,
          geglu=False, gelu=False, out_f32=False, out=None, mode=PLAIN, tmix=None, conv=None, m=None, tile=0, split_k=1,
-         rowstats=None, ln=None, master=None, stats_pos=None, ln_pos=None):
+         rowstats=None, ln=None, master=None, stats_pos=None, ln_pos=None, a_rest=None, a2_rest=None, w_rest=None, out_rest=None, w_frag=None):
     assert a.dtype == P.ACT and w.dtype == P.ACT
-    wf = w.float()
+    planes = w_rest is not None       # an explicit three-pass product (per-layer precision plan): operands are main + rest
+    if planes:
+        assert a_rest is not None and (a2 is None) == (a2_rest is None) and out_f32 == (out_rest is None) and not (out_f32 and master is not None)
+        assert all(r is None or r.dtype == F32 for r in (res1, res2))
+        COUNTS["three_pass"] += 1
+    else:
+        assert a_rest is None and a2_rest is None
+    if out_rest is not None:
+        assert out is not None and not out_f32 and not geglu
+    wf = w.float() + (w_rest.float() if planes else 0.0)
+    if planes:
+        a = a.float() + a_rest.float()
+        a2 = None if a2 is None else a2.float() + a2_rest.float()
     if mode == PLAIN:
         x = a.float() if a2 is None else torch.cat([a.float(), a2.float()], 1)
     elif mode == TMIX:
@@ -31,6 +43,8 @@ def gemm(a, w, *, n=None, k=None, a2=None, bias=None, rowvec=None, rows_per_vec=
         y = a.float().reshape(-1, frames, hw, C)
         prev = torch.cat([y[:, :1], y[:, :-1]], 1)
         x = torch.cat([y[:, :1].expand_as(y), prev, y], -1).reshape(-1, 3 * C)
+    elif conv[4] == 2:
+        x = None
     else:
         n_img, hs, ws, stride, ups = conv[:5]
         pad = conv[5] if len(conv) > 5 else 1
@@ -46,8 +60,27 @@ def gemm(a, w, *, n=None, k=None, a2=None, bias=None, rowvec=None, rows_per_vec=
         cols = cols.reshape(n_img, cin * 9, -1, full_w)[:, :, :ho, :wo].reshape(n_img, cin * 9, ho * wo)                      # [n, cin*9, L] (c-major, tap-minor)
         L = cols.shape[-1]
         x = cols.reshape(n_img, cin, 9, L).permute(0, 3, 2, 1).reshape(n_img * L, 9 * cin)   # tap-major, c-minor
-    assert x.shape[1] == wf.shape[1], (x.shape, wf.shape)
-    acc = alpha * (x @ wf.T)
+    if mode == CONV3 and conv[4] == 2:
+        # sub-pixel form of nearest-2x upsample + 3x3 convolution (include/avsd.h, AVSD_GEMM_CONV3 with ups = 2): w [4 cout, 4 cin] holds one
+        # 2x2 kernel per output-pixel parity (dy, dx); output pixel (2y + dy, 2x + dx) reads input pixels (y + dy - 1 + i, x + dx - 1 + j)
+        n_img, hs, ws = conv[:3]
+        cin, cout = a.shape[1], wf.shape[0] // 4
+        assert wf.shape[1] == 4 * cin and a2 is None and rowvec is None and res1 is None and res2 is None and not geglu and not gelu and ln is None
+        xp = F.pad(a.float().reshape(n_img, hs, ws, cin), (0, 0, 1, 1, 1, 1))
+        o = torch.zeros(n_img, 2 * hs, 2 * ws, cout)
+        for dy in range(2):
+            for dx in range(2):
+                taps = torch.cat([xp[:, dy + i:dy + i + hs, dx + j:dx + j + ws] for i in range(2) for j in range(2)], -1).reshape(-1, 4 * cin)
+                par = 2 * dy + dx
+                o[:, dy::2, dx::2] = (taps @ wf[par * cout:(par + 1) * cout].T).reshape(n_img, hs, ws, cout)
+        x = None
+        acc = alpha * o.reshape(-1, cout)
+        if bias is not None:
+            assert torch.equal(bias[:cout], bias[cout:2 * cout])
+            bias = bias[:cout]
+    else:
+        assert x.shape[1] == wf.shape[1], (x.shape, wf.shape)
+        acc = alpha * (x @ wf.T)
     if ln is not None:          # LayerNorm(A) folded in: W carries gamma, bias carries beta . W^T (see avsd.h)
         if ln_pos is not None:  # LayerNorm(A + pos[frame]): pos . W'^T joins the product inside the rstd scaling
             tbl, hw_, fr_ = ln_pos
@@ -81,8 +114,43 @@ def gemm(a, w, *, n=None, k=None, a2=None, bias=None, rowvec=None, rows_per_vec=
         rowstats.copy_(torch.stack([r.sum(-1), (r * r).sum(-1)], -1))
     if out is not None:
         out.copy_(v.to(out.dtype))
+        if out_rest is not None:        # AVSD_GEMM_OUT_REST / the second output plane of a three-pass product
+            out_rest.copy_((v - out.float()).to(out_rest.dtype))
         return out
     return v if out_f32 else v.to(P.ACT)
+
+
+COUNTS = {"three_pass": 0, "split_planes": 0}
+
+
+def alloc_planes(shape, device):
+    buf = torch.empty((2,) + tuple(shape), dtype=P.ACT, device=device)
+    return buf[0], buf[1]
+
+
+def split_planes(x):
+    COUNTS["split_planes"] += 1
+    main = x.to(P.ACT)
+    return main, (x - main.float()).to(P.ACT)
+
+
+def ncfhw_to_rows_planes(x, cpad, rep=1, scale=1.0):
+    B, C, Fr, H, W = x.shape
+    r = (x * scale).permute(0, 2, 3, 4, 1).reshape(-1, C)
+    out = torch.zeros(r.shape[0], cpad)
+    out[:, :C] = r
+    out = out.repeat(rep, 1)
+    main = out.to(P.ACT)
+    return main, (out - main.float()).to(P.ACT)
+
+
+def groupnorm_planes(x1, x1_rest, nb, rows_per_batch, groups, gamma, beta, eps, act):
+    x = x1.float() + x1_rest.float()
+    C = x.shape[1]
+    y = F.group_norm(x.reshape(nb, rows_per_batch, C).permute(0, 2, 1), groups, gamma, beta, eps)
+    y = (F.silu(y) if act else y).permute(0, 2, 1).reshape(-1, C)
+    main = y.to(P.ACT)
+    return main, (y - main.float()).to(P.ACT)
 
 
 def _ln_fold(acc, ln, rows, k):

@@ -27,7 +27,7 @@ def test_header_binding_and_library_agree():
             handle = _lib.lib()                                # raises if the .so is missing or a symbol is absent
             for name in declared:
                 assert hasattr(handle, name)
-            assert handle.avsd_abi_version() == 9
+            assert handle.avsd_abi_version() == 10
             assert handle.avsd_precision() == prec.encode()
             assert handle.avsd_sizeof_gemm_desc() == ctypes.sizeof(_lib.GemmDesc)
         finally:

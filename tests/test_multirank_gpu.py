@@ -33,7 +33,7 @@ def test_bench_two_ranks_on_one_gpu():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, lines                              # rank 0 alone prints
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["world_size_rccl"] == 2 and out["dist_backend"] == "gloo" and out["ranks_share_one_gpu"] is True
+    assert out["n_gpus"] == 2 and out["world_size"] == 2 and out["dist_backend"] == "gloo" and out["ranks_share_one_gpu"] is True
     assert out["ranks_agree_on_witness_clip"] is True and out["all_finite"] is True
     assert len(out["per_rank_steps_per_s"]) == 2 and all(v > 0 for v in out["per_rank_steps_per_s"])
     assert out["scaling"] == "weak" and out["config"]["parallelism"].startswith("dp2")

@@ -952,3 +952,57 @@ def test_gemm_asm_tiles_refuse(ops):
         ops.gemm(rnd(128, 200, seed=1), rnd(64, 200, seed=2), tile=63)     # K % 64 != 0
     with pytest.raises(RuntimeError, match="asm tiles"):
         ops.gemm(rnd(2 * 12 * 32, 64, seed=1), rnd(64, 192, seed=2), mode=ops.TMIX, tmix=(32, 12), tile=60)    # no TMIX form of the 256 x 256 tile
+
+
+# nearest-2x upsample + 3x3 convolution in its sub-pixel form (AVSD_GEMM_CONV3 with ups = 2, include/avsd.h; FFSpatioTempResUpsample3D,
+# ff_spatio_temp_resnet_3d.py:48-55): four per-parity 2x2 convolutions on the original image, results scattered to the upsampled pixels
+@pytest.mark.parametrize("tile,split", [(0, 1), (4, 1), (6, 1), (9, 1), (11, 1), (13, 1), (17, 1), (20, 1), (24, 1), (25, 1), (30, 1), (38, 1), (6, 2), (9, 4)])
+@pytest.mark.parametrize("n_img,hs,ws,cin,cout", [(3, 4, 4, 64, 64), (24, 8, 8, 128, 320), (2, 16, 16, 320, 640), (5, 3, 5, 64, 128)])
+def test_gemm_conv3_subpixel_upsample(ops, tile, split, n_img, hs, ws, cin, cout):
+    from asva_amd import precision as P
+    from asva_amd.weights import subpixel_conv3x3
+
+    if tile in ops.TILE_BN and cout % ops.TILE_BN[tile]:
+        pytest.skip("column tile wider than a divisor of cout")
+    assert tile == 0 or tile in ops.SUBPIX_TILES
+    if split > (4 * cin) // 64 // 2:
+        pytest.skip("too few K tiles for this split")
+    x = rnd(n_img * hs * ws, cin, seed=1)
+    w = rndf(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5)
+    b = rndf(cout, seed=3)
+    wp = subpixel_conv3x3(w.permute(0, 2, 3, 1).contiguous()).to(P.ACT).contiguous()
+    ref = F.conv2d(F.interpolate(x.float().reshape(n_img, hs, ws, cin).permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest"),
+                   w, b, padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
+    # the upsampled 3x3 convolution on the un-folded weights, through the tap-major tile: same function, other rounding of the weights
+    w9 = w.permute(0, 2, 3, 1).reshape(cout, 9 * cin).to(P.ACT).contiguous()
+    old = ops.gemm(x, w9, bias=b, mode=ops.CONV3, conv=(n_img, hs, ws, 1, 1), out_f32=True)
+    o32 = ops.gemm(x, wp, bias=b.repeat(4), mode=ops.CONV3, conv=(n_img, hs, ws, 1, 2), out_f32=True, tile=tile, split_k=split)
+    assert o32.shape == (n_img * 4 * hs * ws, cout)
+    assert rel_l2(o32, ref) < TOL_BF16 and rel_l2(old, ref) < TOL_BF16
+    # exactly: f32 of the packed operands, parity by parity (a wrong tap, parity or output pixel is an O(1) error)
+    wq = wp.float()
+    xp = F.pad(x.float().reshape(n_img, hs, ws, cin), (0, 0, 1, 1, 1, 1))
+    want = torch.zeros(n_img, 2 * hs, 2 * ws, cout, device=dev())
+    for dy in range(2):
+        for dx in range(2):
+            taps = torch.cat([xp[:, dy + i:dy + i + hs, dx + j:dx + j + ws] for i in range(2) for j in range(2)], -1).reshape(-1, 4 * cin)
+            par = 2 * dy + dx
+            want[:, dy::2, dx::2] = (taps @ wq[par * cout:(par + 1) * cout].T + b).reshape(n_img, hs, ws, cout)
+    assert rel_l2(o32, want.reshape(-1, cout)) < TOL_F32
+    # 16-bit output + f32 master + rest plane through the same scatter
+    out, rest = ops.alloc_planes((n_img * 4 * hs * ws, cout), dev())
+    master = torch.empty((n_img * 4 * hs * ws, cout), dtype=torch.float32, device=dev())
+    ops.gemm(x, wp, bias=b.repeat(4), mode=ops.CONV3, conv=(n_img, hs, ws, 1, 2), out=out, out_rest=rest, master=master, tile=tile, split_k=split)
+    assert torch.equal(master, o32) and torch.equal(out, master.to(P.ACT)) and torch.equal(rest, (master - out.float()).to(P.ACT))
+    # three MFMA passes on (main, rest) planes: the summed weights to 2^-17
+    if tile in (0, 11, 13, 24, 25):
+        wm = subpixel_conv3x3(w.permute(0, 2, 3, 1).contiguous())
+        pw, pwr = ops.alloc_planes(tuple(wm.shape), dev())
+        pw.copy_(wm.to(P.ACT)), pwr.copy_((wm - wm.to(P.ACT).float()).to(P.ACT))
+        xf = rndf(n_img * hs * ws, cin, seed=1)
+        px, pxr = ops.alloc_planes(tuple(xf.shape), dev())
+        px.copy_(xf.to(P.ACT)), pxr.copy_((xf - xf.to(P.ACT).float()).to(P.ACT))
+        ref3 = F.conv2d(F.interpolate((px.double() + pxr.double()).reshape(n_img, hs, ws, cin).permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest"),
+                        w.double(), b.double(), padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
+        o3 = ops.gemm(px, pw, bias=b.repeat(4), mode=ops.CONV3, conv=(n_img, hs, ws, 1, 2), out_f32=True, a_rest=pxr, w_rest=pwr, tile=tile, split_k=split)
+        assert rel_l2(o3, ref3) < 3e-5

@@ -24,7 +24,7 @@ def test_bench_runs_its_collectives_on_rccl_with_one_rank():
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
-    assert out["world_size_rccl"] == 1 and out["n_gpus"] == 1 and out["all_finite"] and out["value"] > 0
+    assert out["world_size"] == 1 and out["n_gpus"] == 1 and out["all_finite"] and out["value"] > 0
 
 
 def test_broadcast_fills_a_meta_replica_and_all_gather_returns_the_row():

@@ -39,8 +39,8 @@ def test_hot_path_kernels_keep_their_accumulators_in_registers(built):
     most-used tiles hold the occupancy their LDS footprint admits"""
     bf = built["bf16"]
     for name, waves in (("conv3r_kernel<256, 160, 4, 1, 3, 4>", 2), ("conv3r_kernel<256, 128, 4, 2, 3, 4>", 2),
-                        ("gemm4_kernel<2, 2, 0, false, 2>", 2), ("gemm4_kernel<1, 2, 0, false, 2>", 2), ("gemm4_kernel<1, 2, 1, false, 2>", 2),
-                        ("gemm4_kernel<1, 1, 1, false, 2>", 3), ("gemm2_kernel<256, 128, 4, 2, 3, 2, 4, false>", 3),
+                        ("gemm4_kernel<2, 2, 0, false, 2, 0>", 2), ("gemm4_kernel<1, 2, 0, false, 2, 0>", 2), ("gemm4_kernel<1, 2, 1, false, 2, 0>", 2),
+                        ("gemm4_kernel<1, 1, 1, false, 2, 0>", 3), ("gemm2_kernel<256, 128, 4, 2, 3, 2, 4, false, 0>", 3),
                         ("attn_kernel<40, 1, false>", 4), ("attn_kernel<80, 1, false>", 3)):
         r = bf[name]
         # (<= 16 B: a couple of address registers parked around the epilogue; the accumulator array itself was 1216 B in round 4)

@@ -6,7 +6,7 @@ made another spill 96 registers.  This tool makes that visible at build time, wi
 
     python tools/resource_usage.py                      # table of both libraries -> stdout
     python tools/resource_usage.py --write              # refresh asva_amd/resource_usage_gfx950.json (the committed table) and
-                                                        #   profiles/r5_resource_usage.txt (the readable dump)
+                                                        #   profiles/r6_resource_usage.txt (the readable dump)
     python tools/resource_usage.py --check              # compare the built libraries with the committed table (exit 1 on a regression)
 
 Source of the numbers: the AMDGPU metadata note of each gfx950 code object embedded in libavsd_hip*.so (llvm-objdump --offloading,
@@ -135,7 +135,7 @@ def main():
     if "--write" in sys.argv:
         with open(TABLE, "w") as f:
             json.dump(built, f, indent=0, sort_keys=True)
-        out = os.path.join(ROOT, "profiles", "r5_resource_usage.txt")
+        out = os.path.join(ROOT, "profiles", "r6_resource_usage.txt")
         with open(out, "w") as f:
             f.write(dump(built))
         print(f"wrote {TABLE} and {out}: " + ", ".join(f"{v} {len(r)} kernels" for v, r in built.items()))

@@ -674,9 +674,10 @@ __global__ __launch_bounds__(64 * (WM * WN + LW), gemm2_min_waves(BM, BN, STAGES
     if constexpr (X2) epilogue_x2<FN, FM, true>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
     else epilogue_each<FN, FM, (64 * (WM * WN + LW) > 512), EPI_SHUF>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
   } else if constexpr (X2) epilogue_x2<FN, FM>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
-  else if constexpr (EX == EPI_REST)     // (a fragment at a time: the rest-plane words need one fragment of temporaries more)
-    epilogue_each<FN, FM, (64 * (WM * WN + LW) > 512), EPI_REST>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
-  else if constexpr (FN * FM >= 10)      // 64 x 160 wave tiles (tile 19): the 10-fragment epilogue is not unrolled -> accumulators in scratch (gemm_common.h)
+  else if constexpr (EX == EPI_REST) {     // the same forms as below with the rest-plane store compiled in
+    if constexpr (FN * FM >= 10) epilogue_each<FN, FM, (64 * (WM * WN + LW) > 512), EPI_REST>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
+    else epilogue<FN, FM, (64 * (WM * WN + LW) > 512), EPI_REST>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
+  } else if constexpr (FN * FM >= 10)      // 64 x 160 wave tiles (tile 19): the 10-fragment epilogue is not unrolled -> accumulators in scratch (gemm_common.h)
     epilogue_each<FN, FM, (64 * (WM * WN + LW) > 512)>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
   else epilogue<FN, FM, (64 * (WM * WN + LW) > 512)>(p, acc, tm * BM + wm * (BM / WM), tn * BN + wn * (BN / WN), lane, bz, pre_ln, pre);
 }
@@ -1074,12 +1075,13 @@ extern "C" int avsd_gemm_bf16(const avsd_gemm_desc* dp, void* stream) {
   }
   if (d.res1) AVSD_REQUIRE(d.ldr1 % 4 == 0, "gemm: ldr1 must be a multiple of 4");
   if (d.res2) AVSD_REQUIRE(d.ldr2 % 4 == 0, "gemm: ldr2 must be a multiple of 4");
-  if (d.out_master) AVSD_REQUIRE(d.ldm % 4 == 0 && d.ldm >= d.N && !(d.flags & AVSD_GEMM_GEGLU),
-                                 "gemm: out_master needs ldm %% 4 == 0, ldm >= N and no GEGLU");
+  if (d.out_master) AVSD_REQUIRE(d.ldm % 4 == 0 && d.ldm >= ((d.mode == AVSD_GEMM_CONV3 && d.ups == 2) ? d.N / 4 : d.N) && !(d.flags & AVSD_GEMM_GEGLU),
+                                 "gemm: out_master needs ldm %% 4 == 0, ldm >= N (ups = 2: cout) and no GEGLU");
   if (d.rowvec) AVSD_REQUIRE(d.rows_per_vec > 0 && d.ldv % 4 == 0, "gemm: rowvec needs rows_per_vec > 0 and ldv %% 4 == 0");
   if (d.flags & AVSD_GEMM_OUT_REST) {
 #ifndef AVSD_F16
-    AVSD_REQUIRE(false, "gemm: OUT_REST is compiled into the IEEE-half build only (libavsd_hip_f16.so: the per-layer precision plan is fp16 storage)");
+    AVSD_REQUIRE(d.mode == AVSD_GEMM_CONV3 && d.ups == 2,
+                 "gemm: OUT_REST is compiled into the IEEE-half build only (libavsd_hip_f16.so: the per-layer precision plan is fp16 storage)");
 #endif
     AVSD_REQUIRE(!(d.flags & (AVSD_GEMM_X2 | AVSD_GEMM_OUT_F32 | AVSD_GEMM_GEGLU)) && d.out_lo != 0 && (d.out_lo & 7) == 0 && d.batch == 1 &&
                      d.tile != AVSD_GEMM_TILE_NSTREAM && !(d.tile >= AVSD_GEMM_TILE_CONV3R_FIRST && d.tile <= AVSD_GEMM_TILE_CONV3R2D_LAST),

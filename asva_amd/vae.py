@@ -25,7 +25,7 @@ from torch import nn
 
 from . import ops
 from .unet import FrozenConfig, _Affine, _Conv, _Linear, _Pk, _Ref
-from .weights import is_twin, pack_conv1x1, pack_conv3x3, pack_linear, rest_of, to_act
+from .weights import is_twin, pack_conv1x1, pack_conv3x3, pack_linear, rest_of, subpixel_conv3x3, to_act
 
 
 class DecoderOutput:
@@ -148,6 +148,9 @@ class _Decoder(nn.Module):
 
 
 # older diffusers checkpoints name the mid-block attention projections differently
+# the upsamplers' nearest-2x + 3x3 convolution as four per-parity 2x2 convolutions on the original image (weights.subpixel_conv3x3): 2.09 of
+# the decoder's 7.47 TFLOP per 12 x 256 x 256 clip become 0.93
+_SUBPIXEL_UPS = os.environ.get("AVSD_SUBPIXEL_UPS", "1") != "0"
 _LEGACY_ATTN = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
 
 
@@ -297,6 +300,16 @@ class AutoencoderKL(nn.Module):
             b[:cout] = m.bias.detach().float()
             return _Pk(w=reg(pack_conv3x3(m.weight.detach().float(), cip, cop)), b=reg(b), cout=cop)
 
+        def conv3_up(m):
+            """an upsampler's convolution (diffusers Upsample2D: nearest 2x, then 3x3 pad 1) in its sub-pixel form — four per-parity 2x2
+            kernels on the original image, 4/9 of the multiplies (weights.subpixel_conv3x3; AVSD_GEMM_CONV3 with ups = 2) — where the
+            kernel's layout rules hold (whole 64-channel K tiles per tap, whole column tiles per parity)"""
+            cout, cin = m.weight.shape[:2]
+            if not _SUBPIXEL_UPS or cout % 64 or cin % 64:
+                return conv3(m)
+            wf = m.weight.detach().float().permute(0, 2, 3, 1).contiguous()
+            return _Pk(w=reg(to_act(subpixel_conv3x3(wf))), b=reg(m.bias.detach().float().repeat(4)), cout=cout, subpixel=True)
+
         def conv1(m):
             cout, cin = m.weight.shape[:2]
             cop, cip = (cout + 7) // 8 * 8, (cin + 7) // 8 * 8
@@ -331,7 +344,7 @@ class AutoencoderKL(nn.Module):
                  mid=[res(d.mid_block.resnets[0]), res(d.mid_block.resnets[1])],
                  attn=attn(d.mid_block.attentions[0]),
                  up=[_Pk(resnets=[res(r) for r in u.resnets],
-                         up=conv3(u.upsamplers[0].conv) if hasattr(u, "upsamplers") else None) for u in d.up_blocks],
+                         up=conv3_up(u.upsamplers[0].conv) if hasattr(u, "upsamplers") else None) for u in d.up_blocks],
                  norm_out=aff(d.conv_norm_out), conv_out=conv3(d.conv_out))
         offs, total = [], 0
         for t in items:
@@ -475,7 +488,7 @@ class AutoencoderKL(nn.Module):
             for r in u.resnets:
                 x = self._res(x, r, n, hw, groups)
             if u.up is not None:
-                x = ops.gemm(x, u.up.w, bias=u.up.b, mode=ops.CONV3, conv=(n, hw[0], hw[1], 1, 1))
+                x = ops.gemm(x, u.up.w, bias=u.up.b, mode=ops.CONV3, conv=(n, hw[0], hw[1], 1, 2 if getattr(u.up, "subpixel", False) else 1))
                 hw = (hw[0] * 2, hw[1] * 2)
         a = ops.groupnorm(x, None, n, hw[0] * hw[1], groups, pk.norm_out.g, pk.norm_out.b, 1e-6, True)
         if postprocess:

@@ -343,10 +343,10 @@ def main():
         Every family's time is the GPU time of its launches of that forward re-issued back to back from ONE captured graph —
         the clock of a rocprofv3 trace of the graph-replayed step; the per-launch event pairs of the eager pass (each carries
         ~4 us of command-processor time) are kept beside it as `ms_event_pairs`.
-        `achieved` counts the multiply-adds the launches EXECUTE at one pass per product (2 M N K of each launch: the sub-pixel
-        upsample convolutions at their 4 taps, a three-pass product of the precision plan once) — the MFMA work a one-pass bf16
-        reference of the same algorithm would need; `achieved_reference_algorithm` prices the same launches as the reference states
-        them (3x3 taps on the upsampled image), `achieved_mfma_issued` counts every MFMA pass issued (three-pass products x 3)."""
+        `achieved` = ALGORITHMIC flops (2 M N K of every product as the reference states it — the upsample convolutions at
+        their 3x3 taps on the upsampled image, a three-pass product of the precision plan once) / time; `achieved_executed` counts the
+        multiply-adds the launches execute at one pass per product (the sub-pixel form of the upsample convolutions runs 4 of the 9
+        taps: 0.23 TFLOP per step fewer), `achieved_mfma_issued` every MFMA pass issued (three-pass products x 3)."""
         timer = ops.KernelTimer()
         ops.set_timer(timer)
         (model or unet).denoise_forward(latents_, torch.full((1,), 501.0, device=device), rep=n_branch)
@@ -361,16 +361,16 @@ def main():
         launches = sum(f["launches"] for f in mm)
         fam_ms = {k: (timer.replay_ms((k,)) if not a.no_graph else v["ms"]) for k, v in fam.items()}
         ms = timer.replay_ms(gemm_fams) if not a.no_graph else ms_events
-        ach = fl / (ms * 1e-3) / 1e12
+        ach = fl_ref / (ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "GEMM family: gemm4_kernel (hand-scheduled tiles) / gemm2_kernel<BM,BN,...,MODE> (linear / temporal-mix / strided and sub-pixel-upsample conv3x3 implicit GEMM) + conv3r_kernel (conv3x3, input tile resident in LDS) + nstream_kernel (GEGLU projections, A band resident), split-K reduce launches included",
                 "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                "achieved_reference_algorithm": round(fl_ref / (ms * 1e-3) / 1e12, 2), "frac_reference_algorithm": round(fl_ref / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                "achieved_executed": round(fl / (ms * 1e-3) / 1e12, 2), "frac_executed": round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                 "achieved_mfma_issued": round(fl_issued / (ms * 1e-3) / 1e12, 2), "frac_mfma_issued": round(fl_issued / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                 "traffic": None, "launches_per_step": launches // clips, "clips_per_forward": clips, "ms_per_step": round(ms / clips, 4),
                 "ms_per_forward": round(ms, 4), "ms_per_step_event_pairs": round(ms_events / clips, 4),
                 "family_ms_sum": round(sum(fam_ms[k] for k in gemm_fams) / clips, 4),
-                "avg_launch_us": round(ms * 1e3 / launches, 2), "tflop_per_step": round(fl / clips / 1e12, 4),
-                "tflop_per_step_reference_algorithm": round(fl_ref / clips / 1e12, 4), "tflop_per_step_mfma_issued": round(fl_issued / clips / 1e12, 4),
+                "avg_launch_us": round(ms * 1e3 / launches, 2), "tflop_per_step": round(fl_ref / clips / 1e12, 4),
+                "tflop_per_step_executed": round(fl / clips / 1e12, 4), "tflop_per_step_mfma_issued": round(fl_issued / clips / 1e12, 4),
                 "algorithmic_bytes_per_launch": round(sum(f["bytes"] for f in mm) / launches)}
         table = {k: {"launches": v["launches"], "ms": round(fam_ms[k], 4), "ms_event_pairs": round(v["ms"], 4),
                      "tflops": round(v["flops"] / (fam_ms[k] * 1e-3) / 1e12, 2) if v["flops"] else None,

@@ -611,3 +611,15 @@ def test_subpixel_upsample_conv_packing_is_the_same_function(hs, ws):
     exact = emu_ops.gemm(rows, wp.to(P.ACT), bias=b.repeat(4), mode=emu_ops.CONV3, conv=(n_img, hs, ws, 1, 2), out_f32=True,
                          a_rest=torch.zeros_like(rows), w_rest=(wp - wp.to(P.ACT).float()).to(P.ACT))
     assert rel_l2(exact.reshape(n_img, 2 * hs, 2 * ws, cout).permute(0, 3, 1, 2), ref.float()) < 3e-5
+
+
+def test_smoke_guard_is_tied_to_measured_values():
+    """__graft_entry__.smoke() asserts the 16-bit modes at `guard` x what they measured on MI355X (tests/golden/smoke_measured.json): the
+    bounds must stay tight (a fixed 3e-2 hid a 23 % drift of the bf16 path in round 5) and smoke() must read them from this file"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "smoke_measured.json")) as f:
+        sm = json.load(f)
+    assert 1.0 < sm["guard"] <= 1.3 and set(sm["measured"]) == {"bf16", "fp16_f32res"}
+    assert sm["guard"] * sm["measured"]["bf16"] < 3e-2 and sm["guard"] * sm["measured"]["fp16_f32res"] < 3e-3
+    src = open(os.path.join(root, "__graft_entry__.py")).read()
+    assert "smoke_measured.json" in src and 'bound("bf16")' in src and 'bound("fp16_f32res")' in src

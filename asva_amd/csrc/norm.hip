@@ -326,6 +326,10 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* S, int l
   }
 }
 
+// (round 6, profiles/r6_pmc_groupnorm.md: the pooled ResBlock norms at 32 x 32 run 512 statistics waves on 1024 SIMDs, 52 vector loads per
+//  wave in dependent batches of 4, 66 % of the wave cycles parked.  Spreading a chunk over up to 1024 threads — 2 batches per thread instead of
+//  8 — was SLOWER on every shape, 20.4 -> 23.3 us for that pair, 12.0 -> 16.3 at 16 x 16: the 32 threads that fold the per-thread sums out of
+//  LDS then walk 4x the positions, serially, behind the barrier.  256 threads stay.)
 void gn_geometry(int C, int* nvec, int* ppb, int* threads) {
   *nvec = C / 8;
   int p = 256 / *nvec;

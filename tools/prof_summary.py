@@ -7,27 +7,28 @@ import sys
 
 
 def short(name: str) -> str:
-    m = re.search(r"gemm2_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?(?:, (\w+))?>", name)
+    modes = ("plain", "tmix", "conv3", "conv3-subpixel")
+    m = re.search(r"gemm2_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?(?:, (\w+))?(?:, (\d+))?>", name)
     if m:
-        bm, bn, wm, wn, st, mode, lw, x2 = m.groups()
-        return (f"gemm2<{bm}x{bn},{wm}x{wn}w{'+' + lw + 'L' if lw and lw != '0' else ''},{st}st,{('plain','tmix','conv3')[int(mode)]}"
-                f"{',x2' if x2 in ('true', '1') else ''}>")
+        bm, bn, wm, wn, st, mode, lw, x2, ex = m.groups()
+        return (f"gemm2<{bm}x{bn},{wm}x{wn}w{'+' + lw + 'L' if lw and lw != '0' else ''},{st}st,{modes[int(mode)]}"
+                f"{',x2' if x2 in ('true', '1') else ''}{',+rest' if ex == '1' else ''}>")
     m = re.search(r"conv3r_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\w+))?>", name)
     if m:
         bm, bn, wm, wn, st, lw, gn = m.groups()
         return f"conv3r<{bm}x{bn},{wm}x{wn}w{'+' + lw + 'L' if lw != '0' else ''},{st}st{',gn' if gn in ('true', '1') else ''}>"
-    m = re.search(r"gemm4_kernel<(\d+), (\d+), (\d+)(?:, (\w+))?(?:, \d+)?>", name)
+    m = re.search(r"gemm4_kernel<(\d+), (\d+), (\d+)(?:, (\w+))?(?:, (\d+))?(?:, (\d+))?>", name)
     if m:
-        fm, fn, mode, x2 = m.groups()
-        return f"gemm4<{64 * int(fm)}x{64 * int(fn)},asm,{('plain','tmix','conv3')[int(mode)]}{',x2' if x2 in ('true', '1') else ''}>"
+        fm, fn, mode, x2, _ns, ex = m.groups()
+        return f"gemm4<{64 * int(fm)}x{64 * int(fn)},asm,{modes[int(mode)]}{',x2' if x2 in ('true', '1') else ''}{',+rest' if ex == '1' else ''}>"
     m = re.search(r"nstream_kernel<(\d+), (\d+), (\w+)>", name)
     if m:
         k, rf, fast = m.groups()
         return f"nstream<A-resident 96 rows x K={k}, W streamed{',geglu' if fast in ('true', '1') else ''}>"
-    m = re.search(r"gemm_kernel<(\d+), (\d+), (\d+)>", name)
+    m = re.search(r"gemm_kernel<(\d+), (\d+), (\d+)(?:, (\d+))?>", name)
     if m:
-        bm, bn, mode = m.groups()
-        return f"gemm1<{bm}x{bn},{('plain','tmix','conv3')[int(mode)]}>"
+        bm, bn, mode, ex = m.groups()
+        return f"gemm1<{bm}x{bn},{modes[int(mode)]}{',+rest' if ex == '1' else ''}>"
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"\(.*", "", name)
     return name[:90]

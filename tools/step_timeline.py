@@ -15,8 +15,8 @@ lo, hi = ends[-nsteps - 1] + 1, ends[-1] + 1
 seg = rows[lo:hi]
 def fam(n):
     k = short(n)
-    for key in ("gemm4", "gemm2", "gemm1", "conv3r", "nstream", "rowpanel", "splitk_reduce", "xattn", "attn_kernel", "tattn", "gn_", "layernorm", "linear_small", "guided", "ncfhw", "rows_to", "timestep"):
-        if key in k: return {"gemm4": "gemm", "gemm2": "gemm", "gemm1": "gemm", "conv3r": "gemm", "nstream": "gemm", "rowpanel": "gemm"}.get(key, key)
+    for key in ("gemm4", "gemm2", "gemm1", "gemm_kernel", "conv3r", "nstream", "rowpanel", "splitk_reduce", "xattn", "attn_kernel", "tattn", "gn_", "layernorm", "linear_small", "guided", "ncfhw", "rows_to", "timestep"):
+        if key in k: return {"gemm4": "gemm", "gemm2": "gemm", "gemm1": "gemm", "gemm_kernel": "gemm", "conv3r": "gemm", "nstream": "gemm", "rowpanel": "gemm"}.get(key, key)
     return k[:30]
 agg = defaultdict(lambda: [0, 0.0]); busy = 0.0; gaps = 0.0; small = [0, 0.0]
 for i, (n, s, e) in enumerate(seg):

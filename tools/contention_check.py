@@ -60,6 +60,21 @@ def main():
             out = unet(xin, 981, t2, a2, audio_attention_mask=audio_segment_mask(12)).sample
             hashes.append(hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:12])
         print("UNet forward hashes:", sorted(set(hashes)), f"over {a.rounds} rounds", flush=True)
+        # the same forward under the per-layer precision plan (round 6: the EPI_REST instantiations, three-pass products writing planes + f32,
+        # the split-precision form of the sub-pixel upsample convolution)
+        from asva_amd import precision as P
+        P.set_plan(True)
+        try:
+            unet._invalidate()
+            ph = []
+            for _ in range(max(2, a.rounds // 2)):
+                out = unet(xin, 981, t2, a2, audio_attention_mask=audio_segment_mask(12)).sample
+                ph.append(hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:12])
+        finally:
+            P.set_plan(False)
+            unet._invalidate()
+        print("UNet forward hashes, precision plan:", sorted(set(ph)), f"over {len(ph)} rounds", flush=True)
+        plan_ok = len(set(ph)) == 1
         # the VAE decode of a clip (resident 3x3 convolution tiles, wide-head attention, GroupNorm at 256 x 256)
         from asva_amd.vae import AutoencoderKL
         torch.manual_seed(1)
@@ -68,7 +83,7 @@ def main():
         z = torch.randn(12, 4, 32, 32, device=dev)
         vh = [hashlib.sha256(vae.decode(z, postprocess="uint8", return_dict=False)[0].cpu().numpy().tobytes()).hexdigest()[:12] for _ in range(max(2, a.rounds // 4))]
         print("VAE decode hashes:", sorted(set(vh)), f"over {len(vh)} rounds", flush=True)
-        ok = total == 0 and len(set(hashes)) == 1 and len(set(vh)) == 1
+        ok = total == 0 and len(set(hashes[:a.rounds])) == 1 and plan_ok and len(set(vh)) == 1
         print("CONTENTION CHECK", "OK" if ok else "FAILED", flush=True)
         return 0 if ok else 1
     finally:
